@@ -1,0 +1,92 @@
+"""ctypes binding of libgroma_hip.so (include/groma_hip.h).
+
+The product path has NO fallback: if the HIP library is missing or an op returns non-zero we raise.
+(The reference raises RuntimeError from TORCH_CHECK inside mmcv `_ext`; same error class here.)
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libgroma_hip.so")
+
+c_void_p = ctypes.c_void_p
+c_int = ctypes.c_int
+c_long = ctypes.c_long
+c_float = ctypes.c_float
+
+
+class GemmDesc(ctypes.Structure):
+    """mirror of `gr_gemm_desc` (include/groma_hip.h)"""
+    _fields_ = [
+        ("A", c_void_p), ("W", c_void_p), ("C", c_void_p),
+        ("bias", c_void_p), ("scale", c_void_p), ("resid", c_void_p), ("ws", c_void_p),
+        ("M", c_int), ("N", c_int), ("K", c_int),
+        ("lda", c_long), ("ldw", c_long), ("ldc", c_long), ("ldr", c_long),
+        ("act", c_int), ("out_f32", c_int), ("splits", c_int),
+        ("conv_H", c_int), ("conv_W", c_int), ("conv_C", c_int),
+        ("conv_seg_stride", c_long),
+        ("resid_mod", c_int),
+        ("c_group", c_int), ("c_group_stride", c_int), ("c_row_off", c_int),
+    ]
+
+
+# name -> argtypes ; every function returns int
+_P, _I, _L, _F = c_void_p, c_int, c_long, c_float
+SIGNATURES = {
+    "gr_abi_version": [],
+    "gr_prof_enable": [_I],
+    "gr_prof_read": [_P, _P, _P],
+    "gr_gemm_bf16": [ctypes.POINTER(GemmDesc), _P],
+    "gr_gemm_f32": [_P, _P, _P, _P, _P, _I, _I, _I, _L, _L, _L, _I, _P],
+    "gr_layernorm": [_P, _P, _P, _P, _P, _I, _I, _L, _L, _F, _I, _I, _P],
+    "gr_rmsnorm": [_P, _P, _P, _I, _I, _L, _L, _F, _I, _P],
+    "gr_attention_bf16": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _F, _P],
+    "gr_qkv_split": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "gr_patchify": [_P, _P, _I, _I, _I, _I, _P],
+    "gr_fill_rows_f32": [_P, _P, _I, _I, _L, _P],
+    "gr_mean4_tokens": [_P, _P, _P, _P, _P, _I, _I, _I, _P],
+    "gr_s2d_pack": [_P, _P, _I, _I, _I, _P],
+    "gr_upsample_coord_pack": [_P, _P, _I, _I, _I, _I, _I, _P],
+    "gr_gn_stats": [_P, _P, _I, _I, _I, _P],
+    "gr_fuse_shuffle": [_P, _P, _I, _P, _P, _I, _P, _P, _I, _P, _P, _P, _I, _I, _I, _F, _I, _I, _P],
+    "gr_cast_f32_bf16": [_P, _P, _P, _L, _P],
+    "gr_add_rows_f32": [_P, _P, _P, _L, _I, _I, _P],
+    "gr_embed_gather": [_P, _P, _P, _P, _L, _I, _I, _I, _P],
+    "gr_scatter_rows_f32": [_P, _P, _P, _L, _I, _P],
+    "gr_argmax_rows": [_P, _P, _I, _I, _L, _P],
+    "gr_msda_f32": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
+    "gr_mha32_f32": [_P, _P, _P, _I, _I, _I, _I, _F, _P],
+    "gr_ddetr_topk_gather": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
+    "gr_box_refine": [_P, _P, _P, _L, _P],
+    "gr_score_fuse": [_P, _P, _P, _L, _L, _P],
+    "gr_topk_desc": [_P, _P, _I, _I, _I, _L, _P],
+    "gr_nms_f32": [_P, _P, _I, _I, _F, _F, _I, _P, _P, _P, _P],
+    "gr_roi_align_pack": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _I, _I, _I, _I, _P],
+}
+
+_lib = None
+
+
+def load():
+    """Load the shared object and type every exported symbol.  Raises if anything is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(groma_amd has no CPU / eager fallback by design)")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.argtypes = argtypes
+        fn.restype = c_int
+    if lib.gr_abi_version() != 1:
+        raise RuntimeError("libgroma_hip.so ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        raise RuntimeError(f"{what} failed with code {rc}" + (" (invalid argument)" if rc == 22 else " (HIP error)"))

@@ -1,0 +1,60 @@
+"""Build libgroma_hip.so (gfx950) in-tree with hipcc.  No cmake, no torch extension machinery:
+the library is a plain C-ABI shared object (include/groma_hip.h) loaded through ctypes."""
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SOURCES = {
+    "gemm_bf16.hip": [],
+    "gemm_f32.hip": [],
+    "attention.hip": [],
+    "norm.hip": [],
+    "pack.hip": [],
+    "ddetr.hip": [],
+    # index-exact kernels: plain IEEE fp32 sequences, no FMA contraction (see oracle/roi_nms.c)
+    "select.hip": ["-ffp-contract=off"],
+    "roi_align.hip": ["-ffp-contract=off"],
+}
+LIB = os.path.join(HERE, "libgroma_hip.so")
+COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=True):
+    hdrs = [os.path.join(HERE, "gr_common.h"), os.path.join(HERE, "..", "..", "include", "groma_hip.h"),
+            os.path.abspath(__file__)]
+    objs, jobs = [], []
+    for src, extra in SOURCES.items():
+        s = os.path.join(HERE, src)
+        o = os.path.join(HERE, src.replace(".hip", ".o"))
+        objs.append(o)
+        if force or _stale(o, [s] + hdrs):
+            jobs.append(["hipcc"] + COMMON + extra + ["-c", s, "-o", o])
+
+    def run(cmd):
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("hipcc failed:\n" + " ".join(cmd) + "\n" + r.stdout + r.stderr)
+        if verbose and r.stderr.strip():
+            print(r.stderr, file=sys.stderr)
+
+    with ThreadPoolExecutor(max_workers=min(8, max(1, len(jobs)))) as ex:
+        list(ex.map(run, jobs))
+    if force or jobs or _stale(LIB, objs):
+        run(["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs)
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)
+    print(LIB)

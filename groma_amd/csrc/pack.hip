@@ -1,0 +1,555 @@
+// Layout / packing kernels around the GEMMs (all HBM-bound, 16-B vector accesses).
+// Each cites the reference statement whose data movement it performs.
+#include "gr_common.h"
+#include "../../include/groma_hip.h"
+
+// ---------------------------------------------------------------------------------------
+// QKV split (+ RoPE) : qkv bf16 [B*L, 3*H*hd] (q|k|v blocks, HF q_proj/k_proj/v_proj order)
+//   -> q  [B,H,L,hd]
+//   -> k  [B,H,kv_stride,hd]   rows pos0..pos0+L-1        (KV cache, post-RoPE)
+//   -> vt [B,H,hd,kv_stride]   columns pos0..pos0+L-1     (V cache, transposed)
+// RoPE as HF LLaMA rotate_half (transformers 4.32 modeling_llama.apply_rotary_pos_emb):
+//   x'[d] = x[d]*cos[d] - x[d+hd/2]*sin[d]        (d <  hd/2)
+//   x'[d] = x[d]*cos[d-hd/2] + x[d-hd/2]*sin[d-hd/2] (d >= hd/2)
+// One block = 64 tokens x one head; V goes through an LDS transpose so Vt rows are written
+// as 128-B segments.
+template <int HD>
+__global__ __launch_bounds__(256) void qkv_split_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ q,
+                                                        bf16_t* __restrict__ k, bf16_t* __restrict__ vt,
+                                                        const float* __restrict__ cosT, const float* __restrict__ sinT,
+                                                        int B, int H, int L, int pos0, int kv_stride) {
+  __shared__ bf16_t vs[64][HD + 2];
+  const int t0 = blockIdx.x * 64;
+  const int h = blockIdx.y, b = blockIdx.z;
+  const int tid = threadIdx.x;
+  const long row_stride = 3L * H * HD;
+  constexpr int HALF = HD / 2;
+  // each thread: token tt = tid/4 (+0), quarter of the head dim per thread
+  const int tt = tid >> 2, part = tid & 3;
+  constexpr int PER = HD / 4;  // elements per thread (16 or 32)
+  const int t = t0 + tt;
+  if (t < L) {
+    const bf16_t* src = qkv + ((long)b * L + t) * row_stride + h * HD;
+    const int pos = pos0 + t;
+    // q and k with optional rope
+    for (int which = 0; which < 2; ++which) {
+      const bf16_t* s = src + (long)which * H * HD;
+      bf16_t* dst = which == 0 ? q + (((long)b * H + h) * L + t) * HD : k + (((long)b * H + h) * kv_stride + pos) * HD;
+#pragma unroll
+      for (int e = 0; e < PER; e += 8) {
+        const int d = part * PER + e;
+        const bf16x8 x = *(const bf16x8*)(s + d);
+        if (cosT) {
+          const int dp = d < HALF ? d + HALF : d - HALF;  // partner
+          const bf16x8 y = *(const bf16x8*)(s + dp);
+          const int dc = d < HALF ? d : d - HALF;
+          const float sgn = d < HALF ? -1.f : 1.f;
+          union { bf16x8 v; uint32_t u[4]; } o;
+#pragma unroll
+          for (int i = 0; i < 8; i += 2) {
+            const float c0 = cosT[(long)pos * HALF + dc + i], s0 = sinT[(long)pos * HALF + dc + i];
+            const float c1 = cosT[(long)pos * HALF + dc + i + 1], s1 = sinT[(long)pos * HALF + dc + i + 1];
+            const float r0 = bf2f((bf16_t)x[i]) * c0 + sgn * bf2f((bf16_t)y[i]) * s0;
+            const float r1 = bf2f((bf16_t)x[i + 1]) * c1 + sgn * bf2f((bf16_t)y[i + 1]) * s1;
+            o.u[i >> 1] = pack2bf(r0, r1);
+          }
+          *(bf16x8*)(dst + d) = o.v;
+        } else {
+          *(bf16x8*)(dst + d) = x;
+        }
+      }
+    }
+    // v -> LDS
+    const bf16_t* s = src + 2L * H * HD;
+#pragma unroll
+    for (int e = 0; e < PER; ++e) vs[tt][part * PER + e] = s[part * PER + e];
+  } else {
+#pragma unroll
+    for (int e = 0; e < PER; ++e) vs[tt][part * PER + e] = 0;
+  }
+  __syncthreads();
+  // transpose out: thread -> (d, 16-token segment)
+  for (int idx = tid; idx < HD * 4; idx += 256) {
+    const int d = idx >> 2, seg = idx & 3;
+    bf16_t* dst = vt + (((long)b * H + h) * HD + d) * kv_stride + pos0 + t0 + seg * 16;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      if (t0 + seg * 16 + i < L) dst[i] = vs[seg * 16 + i][d];
+    }
+  }
+}
+
+extern "C" int gr_qkv_split(const void* qkv, void* q, void* k, void* vt, const float* cosT, const float* sinT, int B,
+                            int H, int L, int head_dim, int pos0, int kv_stride, hipStream_t stream) {
+  if (!qkv || !q || !k || !vt || B <= 0 || H <= 0 || L <= 0) return GR_EINVAL;
+  if ((cosT == nullptr) != (sinT == nullptr)) return GR_EINVAL;
+  dim3 grid(gr_cdiv(L, 64), H, B);
+  if (head_dim == 128)
+    hipLaunchKernelGGL(qkv_split_kernel<128>, grid, dim3(256), 0, stream, (const bf16_t*)qkv, (bf16_t*)q, (bf16_t*)k,
+                       (bf16_t*)vt, cosT, sinT, B, H, L, pos0, kv_stride);
+  else if (head_dim == 64)
+    hipLaunchKernelGGL(qkv_split_kernel<64>, grid, dim3(256), 0, stream, (const bf16_t*)qkv, (bf16_t*)q, (bf16_t*)k,
+                       (bf16_t*)vt, cosT, sinT, B, H, L, pos0, kv_stride);
+  else return GR_EINVAL;
+  GR_CHECK_LAUNCH();
+  return GR_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// Patchify for the DINOv2 patch-embedding conv (kernel = stride = P): images f32 NCHW
+// [B,3,S,S] -> A bf16 [B*G*G, Kpad], k = c*P*P + ky*P + kx (the Conv2d weight flattening),
+// zero padded to Kpad.   (HF Dinov2PatchEmbeddings.projection)
+__global__ void patchify_kernel(const float* __restrict__ img, bf16_t* __restrict__ out, int B, int S, int P, int G,
+                                int Kpad) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long total = (long)B * G * G * Kpad;
+  if (idx >= total) return;
+  const int kk = (int)(idx % Kpad);
+  const long m = idx / Kpad;
+  const int K = 3 * P * P;
+  float v = 0.f;
+  if (kk < K) {
+    const int c = kk / (P * P), r = kk % (P * P);
+    const int ky = r / P, kx = r % P;
+    const int gx = (int)(m % G), gy = (int)((m / G) % G), b = (int)(m / ((long)G * G));
+    v = img[(((long)b * 3 + c) * S + gy * P + ky) * S + gx * P + kx];
+  }
+  out[idx] = f2bf(v);
+}
+
+extern "C" int gr_patchify(const float* images, void* out, int B, int S, int P, int Kpad, hipStream_t stream) {
+  if (!images || !out || B <= 0 || S % P != 0 || Kpad < 3 * P * P) return GR_EINVAL;
+  const int G = S / P;
+  const long total = (long)B * G * G * Kpad;
+  hipLaunchKernelGGL(patchify_kernel, dim3(gr_cdiv(total, 256)), dim3(256), 0, stream, images, (bf16_t*)out, B, S, P, G,
+                     Kpad);
+  GR_CHECK_LAUNCH();
+  return GR_OK;
+}
+
+// dst[r*ld_dst .. +C] = src[0..C) for r in [0,rows)  (CLS+pos[0] row of every image)
+__global__ void fill_rows_kernel(const float* __restrict__ src, float* __restrict__ dst, int rows, int C, long ld_dst) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long)rows * C) return;
+  const int c = (int)(idx % C);
+  const long r = idx / C;
+  dst[r * ld_dst + c] = src[c];
+}
+extern "C" int gr_fill_rows_f32(const float* src, float* dst, int rows, int C, long ld_dst, hipStream_t stream) {
+  if (!src || !dst || rows <= 0 || C <= 0) return GR_EINVAL;
+  hipLaunchKernelGGL(fill_rows_kernel, dim3(gr_cdiv((long)rows * C, 256)), dim3(256), 0, stream, src, dst, rows, C,
+                     ld_dst);
+  GR_CHECK_LAUNCH();
+  return GR_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// mean of the last 4 ViT hidden states, CLS dropped (groma/model/groma.py:240-241):
+// h[i]: f32 [B, T, C] -> out f32 [B*(T-1), C]
+__global__ void mean4_kernel(const float* __restrict__ h0, const float* __restrict__ h1, const float* __restrict__ h2,
+                             const float* __restrict__ h3, float* __restrict__ out, int B, int T, int C) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;  // float4 index
+  const int c4 = C >> 2;
+  const long total = (long)B * (T - 1) * c4;
+  if (idx >= total) return;
+  const int c = (int)(idx % c4) << 2;
+  const long m = idx / c4;
+  const int b = (int)(m / (T - 1)), tkn = (int)(m % (T - 1));
+  const long off = ((long)b * T + 1 + tkn) * C + c;
+  f32x4 s = *(const f32x4*)(h0 + off);
+  s += *(const f32x4*)(h1 + off);
+  s += *(const f32x4*)(h2 + off);
+  s += *(const f32x4*)(h3 + off);
+  *(f32x4*)(out + m * C + c) = s * 0.25f;
+}
+extern "C" int gr_mean4_tokens(const float* h0, const float* h1, const float* h2, const float* h3, float* out, int B,
+                               int T, int C, hipStream_t stream) {
+  if (!h0 || !h1 || !h2 || !h3 || !out || C % 4 != 0) return GR_EINVAL;
+  const long total = (long)B * (T - 1) * (C >> 2);
+  hipLaunchKernelGGL(mean4_kernel, dim3(gr_cdiv(total, 256)), dim3(256), 0, stream, h0, h1, h2, h3, out, B, T, C);
+  GR_CHECK_LAUNCH();
+  return GR_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// 2x2 space-to-depth of the last hidden state (groma/model/groma.py:227-237):
+// h f32 [B, 1+G*G, C] -> out bf16 [B*(G/2)^2, 4C], channel blocks (0::2,0::2),(1::2,0::2),(0::2,1::2),(1::2,1::2)
+__global__ void s2d_kernel(const float* __restrict__ h, bf16_t* __restrict__ out, int B, int G, int C) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;  // 4-element index
+  const int c4 = C;  // 4C/4
+  const int G2 = G >> 1;
+  const long total = (long)B * G2 * G2 * c4;
+  if (idx >= total) return;
+  const int cc = (int)(idx % c4) << 2;  // channel in [0,4C)
+  const long m = idx / c4;
+  const int j = (int)(m % G2), i = (int)((m / G2) % G2), b = (int)(m / ((long)G2 * G2));
+  const int blk = cc / C, c = cc % C;
+  const int dy = blk & 1, dx = blk >> 1;  // blocks: (0,0),(1,0),(0,1),(1,1) as (row offset, col offset)
+  const int y = 2 * i + dy, x = 2 * j + dx;
+  const f32x4 v = *(const f32x4*)(h + ((long)b * (1 + G * G) + 1 + y * G + x) * C + c);
+  uint2 pk;
+  pk.x = pack2bf(v[0], v[1]);
+  pk.y = pack2bf(v[2], v[3]);
+  *(uint2*)(out + m * 4 * C + cc) = pk;
+}
+extern "C" int gr_s2d_pack(const float* h, void* out, int B, int G, int C, hipStream_t stream) {
+  if (!h || !out || G % 2 != 0 || C % 4 != 0) return GR_EINVAL;
+  const long total = (long)B * (G / 2) * (G / 2) * C;
+  hipLaunchKernelGGL(s2d_kernel, dim3(gr_cdiv(total, 256)), dim3(256), 0, stream, h, (bf16_t*)out, B, G, C);
+  GR_CHECK_LAUNCH();
+  return GR_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// Region-encoder input: bilinear (align_corners=True) upsample of one ViT hidden state from
+// GxG to HoxHo (groma/model/roi_align.py:220-227) + the two coordinate channels x,y in [-1,1]
+// (roi_align.py:118-126,181-187), packed as the A operand of the 1x1 input conv:
+// h f32 [B, 1+G*G, C] -> out bf16 [B*Ho*Ho, Cpad]   (channels C..C+1 = x,y ; rest zero)
+__global__ void upsample_coord_kernel(const float* __restrict__ h, bf16_t* __restrict__ out, int B, int G, int Ho, int C,
+                                      int Cpad) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;  // 4-channel index
+  const int c4 = Cpad >> 2;
+  const long total = (long)B * Ho * Ho * c4;
+  if (idx >= total) return;
+  const int c = (int)(idx % c4) << 2;
+  const long m = idx / c4;
+  const int x = (int)(m % Ho), y = (int)((m / Ho) % Ho), b = (int)(m / ((long)Ho * Ho));
+  f32x4 v = {0.f, 0.f, 0.f, 0.f};
+  if (c < C) {
+    // align_corners=True source coordinate (torch area_pixel_compute_source_index)
+    const float sc = Ho > 1 ? (float)(G - 1) / (float)(Ho - 1) : 0.f;
+    const float sy = sc * y, sx = sc * x;
+    int y0 = (int)sy, x0 = (int)sx;
+    const int y1 = y0 + (y0 < G - 1 ? 1 : 0), x1 = x0 + (x0 < G - 1 ? 1 : 0);
+    const float ly = sy - y0, lx = sx - x0;
+    const float hy = 1.f - ly, hx = 1.f - lx;
+    const float* base = h + ((long)b * (1 + G * G) + 1) * C + c;
+    const f32x4 v00 = *(const f32x4*)(base + (long)(y0 * G + x0) * C);
+    const f32x4 v01 = *(const f32x4*)(base + (long)(y0 * G + x1) * C);
+    const f32x4 v10 = *(const f32x4*)(base + (long)(y1 * G + x0) * C);
+    const f32x4 v11 = *(const f32x4*)(base + (long)(y1 * G + x1) * C);
+    v = hy * (hx * v00 + lx * v01) + ly * (hx * v10 + lx * v11);
+  } else if (c == C) {
+    // torch.linspace(-1, 1, n): start + i*step for the first half, end - (n-1-i)*step for the second
+    const float step = Ho > 1 ? 2.f / (float)(Ho - 1) : 0.f;
+    v[0] = x < Ho / 2 ? -1.f + step * x : 1.f - step * (Ho - 1 - x);
+    v[1] = y < Ho / 2 ? -1.f + step * y : 1.f - step * (Ho - 1 - y);
+  }
+  uint2 pk;
+  pk.x = pack2bf(v[0], v[1]);
+  pk.y = pack2bf(v[2], v[3]);
+  *(uint2*)(out + m * Cpad + c) = pk;
+}
+extern "C" int gr_upsample_coord_pack(const float* h, void* out, int B, int G, int Ho, int C, int Cpad,
+                                      hipStream_t stream) {
+  if (!h || !out || C % 4 != 0 || Cpad % 4 != 0 || Cpad < C + 2) return GR_EINVAL;
+  const long total = (long)B * Ho * Ho * (Cpad >> 2);
+  hipLaunchKernelGGL(upsample_coord_kernel, dim3(gr_cdiv(total, 256)), dim3(256), 0, stream, h, (bf16_t*)out, B, G, Ho,
+                     C, Cpad);
+  GR_CHECK_LAUNCH();
+  return GR_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// GroupNorm statistics of a conv output: x bf16 [imgs*HW, C] -> sums f32 [imgs, C, 2] (sum, sumsq), atomics.
+// (mmcv ConvModule norm = GN(64 groups), mmcv/cnn/bricks/conv_module.py:196-206)
+__global__ __launch_bounds__(256) void gn_stats_kernel(const bf16_t* __restrict__ x, float* __restrict__ sums, int HW,
+                                                       int C, int rows_per_block) {
+  const int img = blockIdx.z;
+  const int cblk = blockIdx.y;  // 64-channel slab
+  const int r0 = blockIdx.x * rows_per_block;
+  const int tid = threadIdx.x;
+  const int ch = (tid & 7) * 8;  // 8 channels per thread
+  float s[8], q[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) s[i] = q[i] = 0.f;
+  const int rend = min(HW, r0 + rows_per_block);
+  for (int r = r0 + (tid >> 3); r < rend; r += 32) {
+    const bf16x8 v = *(const bf16x8*)(x + ((long)img * HW + r) * C + cblk * 64 + ch);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const float f = bf2f((bf16_t)v[i]);
+      s[i] += f;
+      q[i] += f * f;
+    }
+  }
+  // reduce over the 32 row-lanes sharing (tid&7): shuffle within wave over bits 3..5, then LDS across 4 waves
+  __shared__ float red[4][8][16];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+#pragma unroll
+    for (int o = 8; o < 64; o <<= 1) {
+      s[i] += __shfl_xor(s[i], o, 64);
+      q[i] += __shfl_xor(q[i], o, 64);
+    }
+  }
+  const int lane = tid & 63, wave = tid >> 6;
+  if (lane < 8) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      red[wave][lane][i] = s[i];
+      red[wave][lane][8 + i] = q[i];
+    }
+  }
+  __syncthreads();
+  if (tid < 128) {
+    const int cc = tid >> 1, which = tid & 1;  // channel within slab 0..63
+    const int l8 = cc >> 3, i = cc & 7;
+    float t = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) t += red[w][l8][which * 8 + i];
+    atomicAdd(sums + ((long)img * C + cblk * 64 + cc) * 2 + which, t);
+  }
+}
+extern "C" int gr_gn_stats(const void* x, float* sums, int imgs, int HW, int C, hipStream_t stream) {
+  if (!x || !sums || C % 64 != 0) return GR_EINVAL;
+  const int rpb = 512;
+  dim3 grid(gr_cdiv(HW, rpb), C / 64, imgs);
+  hipLaunchKernelGGL(gn_stats_kernel, grid, dim3(256), 0, stream, (const bf16_t*)x, sums, HW, C, rpb);
+  GR_CHECK_LAUNCH();
+  return GR_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// GroupNorm + ReLU + cross-level channel shuffle (groma/model/roi_align.py:150-178), producing the
+// zero-bordered NHWC bf16 input of the next 3x3 conv for ONE target level:
+//   ch [0, C/2)        <- tar   [0, C/2)       same pixel
+//   ch [C/2, 3C/4)     <- top   [3C/4, C)      bilinear align_corners=True resize to the target size
+//   ch [3C/4, C)       <- down  [C/2, 3C/4)    bilinear align_corners=True resize to the target size
+// Each source is relu(gn(conv_out)) when its sums pointer is non-null, else the raw map (round 0).
+// shuffle==0: plain relu(gn(.)) of tar for all channels (final round -> RoIAlign input, pad=0 layout allowed).
+struct ShufSrc {
+  const bf16_t* x;    // [imgs*S*S, C]
+  const float* sums;  // [imgs, C, 2] or null
+  int S;
+};
+__device__ __forceinline__ void gn_coeff(const ShufSrc& s, const float* gamma, const float* beta, int img, int c, int C,
+                                         int cpg, float eps, float* a, float* bb) {
+  // 8 consecutive channels starting at c: per-channel scale/shift so y = x*a + b
+  const float n = (float)s.S * (float)s.S * (float)cpg;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int ch = c + i;
+    const int g0 = (ch / cpg) * cpg;
+    float sm = 0.f, sq = 0.f;
+    for (int k = 0; k < cpg; ++k) {
+      sm += s.sums[((long)img * C + g0 + k) * 2];
+      sq += s.sums[((long)img * C + g0 + k) * 2 + 1];
+    }
+    const float mean = sm / n;
+    float var = sq / n - mean * mean;
+    var = fmaxf(var, 0.f);
+    const float rstd = 1.0f / sqrtf(var + eps);
+    a[i] = rstd * gamma[ch];
+    bb[i] = beta[ch] - mean * rstd * gamma[ch];
+  }
+}
+__device__ __forceinline__ void load8(const ShufSrc& s, bool norm, const float* a, const float* bb, int img, int y, int x,
+                                      int c, int C, float* o) {
+  const bf16x8 v = *(const bf16x8*)(s.x + (((long)img * s.S + y) * s.S + x) * C + c);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    float f = bf2f((bf16_t)v[i]);
+    if (norm) f = fmaxf(f * a[i] + bb[i], 0.f);
+    o[i] = f;
+  }
+}
+__global__ __launch_bounds__(256) void fuse_shuffle_kernel(ShufSrc tar, ShufSrc top, ShufSrc down,
+                                                           const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, bf16_t* __restrict__ out,
+                                                           int imgs, int C, int cpg, float eps, int shuffle, int pad) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;  // 8-channel chunk
+  const int c8 = C >> 3;
+  const int S = tar.S;
+  const long total = (long)imgs * S * S * c8;
+  if (idx >= total) return;
+  const int c = (int)(idx % c8) << 3;
+  const long m = idx / c8;
+  const int x = (int)(m % S), y = (int)((m / S) % S), img = (int)(m / ((long)S * S));
+  float o[8];
+  float a[8], bb[8];
+  if (!shuffle || c < C / 2) {
+    const bool norm = tar.sums != nullptr;
+    if (norm) gn_coeff(tar, gamma, beta, img, c, C, cpg, eps, a, bb);
+    load8(tar, norm, a, bb, img, y, x, c, C, o);
+  } else {
+    const bool is_top = c < 3 * C / 4;
+    const ShufSrc& src = is_top ? top : down;
+    const int sc = is_top ? c + C / 4 : c - C / 4;  // source channel
+    const bool norm = src.sums != nullptr;
+    if (norm) gn_coeff(src, gamma, beta, img, sc, C, cpg, eps, a, bb);
+    const int Ss = src.S;
+    if (Ss == S) {
+      load8(src, norm, a, bb, img, y, x, sc, C, o);
+    } else {
+      const float scl = S > 1 ? (float)(Ss - 1) / (float)(S - 1) : 0.f;
+      const float sy = scl * y, sx = scl * x;
+      const int y0 = (int)sy, x0 = (int)sx;
+      const int y1 = y0 + (y0 < Ss - 1 ? 1 : 0), x1 = x0 + (x0 < Ss - 1 ? 1 : 0);
+      const float ly = sy - y0, lx = sx - x0, hy = 1.f - ly, hx = 1.f - lx;
+      float v00[8], v01[8], v10[8], v11[8];
+      load8(src, norm, a, bb, img, y0, x0, sc, C, v00);
+      load8(src, norm, a, bb, img, y0, x1, sc, C, v01);
+      load8(src, norm, a, bb, img, y1, x0, sc, C, v10);
+      load8(src, norm, a, bb, img, y1, x1, sc, C, v11);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) o[i] = hy * (hx * v00[i] + lx * v01[i]) + ly * (hx * v10[i] + lx * v11[i]);
+    }
+  }
+  union { bf16x8 v; uint32_t u[4]; } pk;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) pk.u[i] = pack2bf(o[2 * i], o[2 * i + 1]);
+  const int Sp = S + 2 * pad;
+  *(bf16x8*)(out + (((long)img * Sp + y + pad) * Sp + x + pad) * C + c) = pk.v;
+}
+extern "C" int gr_fuse_shuffle(const void* tar, const float* tar_sums, int tarS, const void* top, const float* top_sums,
+                               int topS, const void* down, const float* down_sums, int downS, const float* gamma,
+                               const float* beta, void* out, int imgs, int C, int groups, float eps, int shuffle, int pad,
+                               hipStream_t stream) {
+  if (!tar || !out || C % 32 != 0 || groups <= 0 || C % groups != 0) return GR_EINVAL;
+  if (shuffle && (!top || !down)) return GR_EINVAL;
+  if ((tar_sums || top_sums || down_sums) && (!gamma || !beta)) return GR_EINVAL;
+  ShufSrc a{(const bf16_t*)tar, tar_sums, tarS}, b{(const bf16_t*)top, top_sums, topS},
+      c{(const bf16_t*)down, down_sums, downS};
+  const long total = (long)imgs * tarS * tarS * (C >> 3);
+  hipLaunchKernelGGL(fuse_shuffle_kernel, dim3(gr_cdiv(total, 256)), dim3(256), 0, stream, a, b, c, gamma, beta,
+                     (bf16_t*)out, imgs, C, C / groups, eps, shuffle, pad);
+  GR_CHECK_LAUNCH();
+  return GR_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// out bf16 = a (+ b)   (f32 -> bf16 cast of a GEMM A operand)
+__global__ void cast_add_kernel(const float* __restrict__ a, const float* __restrict__ b, bf16_t* __restrict__ out,
+                                long n4) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n4) return;
+  f32x4 v = *(const f32x4*)(a + idx * 4);
+  if (b) v += *(const f32x4*)(b + idx * 4);
+  uint2 pk;
+  pk.x = pack2bf(v[0], v[1]);
+  pk.y = pack2bf(v[2], v[3]);
+  *(uint2*)(out + idx * 4) = pk;
+}
+extern "C" int gr_cast_f32_bf16(const float* a, const float* b, void* out, long n, hipStream_t stream) {
+  if (!a || !out || n <= 0 || n % 4 != 0) return GR_EINVAL;
+  hipLaunchKernelGGL(cast_add_kernel, dim3(gr_cdiv(n / 4, 256)), dim3(256), 0, stream, a, b, (bf16_t*)out, n / 4);
+  GR_CHECK_LAUNCH();
+  return GR_OK;
+}
+
+// out f32 [rows, C] = a[rows, C] + b[(row % b_mod), C]
+__global__ void add_rows_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out,
+                                long rows, int C, int b_mod) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int c4 = C >> 2;
+  if (idx >= rows * c4) return;
+  const int c = (int)(idx % c4) << 2;
+  const long r = idx / c4;
+  const long rb = b_mod > 0 ? r % b_mod : r;
+  *(f32x4*)(out + r * C + c) = *(const f32x4*)(a + r * C + c) + *(const f32x4*)(b + rb * C + c);
+}
+extern "C" int gr_add_rows_f32(const float* a, const float* b, float* out, long rows, int C, int b_mod,
+                               hipStream_t stream) {
+  if (!a || !b || !out || rows <= 0 || C % 4 != 0) return GR_EINVAL;
+  hipLaunchKernelGGL(add_rows_kernel, dim3(gr_cdiv(rows * (C >> 2), 256)), dim3(256), 0, stream, a, b, out, rows, C,
+                     b_mod);
+  GR_CHECK_LAUNCH();
+  return GR_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// Split-vocabulary embedding lookup (groma/model/groma.py:165-174): ids < V0 -> table0, else table1[id - V0]
+// tables bf16, out f32 [n, C]
+__global__ void embed_gather_kernel(const long* __restrict__ ids, const bf16_t* __restrict__ t0,
+                                    const bf16_t* __restrict__ t1, float* __restrict__ out, long n, int C, int V0,
+                                    int V1) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;  // 8-chunk
+  const int c8 = C >> 3;
+  if (idx >= n * c8) return;
+  const int c = (int)(idx % c8) << 3;
+  const long r = idx / c8;
+  long id = ids[r];
+  const bf16_t* src;
+  if (id >= V0) {
+    id -= V0;
+    if (id >= V1) id = V1 - 1;
+    src = t1 + id * C + c;
+  } else {
+    if (id < 0) id = 0;
+    src = t0 + id * C + c;
+  }
+  const bf16x8 v = *(const bf16x8*)src;
+  float* o = out + r * C + c;
+  f32x4 lo, hi;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    lo[i] = bf2f((bf16_t)v[i]);
+    hi[i] = bf2f((bf16_t)v[4 + i]);
+  }
+  *(f32x4*)o = lo;
+  *(f32x4*)(o + 4) = hi;
+}
+extern "C" int gr_embed_gather(const long* ids, const void* table0, const void* table1, float* out, long n, int C,
+                               int V0, int V1, hipStream_t stream) {
+  if (!ids || !table0 || !table1 || !out || n <= 0 || C % 8 != 0) return GR_EINVAL;
+  hipLaunchKernelGGL(embed_gather_kernel, dim3(gr_cdiv(n * (C >> 3), 256)), dim3(256), 0, stream, ids,
+                     (const bf16_t*)table0, (const bf16_t*)table1, out, n, C, V0, V1);
+  GR_CHECK_LAUNCH();
+  return GR_OK;
+}
+
+// dst[row_idx[r], :] = src[r, :]   (masked_scatter_ of image / region features, groma.py:364-369)
+__global__ void scatter_rows_kernel(const float* __restrict__ src, const int* __restrict__ row_idx,
+                                    float* __restrict__ dst, long n, int C) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int c4 = C >> 2;
+  if (idx >= n * c4) return;
+  const int c = (int)(idx % c4) << 2;
+  const long r = idx / c4;
+  *(f32x4*)(dst + (long)row_idx[r] * C + c) = *(const f32x4*)(src + r * C + c);
+}
+extern "C" int gr_scatter_rows_f32(const float* src, const int* row_idx, float* dst, long n, int C, hipStream_t stream) {
+  if (!src || !row_idx || !dst || C % 4 != 0) return GR_EINVAL;
+  if (n <= 0) return GR_OK;
+  hipLaunchKernelGGL(scatter_rows_kernel, dim3(gr_cdiv(n * (C >> 2), 256)), dim3(256), 0, stream, src, row_idx, dst, n,
+                     C);
+  GR_CHECK_LAUNCH();
+  return GR_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// Greedy next-token: argmax over logits f32 [rows, ld] restricted to [0, V); first maximal index wins.
+__global__ __launch_bounds__(256) void argmax_kernel(const float* __restrict__ x, long* __restrict__ out, int V, long ld) {
+  const int row = blockIdx.x;
+  const float* xr = x + (long)row * ld;
+  float best = -INFINITY;
+  int bi = 0x7fffffff;
+  for (int i = threadIdx.x; i < V; i += 256) {
+    const float v = xr[i];
+    if (v > best || (v == best && i < bi)) { best = v; bi = i; }
+  }
+  __shared__ float sv[256];
+  __shared__ int si[256];
+  sv[threadIdx.x] = best;
+  si[threadIdx.x] = bi;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (threadIdx.x < s) {
+      const float ov = sv[threadIdx.x + s];
+      const int oi = si[threadIdx.x + s];
+      if (ov > sv[threadIdx.x] || (ov == sv[threadIdx.x] && oi < si[threadIdx.x])) {
+        sv[threadIdx.x] = ov;
+        si[threadIdx.x] = oi;
+      }
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[row] = si[0];
+}
+extern "C" int gr_argmax_rows(const float* x, long* out, int rows, int V, long ld, hipStream_t stream) {
+  if (!x || !out || rows <= 0 || V <= 0) return GR_EINVAL;
+  hipLaunchKernelGGL(argmax_kernel, dim3(rows), dim3(256), 0, stream, x, out, V, ld);
+  GR_CHECK_LAUNCH();
+  return GR_OK;
+}

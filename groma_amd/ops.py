@@ -1,0 +1,314 @@
+"""Tensor-level wrappers over the C ABI (include/groma_hip.h).
+
+torch is used for device memory and the current stream only; every computation below is a HIP kernel
+in groma_amd/csrc.  All wrappers raise (TypeError / RuntimeError) on bad inputs -- there is no eager path.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import GemmDesc
+
+BF16, F32, I32, I64 = torch.bfloat16, torch.float32, torch.int32, torch.int64
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _chk(t, dtype, name):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise TypeError(f"{name}: expected a CUDA/HIP tensor")
+    if t.dtype != dtype:
+        raise TypeError(f"{name}: expected {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise TypeError(f"{name}: must be contiguous")
+    return t
+
+
+def gemm(a, w, *, out=None, bias=None, scale=None, resid=None, act=0, out_f32=False, splits=1, ws=None,
+         M=None, lda=None, conv=None, resid_mod=0, row_map=None, ldc=None, ldr=None):
+    """out[M,N] = epilogue(a[M,K] @ w[N,K]^T).  `conv=(imgs,H,W,C,seg_stride)` switches A to the implicit
+    3x3 gather over zero-bordered NHWC maps (then M = imgs*H*W, K = w.shape[1])."""
+    lib = _lib.load()
+    _chk(a, BF16, "a"); _chk(w, BF16, "w")
+    N, K = w.shape
+    d = GemmDesc()
+    if conv is not None:
+        imgs, H, W_, C, seg = conv
+        M = imgs * H * W_
+        d.conv_H, d.conv_W, d.conv_C, d.conv_seg_stride = H, W_, C, seg
+        d.lda = 0
+    else:
+        if M is None:
+            M = a.numel() // a.shape[-1]
+        d.lda = lda if lda is not None else a.shape[-1]
+        if a.shape[-1] != K and lda is None:
+            raise ValueError(f"gemm: K mismatch {a.shape[-1]} vs {K}")
+    n_out = N // 2 if act == 3 else N
+    if out is None:
+        out = torch.empty((M, n_out), dtype=F32 if out_f32 else BF16, device=a.device)
+    _chk(out, F32 if out_f32 else BF16, "out")
+    if splits > 1 and ws is None:
+        ws = torch.empty((splits, M, N), dtype=F32, device=a.device)
+    d.A, d.W, d.C = a.data_ptr(), w.data_ptr(), out.data_ptr()
+    d.bias = _chk(bias, F32, "bias").data_ptr() if bias is not None else None
+    d.scale = _chk(scale, F32, "scale").data_ptr() if scale is not None else None
+    d.resid = _chk(resid, F32, "resid").data_ptr() if resid is not None else None
+    d.ws = ws.data_ptr() if ws is not None else None
+    d.M, d.N, d.K = M, N, K
+    d.ldw = w.stride(0)
+    d.ldc = ldc if ldc is not None else out.shape[-1]
+    d.ldr = ldr if ldr is not None else (resid.shape[-1] if resid is not None else 0)
+    d.act, d.out_f32, d.splits = act, int(out_f32), splits
+    d.resid_mod = resid_mod
+    if row_map is not None:
+        d.c_group, d.c_group_stride, d.c_row_off = row_map
+    _lib.check(lib.gr_gemm_bf16(ctypes.byref(d), _stream()), "gr_gemm_bf16")
+    return out
+
+
+def gemm_f32(a, w, *, bias=None, resid=None, act=0, out=None, M=None, lda=None, ldc=None):
+    lib = _lib.load()
+    _chk(a, F32, "a"); _chk(w, F32, "w")
+    N, K = w.shape
+    if M is None:
+        M = a.numel() // a.shape[-1]
+    lda = lda if lda is not None else a.shape[-1]
+    if out is None:
+        out = torch.empty((M, N), dtype=F32, device=a.device)
+    ldc = ldc if ldc is not None else out.shape[-1]
+    _lib.check(lib.gr_gemm_f32(_p(a), _p(w), _p(out), _p(bias), _p(resid), M, N, K, lda, w.stride(0), ldc, act,
+                               _stream()), "gr_gemm_f32")
+    return out
+
+
+def layernorm(x, gamma, beta, eps, *, add=None, out_bf16=False, relu_in=False, out=None):
+    lib = _lib.load()
+    _chk(x, F32, "x")
+    C = x.shape[-1]
+    rows = x.numel() // C
+    if out is None:
+        out = torch.empty(x.shape, dtype=BF16 if out_bf16 else F32, device=x.device)
+    _lib.check(lib.gr_layernorm(_p(x), _p(add), _p(gamma), _p(beta), _p(out), rows, C, C, C, eps, int(out_bf16),
+                                int(relu_in), _stream()), "gr_layernorm")
+    return out
+
+
+def rmsnorm(x, gamma, eps, *, out_bf16=True, out=None):
+    lib = _lib.load()
+    _chk(x, F32, "x")
+    C = x.shape[-1]
+    rows = x.numel() // C
+    if out is None:
+        out = torch.empty(x.shape, dtype=BF16 if out_bf16 else F32, device=x.device)
+    _lib.check(lib.gr_rmsnorm(_p(x), _p(gamma), _p(out), rows, C, C, C, eps, int(out_bf16), _stream()), "gr_rmsnorm")
+    return out
+
+
+def attention(q, k, vt, *, Skv, causal, q_pos0=0, kv_len=None, scale=None, out=None):
+    """q [B,H,Lq,hd]; k [B,H,kv_stride,hd]; vt [B,H,hd,kv_stride] -> [B*Lq, H*hd]"""
+    lib = _lib.load()
+    _chk(q, BF16, "q"); _chk(k, BF16, "k"); _chk(vt, BF16, "vt")
+    B, H, Lq, hd = q.shape
+    kv_stride = k.shape[2]
+    if scale is None:
+        scale = hd ** -0.5
+    if out is None:
+        out = torch.empty((B * Lq, H * hd), dtype=BF16, device=q.device)
+    if kv_len is not None:
+        _chk(kv_len, I32, "kv_len")
+    _lib.check(lib.gr_attention_bf16(_p(q), _p(k), _p(vt), _p(out), _p(kv_len), B, H, Lq, Skv, kv_stride, hd,
+                                     int(causal), q_pos0, scale, _stream()), "gr_attention_bf16")
+    return out
+
+
+def qkv_split(qkv, q, k, vt, *, B, H, L, hd, pos0=0, cos=None, sin=None):
+    lib = _lib.load()
+    _chk(qkv, BF16, "qkv")
+    _lib.check(lib.gr_qkv_split(_p(qkv), _p(q), _p(k), _p(vt), _p(cos), _p(sin), B, H, L, hd, pos0, k.shape[2],
+                                _stream()), "gr_qkv_split")
+
+
+def patchify(images, P, Kpad):
+    lib = _lib.load()
+    _chk(images, F32, "images")
+    B, _, S, _ = images.shape
+    G = S // P
+    out = torch.empty((B * G * G, Kpad), dtype=BF16, device=images.device)
+    _lib.check(lib.gr_patchify(_p(images), _p(out), B, S, P, Kpad, _stream()), "gr_patchify")
+    return out
+
+
+def fill_rows(src, dst, rows, ld_dst):
+    lib = _lib.load()
+    _lib.check(lib.gr_fill_rows_f32(_p(src), _p(dst), rows, src.numel(), ld_dst, _stream()), "gr_fill_rows_f32")
+
+
+def mean4_tokens(h0, h1, h2, h3):
+    lib = _lib.load()
+    B, T, C = h0.shape
+    out = torch.empty((B * (T - 1), C), dtype=F32, device=h0.device)
+    _lib.check(lib.gr_mean4_tokens(_p(h0), _p(h1), _p(h2), _p(h3), _p(out), B, T, C, _stream()), "gr_mean4_tokens")
+    return out
+
+
+def s2d_pack(h, G):
+    lib = _lib.load()
+    B, T, C = h.shape
+    out = torch.empty((B * (G // 2) ** 2, 4 * C), dtype=BF16, device=h.device)
+    _lib.check(lib.gr_s2d_pack(_p(h), _p(out), B, G, C, _stream()), "gr_s2d_pack")
+    return out
+
+
+def upsample_coord_pack(h, G, Ho, Cpad):
+    lib = _lib.load()
+    B, T, C = h.shape
+    out = torch.empty((B * Ho * Ho, Cpad), dtype=BF16, device=h.device)
+    _lib.check(lib.gr_upsample_coord_pack(_p(h), _p(out), B, G, Ho, C, Cpad, _stream()), "gr_upsample_coord_pack")
+    return out
+
+
+def gn_stats(x, imgs, HW, C):
+    lib = _lib.load()
+    sums = torch.zeros((imgs, C, 2), dtype=F32, device=x.device)
+    _lib.check(lib.gr_gn_stats(_p(x), _p(sums), imgs, HW, C, _stream()), "gr_gn_stats")
+    return sums
+
+
+def fuse_shuffle(tar, top, down, gamma, beta, out, *, imgs, C, groups, eps, shuffle, pad):
+    """each of tar/top/down = (map bf16 [imgs*S*S, C], sums or None, S)"""
+    lib = _lib.load()
+    t, tp, dn = tar, top or (None, None, 0), down or (None, None, 0)
+    _lib.check(lib.gr_fuse_shuffle(_p(t[0]), _p(t[1]), t[2], _p(tp[0]), _p(tp[1]), tp[2], _p(dn[0]), _p(dn[1]), dn[2],
+                                   _p(gamma), _p(beta), _p(out), imgs, C, groups, eps, int(shuffle), pad, _stream()),
+               "gr_fuse_shuffle")
+    return out
+
+
+def cast_bf16(a, b=None):
+    lib = _lib.load()
+    _chk(a, F32, "a")
+    out = torch.empty(a.shape, dtype=BF16, device=a.device)
+    _lib.check(lib.gr_cast_f32_bf16(_p(a), _p(b), _p(out), a.numel(), _stream()), "gr_cast_f32_bf16")
+    return out
+
+
+def add_rows(a, b, b_mod=0, out=None):
+    lib = _lib.load()
+    _chk(a, F32, "a"); _chk(b, F32, "b")
+    C = a.shape[-1]
+    if out is None:
+        out = torch.empty_like(a)
+    _lib.check(lib.gr_add_rows_f32(_p(a), _p(b), _p(out), a.numel() // C, C, b_mod, _stream()), "gr_add_rows_f32")
+    return out
+
+
+def embed_gather(ids, table0, table1):
+    lib = _lib.load()
+    _chk(ids, I64, "ids")
+    C = table0.shape[1]
+    out = torch.empty((ids.numel(), C), dtype=F32, device=ids.device)
+    _lib.check(lib.gr_embed_gather(_p(ids), _p(table0), _p(table1), _p(out), ids.numel(), C, table0.shape[0],
+                                   table1.shape[0], _stream()), "gr_embed_gather")
+    return out
+
+
+def scatter_rows(src, row_idx, dst):
+    lib = _lib.load()
+    _chk(src, F32, "src"); _chk(row_idx, I32, "row_idx"); _chk(dst, F32, "dst")
+    _lib.check(lib.gr_scatter_rows_f32(_p(src), _p(row_idx), _p(dst), row_idx.numel(), src.shape[-1], _stream()),
+               "gr_scatter_rows_f32")
+
+
+def argmax_rows(x, V):
+    lib = _lib.load()
+    _chk(x, F32, "x")
+    rows = x.numel() // x.shape[-1]
+    out = torch.empty((rows,), dtype=I64, device=x.device)
+    _lib.check(lib.gr_argmax_rows(_p(x), _p(out), rows, V, x.shape[-1], _stream()), "gr_argmax_rows")
+    return out
+
+
+def msda(value, offw, ref, *, B, Q, heads, n_points, Hs, Ws, rdim, ref_batched):
+    lib = _lib.load()
+    out = torch.empty((B * Q, heads * 32), dtype=F32, device=value.device)
+    _lib.check(lib.gr_msda_f32(_p(value), _p(offw), _p(ref), _p(out), B, Q, heads, n_points, Hs, Ws, offw.shape[-1],
+                               rdim, int(ref_batched), _stream()), "gr_msda_f32")
+    return out
+
+
+def mha32(qk, v, *, B, Q, heads, scale):
+    lib = _lib.load()
+    out = torch.empty((B * Q, heads * 32), dtype=F32, device=qk.device)
+    _lib.check(lib.gr_mha32_f32(_p(qk), _p(v), _p(out), B, Q, heads, qk.shape[-1], scale, _stream()), "gr_mha32_f32")
+    return out
+
+
+def ddetr_topk_gather(idx, delta, prop, *, B, S, Kq, npf):
+    lib = _lib.load()
+    ref = torch.empty((B * Kq, 4), dtype=F32, device=delta.device)
+    pos = torch.empty((B * Kq, 4 * npf), dtype=F32, device=delta.device)
+    _lib.check(lib.gr_ddetr_topk_gather(_p(idx), _p(delta), _p(prop), _p(ref), _p(pos), B, S, Kq, npf, _stream()),
+               "gr_ddetr_topk_gather")
+    return ref, pos
+
+
+def box_refine(tmp, ref):
+    lib = _lib.load()
+    out = torch.empty_like(ref)
+    _lib.check(lib.gr_box_refine(_p(tmp), _p(ref), _p(out), ref.numel(), _stream()), "gr_box_refine")
+    return out
+
+
+def score_fuse(coco, sa1b, n, ld=1):
+    lib = _lib.load()
+    out = torch.empty((n,), dtype=F32, device=coco.device)
+    _lib.check(lib.gr_score_fuse(_p(coco), _p(sa1b), _p(out), n, ld, _stream()), "gr_score_fuse")
+    return out
+
+
+def topk_desc(x, K):
+    """x f32 [B,S] -> int32 [B,K], order (value desc, index asc)"""
+    lib = _lib.load()
+    _chk(x, F32, "x")
+    B, S = x.shape
+    out = torch.empty((B, K), dtype=I32, device=x.device)
+    _lib.check(lib.gr_topk_desc(_p(x), _p(out), B, S, K, S, _stream()), "gr_topk_desc")
+    return out
+
+
+def nms(boxes_cxcywh, scores, iou_thr, score_thr, max_num, n_valid=None):
+    """boxes [B,n,4] (cx,cy,w,h), scores [B,n] -> keep int64 [B,max_num] (-1 padded), n_keep int32 [B]"""
+    lib = _lib.load()
+    _chk(boxes_cxcywh, F32, "boxes"); _chk(scores, F32, "scores")
+    B, n = scores.shape
+    keep = torch.empty((B, max_num), dtype=I64, device=scores.device)
+    n_keep = torch.empty((B,), dtype=I32, device=scores.device)
+    _lib.check(lib.gr_nms_f32(_p(boxes_cxcywh), _p(scores), B, n, iou_thr, score_thr, max_num, _p(n_valid), _p(keep),
+                              _p(n_keep), _stream()), "gr_nms_f32")
+    return keep, n_keep
+
+
+def roi_align_pack(feat_nhwc, rois, out, *, C, H, W, ph, pw, spatial_scale, sampling_ratio, aligned=True, pad=1,
+                   out_f32=False):
+    lib = _lib.load()
+    _chk(feat_nhwc, BF16, "feat"); _chk(rois, F32, "rois")
+    _lib.check(lib.gr_roi_align_pack(_p(feat_nhwc), _p(rois), _p(out), rois.shape[0], C, H, W, ph, pw, spatial_scale,
+                                     sampling_ratio, int(aligned), pad, int(out_f32), _stream()), "gr_roi_align_pack")
+    return out
+
+
+def prof_enable(on):
+    _lib.check(_lib.load().gr_prof_enable(int(on)), "gr_prof_enable")
+
+
+def prof_read():
+    ms, n, fl = ctypes.c_double(), ctypes.c_long(), ctypes.c_double()
+    _lib.check(_lib.load().gr_prof_read(ctypes.byref(ms), ctypes.byref(n), ctypes.byref(fl)), "gr_prof_read")
+    return ms.value, n.value, fl.value

@@ -1,0 +1,135 @@
+/*
+ * groma_hip.h -- C ABI of libgroma_hip.so, the MI355X (gfx950) operator library behind
+ * groma_amd.GromaModel (the drop-in for reference groma/model/groma.py:86-427).
+ *
+ * Boundary rules (inner boundary = the reference's mmcv `_ext` op plugin,
+ * mmcv/ops/csrc/pytorch/pybind.cpp:175,191,596,611):
+ *   - extern "C", plain device pointers + sizes + hipStream_t; no torch / ATen types;
+ *   - the caller owns every buffer; ops never allocate, never synchronise, never throw;
+ *   - work is enqueued on the given stream (the reference ops use the current CUDA stream:
+ *     mmcv/ops/csrc/pytorch/cuda/roi_align_cuda.cu:15-16);
+ *   - return 0 on success, GR_EINVAL (22) for a rejected argument set, or the hipError_t of a failed
+ *     launch (the reference raises RuntimeError via TORCH_CHECK; the Python host maps non-zero to
+ *     RuntimeError the same way).
+ * bf16 tensors are raw uint16 bit patterns; "f32" = IEEE binary32.  All row-major.
+ */
+#ifndef GROMA_HIP_H
+#define GROMA_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#ifndef __HIP_PLATFORM_AMD__
+typedef struct ihipStream_t* hipStream_t;
+#endif
+
+#define GROMA_HIP_ABI_VERSION 1
+int gr_abi_version(void);
+/* kernel timing hook used by bench.py: when enabled, every gr_gemm_bf16 launch is bracketed by HIP
+ * events on its own stream; gr_prof_read drains them (sync) and returns total ms + launch count. */
+int gr_prof_enable(int on);
+int gr_prof_read(double* total_ms, long* launches, double* flops);
+
+/* ------------------------------------------------------------------ dense contractions (MFMA) -- */
+/* C[M,N] = epilogue(A[M,K] . W[N,K]^T).  Replaces every nn.Linear / nn.Conv2d on the path:
+ * HF Dinov2 / LLaMA projections, img_txt_bridge (groma/model/groma.py:112-116), lm_head (+) extra_lm_head
+ * (groma.py:399-402), MLVLFuseModule / MlvlRoIExtractor convs (groma/model/roi_align.py:128-143,251-264). */
+typedef struct gr_gemm_desc {
+  const void* A;      /* bf16 [M,K] (lda), or zero-bordered NHWC maps when conv_C > 0              */
+  const void* W;      /* bf16 [N,K] (ldw) -- nn.Linear.weight layout                               */
+  void* C;            /* bf16 or f32 [M,N] (ldc)                                                   */
+  const float* bias;  /* [N] or NULL                                                               */
+  const float* scale; /* [N] or NULL (DINOv2 LayerScale), applied after bias/activation            */
+  const float* resid; /* f32 [*,N] (ldr) or NULL, added last                                       */
+  float* ws;          /* split-K workspace f32 [splits,M,N] (required when splits > 1)             */
+  int M, N, K;        /* K % 64 == 0, N % 4 == 0                                                   */
+  long lda, ldw, ldc, ldr;
+  int act;            /* 0 none, 1 GELU(erf), 2 ReLU, 3 SwiGLU over interleaved (gate,up) rows of W:
+                         C is [M, N/2] bf16 = silu(gate)*up                                        */
+  int out_f32;        /* C element type                                                            */
+  int splits;         /* split-K factor >= 1                                                       */
+  /* implicit 3x3 / pad 1 convolution gather for A (conv_C > 0): row m = output pixel (img,y,x) of
+   * [imgs,conv_H,conv_W]; A = [imgs,conv_H+2,conv_W+2,conv_C] bf16 with a zero border; K = S*9*conv_C with
+   * k = ((s*9 + ky*3+kx)*conv_C + c); segment s (summed source maps) is conv_seg_stride elements apart. */
+  int conv_H, conv_W, conv_C;
+  long conv_seg_stride;
+  int resid_mod;      /* > 0: residual row = m % resid_mod (position-embedding broadcast)          */
+  /* output row remap: row(m) = (m / c_group)*c_group_stride + c_row_off + m % c_group (c_group > 0) */
+  int c_group, c_group_stride, c_row_off;
+} gr_gemm_desc;
+int gr_gemm_bf16(const gr_gemm_desc* d, hipStream_t stream);
+
+/* exact fp32 GEMM (f32-input MFMA): C = act(A.W^T + bias) (+ resid); K % 16 == 0.  DDETR linears
+ * (HF 4.32 DeformableDetr* layers used from groma/model/ddetr_transformer.py:299-359). act: 0 | 2 (ReLU) */
+int gr_gemm_f32(const float* A, const float* W, float* C, const float* bias, const float* resid, int M, int N, int K,
+                long lda, long ldw, long ldc, int act, hipStream_t stream);
+
+/* ------------------------------------------------------------------------------ normalisation -- */
+/* out = LN(x (+ add)) * gamma + beta over C (C % 256 == 0, C <= 4096); out bf16 or f32. */
+int gr_layernorm(const float* x, const float* add, const float* gamma, const float* beta, void* out, int rows, int C,
+                 long ldx, long ldo, float eps, int out_bf16, int relu_in, hipStream_t stream);
+/* HF LlamaRMSNorm */
+int gr_rmsnorm(const float* x, const float* gamma, void* out, int rows, int C, long ldx, long ldo, float eps,
+               int out_bf16, hipStream_t stream);
+
+/* ---------------------------------------------------------------------------------- attention -- */
+/* q [B,H,Lq,hd], k [B,H,kv_stride,hd], vt [B,H,hd,kv_stride] bf16 -> out [B*Lq, H*hd] bf16.
+ * key j visible to query i <=> j < Skv, j < kv_len[b] (if given), and (causal) j <= q_pos0 + i.  hd in {64,128}. */
+int gr_attention_bf16(const void* q, const void* k, const void* vt, void* out, const int* kv_len, int B, int H, int Lq,
+                      int Skv, int kv_stride, int head_dim, int causal, int q_pos0, float scale, hipStream_t stream);
+/* fused-QKV split (+ HF rotate_half RoPE when cos/sin given) into the layouts above / the KV cache */
+int gr_qkv_split(const void* qkv, void* q, void* k, void* vt, const float* cosT, const float* sinT, int B, int H, int L,
+                 int head_dim, int pos0, int kv_stride, hipStream_t stream);
+
+/* ------------------------------------------------------------------------- packing / movement -- */
+int gr_patchify(const float* images, void* out, int B, int S, int P, int Kpad, hipStream_t stream);
+int gr_fill_rows_f32(const float* src, float* dst, int rows, int C, long ld_dst, hipStream_t stream);
+int gr_mean4_tokens(const float* h0, const float* h1, const float* h2, const float* h3, float* out, int B, int T, int C,
+                    hipStream_t stream);
+int gr_s2d_pack(const float* h, void* out, int B, int G, int C, hipStream_t stream);
+int gr_upsample_coord_pack(const float* h, void* out, int B, int G, int Ho, int C, int Cpad, hipStream_t stream);
+int gr_gn_stats(const void* x, float* sums, int imgs, int HW, int C, hipStream_t stream);
+int gr_fuse_shuffle(const void* tar, const float* tar_sums, int tarS, const void* top, const float* top_sums, int topS,
+                    const void* down, const float* down_sums, int downS, const float* gamma, const float* beta, void* out,
+                    int imgs, int C, int groups, float eps, int shuffle, int pad, hipStream_t stream);
+int gr_cast_f32_bf16(const float* a, const float* b, void* out, long n, hipStream_t stream);
+int gr_add_rows_f32(const float* a, const float* b, float* out, long rows, int C, int b_mod, hipStream_t stream);
+int gr_embed_gather(const long* ids, const void* table0, const void* table1, float* out, long n, int C, int V0, int V1,
+                    hipStream_t stream);
+int gr_scatter_rows_f32(const float* src, const int* row_idx, float* dst, long n, int C, hipStream_t stream);
+int gr_argmax_rows(const float* x, long* out, int rows, int V, long ld, hipStream_t stream);
+
+/* --------------------------------------------------------------- region proposer (fp32, DDETR) -- */
+int gr_msda_f32(const float* value, const float* offw, const float* ref, float* out, int B, int Q, int heads,
+                int n_points, int Hs, int Ws, int ld, int rdim, int ref_batched, hipStream_t stream);
+int gr_mha32_f32(const float* qk, const float* v, float* out, int B, int Q, int heads, int ldqk, float scale,
+                 hipStream_t stream);
+int gr_ddetr_topk_gather(const int* idx, const float* delta, const float* prop, float* ref, float* pos, int B, int S,
+                         int Kq, int npf, hipStream_t stream);
+int gr_box_refine(const float* tmp, const float* ref, float* out, long n, hipStream_t stream);
+int gr_score_fuse(const float* coco, const float* sa1b, float* out, long n, long ld, hipStream_t stream);
+
+/* ------------------------------------------------------------------- selection (index-exact) -- */
+/* replaces torch.topk at groma/model/ddetr_transformer.py:556; order (value desc, index asc); S <= 1024 */
+int gr_topk_desc(const float* x, int* out_idx, int B, int S, int K, long ldx, hipStream_t stream);
+/* replaces mmcv `_ext.nms` + NMSop glue (mmcv/ops/nms.py:14-33, csrc/pytorch/cpu/nms.cpp:5-54) for the call at
+ * groma/model/groma.py:266-272; boxes are (cx,cy,w,h); n <= 512; keep is int64 [B,max_num], -1 padded. */
+int gr_nms_f32(const float* boxes_cxcywh, const float* scores, int B, int n, float iou_thr, float score_thr, int max_num,
+               const int* n_valid, long* keep, int* n_keep, hipStream_t stream);
+
+/* ---------------------------------------------------------------------- fused RoIAlign + pack -- */
+/* replaces mmcv `_ext.roi_align_forward` (mmcv/ops/roi_align.py:93-104; kernel
+ * csrc/common/cuda/roi_align_cuda_kernel.cuh:17-108) for the calls at groma/model/roi_align.py:299-305.
+ * feat bf16 NHWC [imgs,H,W,C]; rois f32 [R,5] = (img, x1,y1,x2,y2) exactly as the reference passes them;
+ * out [R, PH+2*pad, PW+2*pad, C] bf16 (or f32), interior written, border left untouched (zero it once). */
+int gr_roi_align_pack(const void* feat_nhwc, const float* rois, void* out, int R, int C, int H, int W, int pooled_h,
+                      int pooled_w, float spatial_scale, int sampling_ratio, int aligned, int pad, int out_f32,
+                      hipStream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GROMA_HIP_H */

@@ -1,0 +1,338 @@
+"""Per-kernel numerics on a real MI355X: every HIP kernel (through the C ABI) against a plain torch fp32
+statement of the same op.  bf16 kernels: inputs are bf16-exact, accumulation fp32, tolerance = output rounding.
+Index-producing kernels are compared bit-exactly against the oracle in tests/test_parity_gpu.py."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _ops():
+    from groma_amd import ops
+    return ops
+
+
+def rnd(shape, dev, scale=1.0, seed=0):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    return (torch.randn(shape, generator=g) * scale).to(dev)
+
+
+def relerr(a, b):
+    a, b = a.float(), b.float()
+    return ((a - b).norm() / b.norm().clamp_min(1e-12)).item()
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 512), (582, 4096, 1024), (100, 260, 192), (1, 128, 4096),
+                                   (1025, 3072, 1024)])
+def test_gemm_plain(dev, M, N, K):
+    ops = _ops()
+    a = rnd((M, K), dev, seed=1).bfloat16()
+    w = rnd((N, K), dev, seed=2).bfloat16()
+    # asymmetric structure so a transposed / permuted result cannot pass
+    a[:, 0] += 3.0
+    w[0, :] -= 2.0
+    ref = a.float() @ w.float().t()
+    out = ops.gemm(a, w, out_f32=True)
+    assert out.shape == (M, N)
+    assert relerr(out, ref) < 1e-5
+    out16 = ops.gemm(a, w)
+    assert relerr(out16, ref) < 4e-3
+
+
+def test_gemm_epilogues(dev):
+    ops = _ops()
+    M, N, K = 300, 512, 256
+    a = rnd((M, K), dev, seed=1).bfloat16()
+    w = rnd((N, K), dev, 0.1, seed=2).bfloat16()
+    bias = rnd((N,), dev, seed=3)
+    scale = rnd((N,), dev, seed=4)
+    resid = rnd((M, N), dev, seed=5)
+    base = a.float() @ w.float().t() + bias
+    assert relerr(ops.gemm(a, w, bias=bias, act=1), F.gelu(base)) < 4e-3
+    assert relerr(ops.gemm(a, w, bias=bias, act=2), F.relu(base)) < 4e-3
+    out = ops.gemm(a, w, bias=bias, scale=scale, resid=resid, out_f32=True)
+    assert relerr(out, resid + scale * base) < 1e-5
+    # in-place residual update (out aliases resid)
+    r2 = resid.clone()
+    ops.gemm(a, w, bias=bias, scale=scale, resid=r2, out=r2, out_f32=True)
+    assert relerr(r2, resid + scale * base) < 1e-5
+    # swiglu over interleaved rows
+    g, u = base[:, 0::2], base[:, 1::2]
+    assert relerr(ops.gemm(a, w, bias=bias, act=3), F.silu(g) * u) < 4e-3
+    # split-K
+    out = ops.gemm(a, w, bias=bias, resid=resid, out_f32=True, splits=3)
+    assert relerr(out, resid + base) < 1e-5
+    # position-embedding style residual + row remap (patch tokens -> rows 1.. of each image)
+    pos = rnd((100, N), dev, seed=6)
+    buf = torch.zeros((3 * 101, N), device=dev)
+    ops.gemm(a, w, bias=bias, resid=pos, resid_mod=100, out=buf, out_f32=True, row_map=(100, 101, 1))
+    exp = (base + pos.repeat(3, 1)).view(3, 100, N)
+    assert relerr(buf.view(3, 101, N)[:, 1:], exp) < 1e-5
+    assert buf.view(3, 101, N)[:, 0].abs().max().item() == 0.0
+
+
+@pytest.mark.parametrize("imgs,H,C,Cout,segs", [(2, 16, 64, 128, 1), (1, 32, 128, 64, 1), (3, 14, 64, 64, 3)])
+def test_gemm_conv3x3(dev, imgs, H, C, Cout, segs):
+    ops = _ops()
+    xs = [rnd((imgs, C, H, H), dev, seed=10 + s).bfloat16() for s in range(segs)]
+    ws = [rnd((Cout, C, 3, 3), dev, 0.1, seed=20 + s).bfloat16() for s in range(segs)]
+    ref = sum(F.conv2d(x.float(), w.float(), padding=1) for x, w in zip(xs, ws))
+    ref = ref.permute(0, 2, 3, 1).reshape(imgs * H * H, Cout)
+    pad = torch.zeros((segs, imgs, H + 2, H + 2, C), dtype=torch.bfloat16, device=dev)
+    for s in range(segs):
+        pad[s, :, 1:-1, 1:-1] = xs[s].permute(0, 2, 3, 1)
+    # weight [Cout, segs*9*C], k = (s*9 + ky*3+kx)*C + c
+    wk = torch.cat([w.permute(0, 2, 3, 1).reshape(Cout, 9 * C) for w in ws], dim=1).contiguous()
+    out = ops.gemm(pad, wk, conv=(imgs, H, H, C, imgs * (H + 2) * (H + 2) * C), out_f32=True)
+    assert relerr(out, ref) < 1e-5
+
+
+@pytest.mark.parametrize("M,N,K", [(1024, 256, 1024), (300, 96, 256), (100, 256, 16), (77, 4, 256)])
+def test_gemm_f32(dev, M, N, K):
+    ops = _ops()
+    a, w, b = rnd((M, K), dev, seed=1), rnd((N, K), dev, seed=2), rnd((N,), dev, seed=3)
+    ref = F.relu(a.double() @ w.double().t() + b.double())
+    out = ops.gemm_f32(a, w, bias=b, act=2)
+    assert relerr(out, ref) < 1e-6
+    out = ops.gemm_f32(a, w)
+    assert relerr(out, a.double() @ w.double().t()) < 1e-6
+
+
+@pytest.mark.parametrize("C", [256, 1024, 4096])
+def test_norms(dev, C):
+    ops = _ops()
+    x = rnd((37, C), dev, 2.0, seed=1) + 0.5
+    y = rnd((37, C), dev, seed=2)
+    g, b = rnd((C,), dev, seed=3), rnd((C,), dev, seed=4)
+    ref = F.layer_norm(x + y, (C,), g, b, 1e-6)
+    assert relerr(ops.layernorm(x, g, b, 1e-6, add=y), ref) < 1e-5
+    assert relerr(ops.layernorm(x, g, b, 1e-6, add=y, out_bf16=True), ref) < 4e-3
+    rms = g * (x * torch.rsqrt(x.pow(2).mean(-1, keepdim=True) + 1e-5))
+    assert relerr(ops.rmsnorm(x, g, 1e-5, out_bf16=False), rms) < 1e-5
+    assert relerr(ops.rmsnorm(x, g, 1e-5), rms) < 4e-3
+
+
+def _attn_ref(q, k, v, causal, q_pos0, kv_len):
+    B, H, Lq, hd = q.shape
+    S = k.shape[2]
+    s = torch.einsum("bhqd,bhkd->bhqk", q.float(), k.float()) / math.sqrt(hd)
+    ki = torch.arange(S, device=q.device)[None, None, None, :]
+    qi = torch.arange(Lq, device=q.device)[None, None, :, None]
+    vis = torch.ones((B, 1, Lq, S), dtype=torch.bool, device=q.device)
+    if causal:
+        vis = vis & (ki <= qi + q_pos0)
+    if kv_len is not None:
+        vis = vis & (ki < kv_len.view(B, 1, 1, 1))
+    s = s.masked_fill(~vis, float("-inf"))
+    p = torch.softmax(s, -1)
+    o = torch.einsum("bhqk,bhkd->bhqd", p, v.float())
+    return o.permute(0, 2, 1, 3).reshape(B * Lq, H * hd)
+
+
+@pytest.mark.parametrize("B,H,Lq,S,hd,causal,q_pos0,use_len", [
+    (2, 4, 1025, 1025, 64, False, 0, False),   # DINOv2 shape
+    (2, 3, 582, 582, 128, True, 0, True),      # LLaMA prefill with right padding
+    (1, 2, 70, 70, 128, True, 0, False),
+    (2, 2, 1, 300, 128, True, 299, False),     # decode step against a KV cache
+    (1, 2, 33, 200, 64, True, 167, False),
+])
+def test_attention(dev, B, H, Lq, S, hd, causal, q_pos0, use_len):
+    ops = _ops()
+    stride = (S + 63) // 64 * 64
+    q = rnd((B, H, Lq, hd), dev, seed=1).bfloat16()
+    k = torch.zeros((B, H, stride, hd), dtype=torch.bfloat16, device=dev)
+    v = torch.zeros((B, H, stride, hd), dtype=torch.bfloat16, device=dev)
+    k[:, :, :S] = rnd((B, H, S, hd), dev, seed=2).bfloat16()
+    v[:, :, :S] = rnd((B, H, S, hd), dev, seed=3).bfloat16()
+    # a spiked key forces the online-softmax rescale branch
+    k[0, 0, S // 2] *= 8.0
+    vt = v.transpose(2, 3).contiguous()
+    kv_len = None
+    if use_len:
+        kv_len = torch.tensor([S - 37, S][:B], dtype=torch.int32, device=dev)
+    out = ops.attention(q, k, vt, Skv=S, causal=causal, q_pos0=q_pos0, kv_len=kv_len)
+    ref = _attn_ref(q, k[:, :, :S], v[:, :, :S], causal, q_pos0, kv_len)
+    assert relerr(out, ref) < 1e-2
+    assert (out.float() - ref).abs().max().item() < 5e-2
+
+
+@pytest.mark.parametrize("hd,rope", [(64, False), (128, True)])
+def test_qkv_split(dev, hd, rope):
+    ops = _ops()
+    B, H, L, pos0 = 2, 3, 70, 5
+    stride = 128
+    qkv = rnd((B * L, 3 * H * hd), dev, seed=1).bfloat16()
+    q = torch.zeros((B, H, L, hd), dtype=torch.bfloat16, device=dev)
+    k = torch.zeros((B, H, stride, hd), dtype=torch.bfloat16, device=dev)
+    vt = torch.zeros((B, H, hd, stride), dtype=torch.bfloat16, device=dev)
+    cos = sin = None
+    if rope:
+        inv = 1.0 / (10000 ** (torch.arange(0, hd, 2, device=dev).float() / hd))
+        fr = torch.outer(torch.arange(256, device=dev).float(), inv)
+        cos, sin = fr.cos().contiguous(), fr.sin().contiguous()
+    ops.qkv_split(qkv, q, k, vt, B=B, H=H, L=L, hd=hd, pos0=pos0, cos=cos, sin=sin)
+    x = qkv.float().view(B, L, 3, H, hd).permute(2, 0, 3, 1, 4)  # [3,B,H,L,hd]
+    qr, kr, vr = x[0], x[1], x[2]
+    if rope:
+        c = torch.cat([cos, cos], -1)[pos0:pos0 + L]
+        s = torch.cat([sin, sin], -1)[pos0:pos0 + L]
+        rot = lambda t: torch.cat([-t[..., hd // 2:], t[..., :hd // 2]], -1)
+        qr, kr = qr * c + rot(qr) * s, kr * c + rot(kr) * s
+    assert relerr(q, qr) < 4e-3
+    assert relerr(k[:, :, pos0:pos0 + L], kr) < 4e-3
+    assert torch.equal(vt[:, :, :, pos0:pos0 + L].float(), vr.transpose(2, 3))
+    assert k[:, :, :pos0].abs().max().item() == 0 and vt[..., pos0 + L:].abs().max().item() == 0
+
+
+def test_vit_packing(dev):
+    ops = _ops()
+    B, S, P, C = 2, 56, 14, 64
+    G = S // P
+    img = rnd((B, 3, S, S), dev, seed=1)
+    w = rnd((C, 3, P, P), dev, 0.05, seed=2).bfloat16()
+    Kpad = 640
+    a = ops.patchify(img, P, Kpad)
+    wk = torch.zeros((C, Kpad), dtype=torch.bfloat16, device=dev)
+    wk[:, :3 * P * P] = w.reshape(C, -1)
+    ref = F.conv2d(img.bfloat16().float(), w.float(), stride=P).flatten(2).transpose(1, 2).reshape(B * G * G, C)
+    assert relerr(ops.gemm(a, wk, out_f32=True), ref) < 1e-5
+    # mean4 / s2d / upsample
+    T = 1 + G * G
+    hs = [rnd((B, T, C), dev, seed=10 + i) for i in range(4)]
+    ref = torch.stack(hs).mean(0)[:, 1:].reshape(B * (T - 1), C)
+    assert relerr(ops.mean4_tokens(*hs), ref) < 1e-6
+    f = hs[0][:, 1:].reshape(B, G, G, C)
+    ref = torch.cat([f[:, 0::2, 0::2], f[:, 1::2, 0::2], f[:, 0::2, 1::2], f[:, 1::2, 1::2]], -1).reshape(B * 4, 4 * C)
+    assert torch.equal(ops.s2d_pack(hs[0], G).float(), ref.bfloat16().float())
+    Ho, Cpad = 16, 128
+    up = ops.upsample_coord_pack(hs[0], G, Ho, Cpad).float().view(B, Ho, Ho, Cpad)
+    fm = f.permute(0, 3, 1, 2)
+    ref = F.interpolate(fm, size=(Ho, Ho), mode="bilinear", align_corners=True).permute(0, 2, 3, 1)
+    assert relerr(up[..., :C], ref) < 4e-3
+    lin = torch.linspace(-1, 1, Ho, device=dev)
+    assert (up[0, :, :, C] - lin[None, :].bfloat16().float()).abs().max().item() == 0  # x varies along width
+    assert (up[0, :, :, C + 1] - lin[:, None].bfloat16().float()).abs().max().item() == 0
+    assert up[..., C + 2:].abs().max().item() == 0
+
+
+def test_gn_shuffle(dev):
+    ops = _ops()
+    imgs, C, groups = 2, 128, 64
+    S = [16, 8, 4]
+    xs = [rnd((imgs, C, s, s), dev, 1.5, seed=30 + i).bfloat16() for i, s in enumerate(S)]
+    gamma, beta = rnd((C,), dev, seed=1), rnd((C,), dev, seed=2)
+    flat = [x.permute(0, 2, 3, 1).reshape(-1, C).contiguous() for x in xs]
+    sums = [ops.gn_stats(f, imgs, s * s, C) for f, s in zip(flat, S)]
+    act = [F.relu(F.group_norm(x.float(), groups, gamma, beta, 1e-5)) for x in xs]
+    rc, sh = C // 2, C // 4
+    for lvl in range(3):
+        top, dow = min(lvl + 1, 2), max(lvl - 1, 0)
+        for normed in (True, False):
+            src = act if normed else [x.float() for x in xs]
+            ft = F.interpolate(src[top][:, rc:][:, sh:], size=(S[lvl], S[lvl]), mode="bilinear", align_corners=True)
+            fd = F.interpolate(src[dow][:, rc:][:, :sh], size=(S[lvl], S[lvl]), mode="bilinear", align_corners=True)
+            ref = torch.cat([src[lvl][:, :rc], ft, fd], 1).permute(0, 2, 3, 1)
+            out = torch.zeros((imgs, S[lvl] + 2, S[lvl] + 2, C), dtype=torch.bfloat16, device=dev)
+            sm = sums if normed else [None] * 3
+            ops.fuse_shuffle((flat[lvl], sm[lvl], S[lvl]), (flat[top], sm[top], S[top]), (flat[dow], sm[dow], S[dow]),
+                             gamma, beta, out, imgs=imgs, C=C, groups=groups, eps=1e-5, shuffle=True, pad=1)
+            assert relerr(out[:, 1:-1, 1:-1], ref) < 6e-3, (lvl, normed)
+            assert out[:, 0].abs().max().item() == 0 and out[:, :, -1].abs().max().item() == 0
+    out = torch.zeros((imgs, S[0], S[0], C), dtype=torch.bfloat16, device=dev)
+    ops.fuse_shuffle((flat[0], sums[0], S[0]), None, None, gamma, beta, out, imgs=imgs, C=C, groups=groups, eps=1e-5,
+                     shuffle=False, pad=0)
+    assert relerr(out, act[0].permute(0, 2, 3, 1)) < 6e-3
+
+
+def test_small_movers(dev):
+    ops = _ops()
+    V0, V1, C = 50, 7, 64
+    t0, t1 = rnd((V0, C), dev, seed=1).bfloat16(), rnd((V1, C), dev, seed=2).bfloat16()
+    ids = torch.tensor([0, 49, 50, 56, 3, 52], device=dev)
+    ref = torch.where((ids >= V0)[:, None], t1.float()[(ids - V0).clamp(0)], t0.float()[ids.clamp(max=V0 - 1)])
+    assert torch.equal(ops.embed_gather(ids, t0, t1), ref)
+    dst = torch.zeros((10, C), device=dev)
+    src = rnd((3, C), dev, seed=3)
+    ops.scatter_rows(src, torch.tensor([7, 1, 4], dtype=torch.int32, device=dev), dst)
+    assert torch.equal(dst[[7, 1, 4]], src) and dst[0].abs().max().item() == 0
+    x = rnd((5, 1000), dev, seed=4)
+    x[2, 17] = x[2, 900] = 50.0
+    assert torch.equal(ops.argmax_rows(x, 990), x[:, :990].argmax(-1))
+    a, b = rnd((6, 64), dev, seed=5), rnd((3, 64), dev, seed=6)
+    assert torch.equal(ops.add_rows(a, b, b_mod=3), a + b.repeat(2, 1))
+    assert torch.equal(ops.cast_bf16(a, a).float(), (a + a).bfloat16().float())
+    row = rnd((64,), dev, seed=7)
+    buf = torch.zeros((4, 3, 64), device=dev)
+    ops.fill_rows(row, buf, 4, 3 * 64)
+    assert torch.equal(buf[:, 0], row.expand(4, 64)) and buf[:, 1:].abs().max().item() == 0
+
+
+def _msda_ref(value, loc, w, Hs, Ws):
+    # mmcv multi_scale_deformable_attn_pytorch (mmcv/ops/multi_scale_deform_attn.py:93-150), single level
+    B, S, heads, D = value.shape
+    Q, P = loc.shape[1], loc.shape[3]
+    v = value.flatten(2).transpose(1, 2).reshape(B * heads, D, Hs, Ws)
+    grid = (2 * loc - 1).transpose(1, 2).flatten(0, 1)  # [B*heads, Q, P, 2]
+    samp = F.grid_sample(v, grid, mode="bilinear", padding_mode="zeros", align_corners=False)  # [B*h, D, Q, P]
+    aw = w.transpose(1, 2).reshape(B * heads, 1, Q, P)
+    return (samp * aw).sum(-1).view(B, heads * D, Q).transpose(1, 2).reshape(B * Q, heads * D)
+
+
+@pytest.mark.parametrize("rdim", [2, 4])
+def test_msda(dev, rdim):
+    ops = _ops()
+    B, Q, heads, P, Hs, Ws = 2, 50, 8, 4, 32, 32
+    value = rnd((B, Hs * Ws, heads, 32), dev, seed=1)
+    offw = rnd((B * Q, heads * P * 3), dev, 2.0, seed=2)
+    ref_pts = torch.rand((B * Q, rdim), generator=torch.Generator().manual_seed(3)).to(dev)
+    off = offw[:, :heads * P * 2].view(B, Q, heads, P, 2)
+    aw = torch.softmax(offw[:, heads * P * 2:].view(B, Q, heads, P), -1)
+    r = ref_pts.view(B, Q, 1, 1, rdim)
+    if rdim == 2:
+        loc = r + off / torch.tensor([Ws, Hs], device=dev).float()
+    else:
+        loc = r[..., :2] + off / P * r[..., 2:] * 0.5
+    ref = _msda_ref(value, loc, aw, Hs, Ws)
+    out = ops.msda(value, offw, ref_pts, B=B, Q=Q, heads=heads, n_points=P, Hs=Hs, Ws=Ws, rdim=rdim, ref_batched=True)
+    assert relerr(out, ref) < 1e-5
+
+
+def test_mha32(dev):
+    ops = _ops()
+    B, Q, heads = 2, 300, 8
+    D = heads * 32
+    qk = rnd((B * Q, 2 * D), dev, seed=1)
+    v = rnd((B * Q, D), dev, seed=2)
+    scale = 32 ** -0.5
+    q_ = qk[:, :D].view(B, Q, heads, 32).transpose(1, 2) * scale
+    k_ = qk[:, D:].view(B, Q, heads, 32).transpose(1, 2)
+    v_ = v.view(B, Q, heads, 32).transpose(1, 2)
+    ref = (torch.softmax(q_ @ k_.transpose(-1, -2), -1) @ v_).transpose(1, 2).reshape(B * Q, D)
+    assert relerr(ops.mha32(qk, v, B=B, Q=Q, heads=heads, scale=scale), ref) < 1e-5
+
+
+def test_ddetr_small(dev):
+    ops = _ops()
+    B, S, Kq, npf = 2, 1024, 300, 128
+    logits = rnd((B, S), dev, seed=1)
+    logits[0, 5] = logits[0, 900]  # tie -> lower index first
+    idx = ops.topk_desc(logits, Kq)
+    srt = torch.sort(logits, dim=1, descending=True, stable=True)[1][:, :Kq]
+    assert torch.equal(idx.long(), srt)
+    delta, prop = rnd((B, S, 4), dev, seed=2), rnd((S, 4), dev, seed=3)
+    ref, pos = ops.ddetr_topk_gather(idx, delta, prop, B=B, S=S, Kq=Kq, npf=npf)
+    lg = torch.gather(delta + prop[None], 1, srt[..., None].expand(-1, -1, 4))
+    assert relerr(ref.view(B, Kq, 4), lg.sigmoid()) < 1e-6
+    dim_t = 10000 ** (2 * torch.div(torch.arange(npf, device=dev), 2, rounding_mode="floor").float() / npf)
+    pp = (lg.sigmoid() * 2 * math.pi)[..., None] / dim_t
+    pe = torch.stack((pp[..., 0::2].sin(), pp[..., 1::2].cos()), dim=4).flatten(2)
+    assert (pos.view(B, Kq, 4 * npf) - pe).abs().max().item() < 2e-5
+    tmp, r0 = rnd((600, 4), dev, seed=4), torch.rand((600, 4), generator=torch.Generator().manual_seed(5)).to(dev)
+    x = r0.clamp(0, 1)
+    inv = torch.log(x.clamp(min=1e-5) / (1 - x).clamp(min=1e-5))
+    assert relerr(ops.box_refine(tmp, r0), (tmp + inv).sigmoid()) < 1e-6
+    a, b = rnd((600,), dev, seed=6), rnd((600,), dev, seed=7)
+    assert relerr(ops.score_fuse(a, b, 600), a.sigmoid() ** 0.4 * b.sigmoid() ** 0.6) < 1e-6
