@@ -1,0 +1,132 @@
+"""Configuration objects mirroring the reference's nested HF configs
+(GromaConfig: groma/model/groma.py:31-83; CustomDDETRConfig: groma/model/ddetr.py:48-95; the HF 4.32
+Dinov2Config / DeformableDetrConfig / LlamaConfig fields the path reads -- SURVEY.md §8 hyper-parameter list).
+Field names are the reference's so a reference config.json loads unchanged."""
+import copy
+import json
+import os
+
+
+class _Cfg:
+    _defaults = {}
+
+    def __init__(self, **kw):
+        for k, v in self._defaults.items():
+            setattr(self, k, copy.deepcopy(v))
+        for k, v in kw.items():
+            setattr(self, k, v)
+
+    def to_dict(self):
+        out = {}
+        for k, v in self.__dict__.items():
+            out[k] = v.to_dict() if isinstance(v, _Cfg) else copy.deepcopy(v)
+        return out
+
+    def __repr__(self):
+        return f"{type(self).__name__}({self.to_dict()})"
+
+
+class Dinov2Config(_Cfg):  # DINOv2-L defaults
+    _defaults = dict(hidden_size=1024, num_hidden_layers=24, num_attention_heads=16, mlp_ratio=4, patch_size=14,
+                     image_size=518, layer_norm_eps=1e-6, layerscale_value=1.0, qkv_bias=True, num_channels=3)
+
+
+class DeformableDetrConfig(_Cfg):  # scripts/det_pretrain.sh:12-19 + HF defaults
+    _defaults = dict(d_model=256, encoder_layers=6, decoder_layers=6, encoder_attention_heads=8,
+                     decoder_attention_heads=8, encoder_ffn_dim=1024, decoder_ffn_dim=1024, num_feature_levels=1,
+                     encoder_n_points=4, decoder_n_points=4, num_queries=300, two_stage_num_proposals=300,
+                     two_stage=True, with_box_refine=True, num_labels=1, activation_function="relu")
+
+
+class LlamaConfig(_Cfg):  # Vicuna-7B-v1.5
+    _defaults = dict(hidden_size=4096, intermediate_size=11008, num_hidden_layers=32, num_attention_heads=32,
+                     rms_norm_eps=1e-5, vocab_size=32000, rope_theta=10000.0, max_position_embeddings=4096,
+                     bos_token_id=1, eos_token_id=2, pad_token_id=0)
+
+
+class RegionConfig(_Cfg):  # constants hard-coded in groma/model/roi_align.py:196-264
+    _defaults = dict(num_fuse=5, gn_groups=64, roi_size=14, pos_hidden=256, mid_dim=1024, num_levels=3)
+
+
+def _sub(cls, v):
+    if v is None:
+        return cls()
+    if isinstance(v, dict):
+        return cls(**v)
+    if isinstance(v, cls):
+        return v
+    raise NotImplementedError(f"unsupported sub-config {type(v)}")
+
+
+class CustomDDETRConfig(_Cfg):
+    model_type = "ddetr"
+
+    def __init__(self, vis_encoder_cfg=None, zs_weight_path=None, vis_output_layer=-1, ddetr_cfg=None, **kw):
+        super().__init__(**kw)
+        self.vis_encoder_cfg = _sub(Dinov2Config, vis_encoder_cfg)
+        self.ddetr_cfg = _sub(DeformableDetrConfig, ddetr_cfg)
+        self.zs_weight_path = zs_weight_path
+        self.vis_output_layer = vis_output_layer
+
+
+class GromaConfig(_Cfg):
+    model_type = "groma"
+
+    def __init__(self, llm_cfg=None, perceiver_cfg=None, num_new_token=0, nms_thres=0.6, box_score_thres=0.15,
+                 max_region_num=100, region_cfg=None, image_size=448, **kw):
+        super().__init__(**kw)
+        self.perceiver_cfg = _sub(CustomDDETRConfig, perceiver_cfg)
+        self.llm_cfg = _sub(LlamaConfig, llm_cfg)
+        self.region_cfg = _sub(RegionConfig, region_cfg)
+        self.nms_thres = nms_thres
+        self.box_score_thres = box_score_thres
+        self.max_region_num = max_region_num
+        self.num_new_token = num_new_token
+        self.image_size = image_size
+        self.vocab_size = self.llm_cfg.vocab_size + num_new_token
+
+    def to_json_string(self):
+        return json.dumps(self.to_dict(), indent=2, sort_keys=True) + "\n"
+
+    def save_pretrained(self, path):
+        os.makedirs(path, exist_ok=True)
+        with open(os.path.join(path, "config.json"), "w") as f:
+            f.write(self.to_json_string())
+
+    @classmethod
+    def from_pretrained(cls, path):
+        with open(os.path.join(path, "config.json")) as f:
+            d = json.load(f)
+        known = dict(llm_cfg=d.pop("llm_cfg", None), perceiver_cfg=d.pop("perceiver_cfg", None),
+                     region_cfg=d.pop("region_cfg", None))
+        d.pop("vocab_size", None)
+        keep = {k: d[k] for k in ("num_new_token", "nms_thres", "box_score_thres", "max_region_num", "image_size")
+                if k in d}
+        # tolerate the many bookkeeping keys HF writes into config.json
+        for sub in ("llm_cfg",):
+            if isinstance(known[sub], dict):
+                known[sub] = {k: v for k, v in known[sub].items() if k in LlamaConfig._defaults}
+        if isinstance(known["perceiver_cfg"], dict):
+            pc = known["perceiver_cfg"]
+            known["perceiver_cfg"] = dict(
+                vis_encoder_cfg={k: v for k, v in (pc.get("vis_encoder_cfg") or {}).items() if k in Dinov2Config._defaults},
+                ddetr_cfg={k: v for k, v in (pc.get("ddetr_cfg") or {}).items() if k in DeformableDetrConfig._defaults},
+                vis_output_layer=pc.get("vis_output_layer", -1), zs_weight_path=pc.get("zs_weight_path"))
+        return cls(**known, **keep)
+
+
+# ---- named configurations -------------------------------------------------------------------------------
+def groma_7b(**kw):
+    """The benchmark architecture: DINOv2-L + DDETR(300) + region encoder + Vicuna-7B, 114 new tokens."""
+    return GromaConfig(num_new_token=114, **kw)
+
+
+def groma_tiny(**kw):
+    """Structurally identical, small enough for the fp32 CPU oracle to finish in seconds (parity tests)."""
+    return GromaConfig(
+        llm_cfg=dict(hidden_size=512, intermediate_size=1408, num_hidden_layers=2, num_attention_heads=4,
+                     vocab_size=32000),
+        perceiver_cfg=dict(vis_encoder_cfg=dict(hidden_size=256, num_hidden_layers=4, num_attention_heads=4),
+                           ddetr_cfg=dict(encoder_layers=2, decoder_layers=2)),
+        region_cfg=dict(num_fuse=2, mid_dim=256),
+        num_new_token=114, **kw)

@@ -1,0 +1,314 @@
+"""Device-side stages of the Groma forward path, as sequences of HIP kernels (groma_amd/ops.py -> C ABI).
+
+Stage            reference                                                    SURVEY §8a rows
+VitEngine        HF Dinov2Model, groma/model/groma.py:222                     a1
+ProposerEngine   groma/model/ddetr.py + ddetr_transformer.py, groma.py:240-249 a4-a10
+RegionEngine     groma/model/roi_align.py:97-327                               a14-a17
+LlamaEngine      HF LlamaModel + heads, groma.py:389-402                       a19-a22
+Residual streams are fp32 in HBM; GEMM operands bf16 (fp32 accumulate); the proposer is fp32 end to end.
+"""
+import math
+
+import torch
+
+from . import ops
+
+BF16, F32, I32, I64 = torch.bfloat16, torch.float32, torch.int32, torch.int64
+
+
+def _ru(x, m):
+    return (x + m - 1) // m * m
+
+
+class Workspace:
+    """Shape-keyed scratch buffers (allocated once, reused across forwards; zero-filled on first use)."""
+
+    def __init__(self, device):
+        self.device, self._b = device, {}
+
+    def get(self, name, shape, dtype):
+        key = (name, tuple(shape), dtype)
+        t = self._b.get(key)
+        if t is None:
+            t = torch.zeros(tuple(shape), dtype=dtype, device=self.device)
+            self._b[key] = t
+        return t
+
+
+# ------------------------------------------------------------------------------------------------ DINOv2
+class VitEngine:
+    def __init__(self, w, cfg, ws):
+        self.w, self.ws = w, ws
+        vc = cfg.perceiver_cfg.vis_encoder_cfg
+        self.D, self.H, self.P, self.eps = vc.hidden_size, vc.num_attention_heads, vc.patch_size, vc.layer_norm_eps
+        self.hd = self.D // self.H
+        self.G = w["grid"]
+        self.T = 1 + self.G * self.G
+        self.keep = 4  # hidden states the path consumes: -1..-4 (groma.py:224,240,312)
+
+    def forward(self, images):
+        """images f32 [bs,3,S,S] -> list of the last `keep` hidden states, each f32 [bs,T,D] (pre final-LN, T7)."""
+        w, ws = self.w, self.ws
+        bs = images.shape[0]
+        D, T, G, H, hd = self.D, self.T, self.G, self.H, self.hd
+        M = bs * T
+        nl = len(w["layers"])
+        a = ops.patchify(images, self.P, w["Kpad"])
+        kept = [ws.get(f"vit_h{i}", (bs, T, D), F32) for i in range(self.keep)]
+        scratch = [ws.get(f"vit_s{i}", (bs, T, D), F32) for i in range(2)]
+        mid = ws.get("vit_mid", (bs, T, D), F32)
+
+        def out_buf(layer_out_index):  # hidden_states index (0 = embeddings ... nl = last layer)
+            k = layer_out_index - (nl + 1 - self.keep)
+            return kept[k] if k >= 0 else scratch[layer_out_index & 1]
+
+        h = out_buf(0)
+        ops.fill_rows(w["cls_pos0"], h, bs, T * D)
+        ops.gemm(a, w["patch_w"], bias=w["patch_b"], resid=w["pos_patch"], resid_mod=G * G, out=h, out_f32=True,
+                 row_map=(G * G, T, 1))
+        Tp = _ru(T, 64)
+        q = ws.get("vit_q", (bs, H, T, hd), BF16)
+        k = ws.get("vit_k", (bs, H, Tp, hd), BF16)
+        vt = ws.get("vit_vt", (bs, H, hd, Tp), BF16)
+        for i, L in enumerate(w["layers"]):
+            x = ops.layernorm(h, L["ln1_g"], L["ln1_b"], self.eps, out_bf16=True, out=ws.get("vit_x", (M, D), BF16))
+            qkv = ops.gemm(x, L["wqkv"], bias=L["bqkv"], out=ws.get("vit_qkv", (M, 3 * D), BF16))
+            ops.qkv_split(qkv, q, k, vt, B=bs, H=H, L=T, hd=hd)
+            ctx = ops.attention(q, k, vt, Skv=T, causal=False, out=ws.get("vit_ctx", (M, D), BF16))
+            ops.gemm(ctx, L["wo"], bias=L["bo"], scale=L["ls1"], resid=h, out=mid, out_f32=True)
+            x = ops.layernorm(mid, L["ln2_g"], L["ln2_b"], self.eps, out_bf16=True, out=ws.get("vit_x", (M, D), BF16))
+            y = ops.gemm(x, L["w1"], bias=L["b1"], act=1, out=ws.get("vit_y", (M, L["w1"].shape[0]), BF16))
+            hn = out_buf(i + 1)
+            ops.gemm(y, L["w2"], bias=L["b2"], scale=L["ls2"], resid=mid, out=hn, out_f32=True)
+            h = hn
+        first = nl + 1 - self.keep
+        return [out_buf(j) for j in range(max(first, 0), nl + 1)]
+
+
+# ------------------------------------------------------------------------------------------------ DDETR proposer
+class ProposerEngine:
+    def __init__(self, w, cfg, ws):
+        self.w, self.ws = w, ws
+        dc = cfg.perceiver_cfg.ddetr_cfg
+        self.dc = dc
+        self.d, self.g = w["d"], w["g"]
+        self.heads_e, self.heads_d = dc.encoder_attention_heads, dc.decoder_attention_heads
+        if self.d // self.heads_e != 32 or self.d // self.heads_d != 32:
+            raise NotImplementedError("MSDA / decoder attention kernels are built for head_dim 32")
+
+    @staticmethod
+    def _mlp3(x, layers):
+        x = ops.gemm_f32(x, layers[0][0], bias=layers[0][1], act=2)
+        x = ops.gemm_f32(x, layers[1][0], bias=layers[1][1], act=2)
+        return ops.gemm_f32(x, layers[2][0], bias=layers[2][1])
+
+    def forward(self, hidden4, debug=None):
+        """hidden4: the last 4 ViT hidden states (f32 [bs,T,D]).  Returns pred_boxes f32 [bs,Q,4] (cxcywh),
+        fused scores f32 [bs,Q], topk_idx int32 [bs,Q]."""
+        w, dc = self.w, self.dc
+        bs, T, D = hidden4[0].shape
+        g, d = self.g, self.d
+        HW = g * g
+        x_in = ops.mean4_tokens(*hidden4)
+        src = ops.gemm_f32(x_in, w["proj_w"], bias=w["proj_b"])
+        x = ops.layernorm(src, w["proj_ln"][0], w["proj_ln"][1], 1e-6)
+        src = x
+        for L in w["enc"]:
+            a = L["att"]
+            qin = ops.add_rows(x, w["pos"], b_mod=HW)
+            offw = ops.gemm_f32(qin, a["offw_w"], bias=a["offw_b"])
+            val = ops.gemm_f32(x, a["v_w"], bias=a["v_b"])
+            samp = ops.msda(val, offw, w["enc_ref"], B=bs, Q=HW, heads=self.heads_e, n_points=dc.encoder_n_points, Hs=g,
+                            Ws=g, rdim=2, ref_batched=False)
+            y = ops.gemm_f32(samp, a["o_w"], bias=a["o_b"])
+            x = ops.layernorm(x, L["ln1"][0], L["ln1"][1], 1e-5, add=y)
+            y = ops.gemm_f32(ops.gemm_f32(x, L["fc1"][0], bias=L["fc1"][1], act=2), L["fc2"][0], bias=L["fc2"][1])
+            x = ops.layernorm(x, L["ln2"][0], L["ln2"][1], 1e-5, add=y)
+        memory = x
+        oq = ops.gemm_f32(memory, w["enc_output"][0], bias=w["enc_output"][1])
+        oq = ops.layernorm(oq, w["enc_output_norm"][0], w["enc_output_norm"][1], 1e-5)
+        enc_class = ops.gemm_f32(oq, w["class_enc"][0], bias=w["class_enc"][1])  # [bs*HW, 1]
+        delta = self._mlp3(oq, w["bbox_enc"])
+        Q = dc.two_stage_num_proposals
+        idx = ops.topk_desc(enc_class.view(bs, HW), Q)
+        ref0, pose = ops.ddetr_topk_gather(idx, delta, w["proposals"], B=bs, S=HW, Kq=Q, npf=d // 2)
+        pt = ops.gemm_f32(pose, w["pos_trans"][0], bias=w["pos_trans"][1])
+        pt = ops.layernorm(pt, w["pos_trans_norm"][0], w["pos_trans_norm"][1], 1e-5)
+        qpos = pt[:, :d].contiguous()
+        hs = w["target"].unsqueeze(0).expand(bs, -1, -1).reshape(bs * Q, d).contiguous()
+        n = len(w["dec"])
+        ref_prev = ref0
+        pred = None
+        for i, L in enumerate(w["dec"]):
+            qk = ops.gemm_f32(ops.add_rows(hs, qpos), L["qk_w"], bias=L["qk_b"])
+            v = ops.gemm_f32(hs, L["v"][0], bias=L["v"][1])
+            att = ops.mha32(qk, v, B=bs, Q=Q, heads=self.heads_d, scale=32 ** -0.5)
+            y = ops.gemm_f32(att, L["o"][0], bias=L["o"][1])
+            hs = ops.layernorm(hs, L["ln1"][0], L["ln1"][1], 1e-5, add=y)
+            a = L["att"]
+            offw = ops.gemm_f32(ops.add_rows(hs, qpos), a["offw_w"], bias=a["offw_b"])
+            val = ops.gemm_f32(memory, a["v_w"], bias=a["v_b"])
+            samp = ops.msda(val, offw, ref0, B=bs, Q=Q, heads=self.heads_d, n_points=dc.decoder_n_points, Hs=g, Ws=g,
+                            rdim=4, ref_batched=True)
+            y = ops.gemm_f32(samp, a["o_w"], bias=a["o_b"])
+            hs = ops.layernorm(hs, L["ln2"][0], L["ln2"][1], 1e-5, add=y)
+            y = ops.gemm_f32(ops.gemm_f32(hs, L["fc1"][0], bias=L["fc1"][1], act=2), L["fc2"][0], bias=L["fc2"][1])
+            hs = ops.layernorm(hs, L["ln3"][0], L["ln3"][1], 1e-5, add=y)
+            # box refinement; the reference never feeds refined points back (ddetr_transformer.py:163, T3), so only
+            # the last two levels reach pred_boxes (ddetr_transformer.py:696-728)
+            if i == n - 2:
+                ref_prev = ops.box_refine(self._mlp3(hs, w["bbox_prev"]), ref0)
+            if i == n - 1:
+                pred = ops.box_refine(self._mlp3(hs, w["bbox_last"]), ref_prev)
+        coco = ops.gemm_f32(hs, w["class_coco"][0], bias=w["class_coco"][1])
+        sa1b = ops.gemm_f32(hs, w["class_sa1b"][0], bias=w["class_sa1b"][1])
+        scores = ops.score_fuse(coco, sa1b, bs * Q)
+        if debug is not None:
+            debug.update(enc_class=enc_class.view(bs, HW), memory=memory.view(bs, HW, d), src=src.view(bs, HW, d),
+                         ref0=ref0.view(bs, Q, 4), coco=coco.view(bs, Q), sa1b=sa1b.view(bs, Q), last_hidden=hs.view(bs, Q, d))
+        return pred.view(bs, Q, 4), scores.view(bs, Q), idx
+
+
+# ------------------------------------------------------------------------------------------------ region encoder
+class RegionEngine:
+    STRIDES = (14 / 8, 14 / 4, 14 / 2)  # groma/model/roi_align.py:204 (2x off the true strides: T2, reproduced)
+
+    def __init__(self, w, cfg, ws):
+        self.w, self.ws, self.rc = w, ws, cfg.region_cfg
+        self.D = cfg.perceiver_cfg.vis_encoder_cfg.hidden_size
+        self.G = cfg.image_size // cfg.perceiver_cfg.vis_encoder_cfg.patch_size
+        self.img = cfg.image_size
+        if self.rc.num_levels != 3:
+            raise NotImplementedError("3 pyramid levels (reference: MLVLROIQueryModule(num_levels=3))")
+
+    def fuse(self, hidden3):
+        """MLVLFuseModule: 3 ViT hidden states -> 3 NHWC bf16 maps [bs,S,S,D], S = 4G, 2G, G."""
+        w, ws, rc, D, G = self.w, self.ws, self.rc, self.D, self.G
+        bs = hidden3[0].shape[0]
+        S = [G * 4, G * 2, G]
+        maps, sums = [], [None, None, None]
+        for l in range(3):
+            a = ops.upsample_coord_pack(hidden3[l], G, S[l], w["Cpad"])
+            maps.append(ops.gemm(a, w["in_w"][l], bias=w["in_b"][l], out=ws.get(f"reg_in{l}", (bs * S[l] * S[l], D), BF16)))
+        gamma = beta = None
+        for r in range(rc.num_fuse):
+            new_maps, new_sums = [], []
+            for l in range(3):
+                top, dow = min(l + 1, 2), max(l - 1, 0)
+                pad = ws.get(f"reg_pad{l}", (bs, S[l] + 2, S[l] + 2, D), BF16)
+                ops.fuse_shuffle((maps[l], sums[l], S[l]), (maps[top], sums[top], S[top]), (maps[dow], sums[dow], S[dow]),
+                                 gamma, beta, pad, imgs=bs, C=D, groups=rc.gn_groups, eps=1e-5, shuffle=True, pad=1)
+                out = ws.get(f"reg_conv{l}_{r & 1}", (bs * S[l] * S[l], D), BF16)
+                ops.gemm(pad, w["fuse"][r]["w"], conv=(bs, S[l], S[l], D, 0), out=out)
+                new_maps.append(out)
+                new_sums.append(ops.gn_stats(out, bs, S[l] * S[l], D))
+            maps, sums = new_maps, new_sums
+            gamma, beta = w["fuse"][r]["g"], w["fuse"][r]["b"]
+        feats = []
+        for l in range(3):
+            f = ws.get(f"reg_feat{l}", (bs, S[l], S[l], D), BF16)
+            ops.fuse_shuffle((maps[l], sums[l], S[l]), None, None, gamma, beta, f, imgs=bs, C=D, groups=rc.gn_groups,
+                             eps=1e-5, shuffle=False, pad=0)
+            feats.append(f)
+        return feats, S
+
+    def extract(self, feats, S, boxes, img_idx):
+        """MlvlRoIExtractor: boxes f32 [R,4] normalised cxcywh (device), img_idx f32 [R] -> region tokens f32 [R, T]."""
+        w, ws, rc, D = self.w, self.ws, self.rc, self.D
+        R = boxes.shape[0]
+        P = rc.roi_size
+        rois = torch.cat([img_idx[:, None], boxes * float(self.img)], dim=1).contiguous()  # (idx, "x1,y1,x2,y2") -- T1
+        tiles = ws.get("reg_tiles", (3, R, P + 2, P + 2, D), BF16)
+        for l in range(3):
+            ops.roi_align_pack(feats[l], rois, tiles[l], C=D, H=S[l], W=S[l], ph=P, pw=P,
+                               spatial_scale=1.0 / self.STRIDES[l], sampling_ratio=2, aligned=True, pad=1)
+        pc = ops.gemm(tiles, w["pconv_w"], bias=w["pconv_b"], act=2, conv=(R, P, P, D, R * (P + 2) * (P + 2) * D),
+                      out=ws.get("reg_pc", (R * P * P, D), BF16))
+        # pos_embedd(rois) on the UNSCALED cxcywh boxes (roi_align.py:278)
+        b16 = torch.zeros((R, 16), dtype=F32, device=boxes.device)
+        b16[:, :4] = boxes
+        pe = ops.gemm_f32(b16, w["pe0_w"], bias=w["pe0_b"], act=2)
+        pe = ops.layernorm(pe, w["pe_ln1"][0], w["pe_ln1"][1], 1e-5)
+        pe = ops.gemm_f32(pe, w["pe3_w"], bias=w["pe3_b"], act=2)
+        pe = ops.layernorm(pe, w["pe_ln2"][0], w["pe_ln2"][1], 1e-5)
+        K = P * P * D
+        splits = max(1, min(32, K // 4096))
+        fl = ops.gemm(pc.view(R, K), w["flat_w"], bias=w["flat_b"], resid=pe, splits=splits)
+        return ops.gemm(fl, w["up_w"], bias=w["up_b"], out_f32=True)
+
+
+# ------------------------------------------------------------------------------------------------ LLaMA
+class KVCache:
+    """Device KV cache: K [bs,H,Smax,hd], V transposed [bs,H,hd,Smax] per layer.  Indexing gives the reference's legacy
+    tuple view: cache[l][0].shape == [bs, H, S, hd] (groma/model/groma.py:377-378, groma/serve/model_worker.py:298)."""
+
+    def __init__(self, n_layers, bs, H, hd, smax, device):
+        self.k = [torch.zeros((bs, H, smax, hd), dtype=BF16, device=device) for _ in range(n_layers)]
+        self.vt = [torch.zeros((bs, H, hd, smax), dtype=BF16, device=device) for _ in range(n_layers)]
+        self.seq_len, self.smax, self.bs = 0, smax, bs
+
+    def __len__(self):
+        return len(self.k)
+
+    def __getitem__(self, l):
+        S = self.seq_len
+        return (self.k[l][:, :, :S], self.vt[l][:, :, :, :S].transpose(2, 3))
+
+    def __bool__(self):
+        return True
+
+    def grow(self, smax):
+        if smax <= self.smax:
+            return
+        for l in range(len(self.k)):
+            k = torch.zeros((self.bs,) + tuple(self.k[l].shape[1:2]) + (smax, self.k[l].shape[3]), dtype=BF16,
+                            device=self.k[l].device)
+            k[:, :, : self.smax] = self.k[l]
+            v = torch.zeros(tuple(self.vt[l].shape[:3]) + (smax,), dtype=BF16, device=self.k[l].device)
+            v[..., : self.smax] = self.vt[l]
+            self.k[l], self.vt[l] = k, v
+        self.smax = smax
+
+
+class LlamaEngine:
+    def __init__(self, w, cfg, ws):
+        self.w, self.ws = w, ws
+        lc = cfg.llm_cfg
+        self.T, self.H, self.eps, self.I = lc.hidden_size, lc.num_attention_heads, lc.rms_norm_eps, lc.intermediate_size
+        self.hd = self.T // self.H
+        self.V, self.Vpad = w["V"], w["Vpad"]
+        self.V0 = lc.vocab_size
+
+    def embed(self, ids):
+        return ops.embed_gather(ids.reshape(-1).contiguous(), self.w["embed"], self.w["new_embed"])
+
+    def new_cache(self, bs, smax, device):
+        return KVCache(len(self.w["layers"]), bs, self.H, self.hd, _ru(smax, 64), device)
+
+    def forward(self, h, bs, L, cache, kv_len=None, all_logits=True):
+        """h: f32 [bs*L, T] input embeddings (consumed as the residual stream, updated in place).
+        Appends L positions to `cache`.  Returns logits f32 [bs, L or 1, V] (view into a Vpad-wide buffer)."""
+        w, ws, T, H, hd = self.w, self.ws, self.T, self.H, self.hd
+        M = bs * L
+        past = cache.seq_len
+        if past + L > cache.smax:
+            cache.grow(_ru(past + L + 64, 64))
+        q = ws.get("llm_q", (bs, H, L, hd), BF16)
+        for i, Lw in enumerate(w["layers"]):
+            x = ops.rmsnorm(h, Lw["n1"], self.eps, out=ws.get("llm_x", (M, T), BF16))
+            qkv = ops.gemm(x, Lw["wqkv"], out=ws.get("llm_qkv", (M, 3 * T), BF16))
+            ops.qkv_split(qkv, q, cache.k[i], cache.vt[i], B=bs, H=H, L=L, hd=hd, pos0=past, cos=w["cos"], sin=w["sin"])
+            ctx = ops.attention(q, cache.k[i], cache.vt[i], Skv=past + L, causal=True, q_pos0=past, kv_len=kv_len,
+                                out=ws.get("llm_ctx", (M, T), BF16))
+            ops.gemm(ctx, Lw["wo"], resid=h, out=h, out_f32=True)
+            x = ops.rmsnorm(h, Lw["n2"], self.eps, out=ws.get("llm_x", (M, T), BF16))
+            y = ops.gemm(x, Lw["wgu"], act=3, out=ws.get("llm_y", (M, self.I), BF16))
+            ops.gemm(y, Lw["wd"], resid=h, out=h, out_f32=True)
+        cache.seq_len = past + L
+        hn = ops.rmsnorm(h, w["norm"], self.eps, out=ws.get("llm_x", (M, T), BF16))
+        if not all_logits and L > 1:
+            hn = hn.view(bs, L, T)[:, -1].contiguous()
+            logits = ops.gemm(hn, w["head"], out_f32=True)
+            return logits.view(bs, 1, self.Vpad)[:, :, : self.V], hn
+        logits = ops.gemm(hn, w["head"], out_f32=True, out=ws.get("llm_logits", (M, self.Vpad), F32))
+        return logits.view(bs, L, self.Vpad)[:, :, : self.V], hn

@@ -1,0 +1,396 @@
+"""GromaModel / GromaConfig -- the drop-in boundary (reference: groma/model/groma.py:31-431).
+
+Same constructor-level names, `forward()` / `generate()` / `prepare_inputs_for_generation()` /
+`init_special_token_id()` signatures, argument meaning, return packaging and error behaviour (asserts) as the
+reference, so `groma/eval/*.py` and `groma/serve/model_worker.py` call it unchanged:
+
+    model = GromaModel.from_pretrained(path).cuda(); model.init_special_token_id(tokenizer)
+    out = model.generate(input_ids, images=image, use_cache=True, do_sample=False, max_new_tokens=3,
+                         return_dict_in_generate=True, output_hidden_states=True,
+                         generation_config=model.generation_config)
+    out.sequences;  out.hidden_states[0][-1]['pred_boxes'][0]
+
+Host code is Python; every tensor computation is a HIP kernel behind the C ABI (no eager fallback: a missing
+libgroma_hip.so raises).  The host keeps only index bookkeeping the reference also does in Python
+(placeholder splice, randperm, refer-box matching on a handful of boxes).
+"""
+import glob
+import json
+import os
+from types import SimpleNamespace
+
+import torch
+
+from . import engine, ops, weights
+from .config import GromaConfig
+from .constants import DEFAULT_TOKENS, REGION_IDX_TOKENS, IGNORE_INDEX
+
+F32, I32, I64 = torch.float32, torch.int32, torch.int64
+
+
+class CausalLMOutputWithPast(dict):
+    """Attribute + index access like transformers.modeling_outputs.CausalLMOutputWithPast."""
+
+    def __init__(self, **kw):
+        super().__init__(**kw)
+        self.__dict__.update(kw)
+
+    def __getitem__(self, k):
+        if isinstance(k, int):
+            return [v for v in self.values() if v is not None][k]
+        return super().__getitem__(k)
+
+
+class GenerateOutput(SimpleNamespace):
+    pass
+
+
+def _c2c(b):  # HF center_to_corners_format
+    cx, cy, w, h = b.unbind(-1)
+    return torch.stack([cx - 0.5 * w, cy - 0.5 * h, cx + 0.5 * w, cy + 0.5 * h], dim=-1)
+
+
+def _box_iou(b1, b2):  # torchvision.ops.box_iou on a handful of host-side boxes
+    a1 = (b1[:, 2] - b1[:, 0]) * (b1[:, 3] - b1[:, 1])
+    a2 = (b2[:, 2] - b2[:, 0]) * (b2[:, 3] - b2[:, 1])
+    lt = torch.max(b1[:, None, :2], b2[:, :2])
+    rb = torch.min(b1[:, None, 2:], b2[:, 2:])
+    wh = (rb - lt).clamp(min=0)
+    inter = wh[:, :, 0] * wh[:, :, 1]
+    return inter / (a1[:, None] + a2 - inter)
+
+
+class GromaModel:
+    config_class = GromaConfig
+
+    def __init__(self, config: GromaConfig, source=None, device="cuda"):
+        self.config = config
+        self.device = torch.device(device)
+        self.training = False
+        self.pad_token_id = None
+        self.img_token_id = None
+        self.reg_token_id = None
+        self.refer_box_token_id = None
+        self.refer_feat_token_id = None
+        self.ground_box_token_id = None
+        self.box_idx_token_ids = None
+        lc = config.llm_cfg
+        self.generation_config = SimpleNamespace(pad_token_id=lc.pad_token_id, bos_token_id=lc.bos_token_id,
+                                                 eos_token_id=lc.eos_token_id, do_sample=False, max_new_tokens=20)
+        self._ws = None
+        self._loaded = False
+        if source is not None:
+            self._load(source)
+
+    # ------------------------------------------------------------------ construction / loading
+    def _load(self, source):
+        ops._lib.load()  # fail loudly if the HIP library is missing
+        cfg = self.config
+        self._ws = engine.Workspace(self.device)
+        self.vit = engine.VitEngine(weights.pack_vit(source, cfg), cfg, self._ws)
+        self.proposer = engine.ProposerEngine(weights.pack_ddetr(source, cfg), cfg, self._ws)
+        self.region = engine.RegionEngine(weights.pack_region(source, cfg), cfg, self._ws)
+        self.bridge = weights.pack_bridge(source, cfg)
+        self.llm = engine.LlamaEngine(weights.pack_llm(source, cfg), cfg, self._ws)
+        self._loaded = True
+
+    @classmethod
+    def from_state_dict(cls, config, state_dict, device="cuda"):
+        return cls(config, weights.Source.from_state_dict(state_dict, torch.device(device)), device)
+
+    @classmethod
+    def from_synthetic(cls, config, seed=0, device="cuda"):
+        """Random-init weights of the configured architecture, generated on the device (benchmark path)."""
+        return cls(config, weights.Source.synthetic(config, seed, torch.device(device)), device)
+
+    @classmethod
+    def from_pretrained(cls, path, torch_dtype=None, device="cuda", **kw):
+        """Reads a reference checkpoint directory: config.json + *.safetensors / pytorch_model*.bin shards with the
+        reference's parameter names (groma/eval/eval_rec.py:69).  Weights are repacked to bf16 device layouts."""
+        for unsupported in ("load_in_8bit", "load_in_4bit", "quantization_config"):
+            if kw.get(unsupported):
+                raise NotImplementedError(f"{unsupported} is not supported by the MI355X path (bf16 / fp32 only)")
+        config = GromaConfig.from_pretrained(path)
+        sd = {}
+        st = sorted(glob.glob(os.path.join(path, "*.safetensors")))
+        if st:
+            from safetensors.torch import load_file
+            for f in st:
+                sd.update(load_file(f))
+        else:
+            for f in sorted(glob.glob(os.path.join(path, "pytorch_model*.bin"))):
+                sd.update(torch.load(f, map_location="cpu"))
+        if not sd:
+            raise FileNotFoundError(f"no weight shards under {path}")
+        return cls.from_state_dict(config, sd, device)
+
+    def cuda(self, device=None):
+        return self
+
+    def eval(self):
+        return self
+
+    def to(self, *a, **k):
+        return self
+
+    def init_special_token_id(self, tokenizer):  # groma/model/groma.py:136-144
+        self.pad_token_id = tokenizer.pad_token_id
+        self.img_token_id = tokenizer.convert_tokens_to_ids([DEFAULT_TOKENS['image']])[0]
+        self.reg_token_id = tokenizer.convert_tokens_to_ids([DEFAULT_TOKENS['region']])[0]
+        self.refer_box_token_id = tokenizer.convert_tokens_to_ids([DEFAULT_TOKENS['rbox']])[0]
+        self.refer_feat_token_id = tokenizer.convert_tokens_to_ids([DEFAULT_TOKENS['rfeat']])[0]
+        self.ground_box_token_id = tokenizer.convert_tokens_to_ids([DEFAULT_TOKENS['gbox']])[0]
+        self.box_idx_token_ids = tokenizer.convert_tokens_to_ids(REGION_IDX_TOKENS)
+        self.generation_config.pad_token_id = tokenizer.pad_token_id
+        return
+
+    def get_input_embeddings(self, input_ids):  # groma/model/groma.py:165-174
+        bs, L = input_ids.shape
+        return self.llm.embed(input_ids.to(self.device)).view(bs, L, -1)
+
+    def prepare_inputs_for_generation(self, input_ids, past_key_values=None, attention_mask=None, inputs_embeds=None,
+                                      **kwargs):  # groma/model/groma.py:176-200
+        if past_key_values:
+            input_ids = input_ids[:, -1:]
+        if inputs_embeds is not None and past_key_values is None:
+            model_inputs = {"inputs_embeds": inputs_embeds}
+        else:
+            model_inputs = {"input_ids": input_ids}
+        model_inputs.update({
+            "past_key_values": past_key_values, "attention_mask": attention_mask, "use_cache": kwargs.get("use_cache"),
+            "images": kwargs.get("images", None), "refer_boxes": kwargs.get("refer_boxes", None),
+            "ground_boxes": kwargs.get("ground_boxes", None)})
+        return model_inputs
+
+    # ------------------------------------------------------------------ stages
+    def perceive(self, images, refer_boxes=None, ground_boxes=None, debug=None):
+        """Steps A-E (groma.py:218-280): ViT -> proposer -> NMS -> shuffle.  Returns (hidden4, selected_boxes list of
+        device f32 [N_i,4], aux dict)."""
+        cfg = self.config
+        images = images.to(device=self.device, dtype=F32).contiguous()
+        bs = images.shape[0]
+        hidden4 = self.vit.forward(images)
+        pred_boxes, scores, topk_idx = self.proposer.forward(hidden4, debug=debug)
+        Q = pred_boxes.shape[1]
+        dev = self.device
+        if refer_boxes is None:
+            refer_boxes = [torch.empty((0, 4), device=dev) for _ in range(bs)]
+        if ground_boxes is None:
+            ground_boxes = [torch.empty((0, 4), device=dev) for _ in range(bs)]
+        n_extra = [refer_boxes[i].shape[0] + ground_boxes[i].shape[0] for i in range(bs)]
+        nmax = Q + max(n_extra)
+        if max(n_extra) == 0:
+            boxes_all, scores_all, n_valid = pred_boxes.contiguous(), scores.contiguous(), None
+        else:
+            boxes_all = torch.zeros((bs, nmax, 4), dtype=F32, device=dev)
+            scores_all = torch.zeros((bs, nmax), dtype=F32, device=dev)
+            boxes_all[:, :Q], scores_all[:, :Q] = pred_boxes, scores
+            for i in range(bs):  # groma.py:259-264: refer boxes score 1.0, ground boxes 0.2
+                r, g = refer_boxes[i].to(dev, F32), ground_boxes[i].to(dev, F32)
+                boxes_all[i, Q:Q + len(r)], scores_all[i, Q:Q + len(r)] = r, 1.0
+                boxes_all[i, Q + len(r):Q + len(r) + len(g)] = g
+                scores_all[i, Q + len(r):Q + len(r) + len(g)] = 0.2
+            n_valid = torch.tensor([Q + e for e in n_extra], dtype=I32, device=dev)
+        keep, n_keep = ops.nms(boxes_all, scores_all, float(cfg.nms_thres), float(cfg.box_score_thres),
+                               int(cfg.max_region_num), n_valid=n_valid)
+        # one host round trip: kept indices + scores arg-max fallback (the reference syncs at nms / len / randperm too)
+        keep_h, n_keep_h = keep.cpu(), n_keep.cpu()
+        selected, sel_idx = [], []
+        for i in range(bs):
+            nk = int(n_keep_h[i])
+            if nk > 0:  # groma.py:273-276 -- torch.randperm on the CPU global RNG (T4)
+                inds = keep_h[i, :nk]
+                inds = inds[torch.randperm(nk)]
+            else:       # groma.py:277-279
+                nv = Q + n_extra[i]
+                inds = torch.max(scores_all[i, :nv], dim=0).indices.reshape(1).cpu()
+            sel_idx.append(inds)
+            selected.append(boxes_all[i].index_select(0, inds.to(dev)))
+        aux = dict(pred_boxes=pred_boxes, scores=scores, topk_idx=topk_idx, nms_keep=[keep_h[i, :int(n_keep_h[i])] for i in range(bs)],
+                   sel_idx=sel_idx)
+        return hidden4, selected, aux
+
+    def _splice(self, input_ids_h, n_img_tok, n_reg):
+        """groma.py:317-357 on the host (index bookkeeping only)."""
+        new_ids = []
+        for i in range(input_ids_h.shape[0]):
+            ids = input_ids_h[i]
+            assert self.img_token_id in ids and self.reg_token_id in ids
+            img_pos = (ids == self.img_token_id).nonzero(as_tuple=True)[0]
+            reg_pos = (ids == self.reg_token_id).nonzero(as_tuple=True)[0]
+            pad_pos = (ids == self.pad_token_id).nonzero(as_tuple=True)[0]
+            pad_pos = pad_pos[0] if len(pad_pos) > 0 else len(ids)
+            assert img_pos < reg_pos
+            img_ph = torch.full((n_img_tok,), self.img_token_id)
+            reg_ph = torch.tensor([[self.box_idx_token_ids[j], self.reg_token_id] for j in range(n_reg[i])],
+                                  dtype=I64).reshape(-1)
+            new_ids.append(torch.cat((ids[:img_pos], img_ph, ids[img_pos + 1: reg_pos], reg_ph, ids[reg_pos + 1: pad_pos])))
+        out = torch.nn.utils.rnn.pad_sequence(new_ids, batch_first=True, padding_value=self.pad_token_id)
+        return out, out.ne(self.pad_token_id)
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, input_ids=None, inputs_embeds=None, labels=None, attention_mask=None, images=None,
+                refer_boxes=None, ground_boxes=None, past_key_values=None, use_cache=False, output_attentions=False,
+                output_hidden_states=False, return_dict=False, _last_logits_only=False, _reserve=0):
+        if not self._loaded:
+            raise RuntimeError("GromaModel has no weights: use from_pretrained / from_state_dict / from_synthetic")
+        if output_attentions:
+            raise NotImplementedError("output_attentions is not available from the fused attention kernel")
+        dev = self.device
+        vis_outputs = None
+        with torch.no_grad():
+            if past_key_values is None:
+                hidden4, selected_boxes, aux = self.perceive(images, refer_boxes, ground_boxes)
+                bs = len(selected_boxes)
+                ids_h = input_ids.cpu()
+                # replace <refer_box>/<ground_box> placeholders by matched <r_k> ids (groma.py:283-309), in place
+                refer_box_inds = []
+                need_boxes = any((self.refer_box_token_id in ids_h[i]) or (self.ground_box_token_id in ids_h[i]) for i in range(bs))
+                sel_h = [b.cpu() for b in selected_boxes] if need_boxes else None
+                box_ids = torch.tensor(self.box_idx_token_ids)
+                for i in range(bs):
+                    if self.refer_box_token_id in ids_h[i]:
+                        ious = _box_iou(_c2c(refer_boxes[i].cpu().float()), _c2c(sel_h[i]))
+                        matched = torch.max(ious, dim=-1).indices
+                        refer_box_inds.append(matched)
+                        ids_h[i].masked_scatter_(ids_h[i] == self.refer_box_token_id, box_ids[matched])
+                    else:
+                        refer_box_inds.append([])
+                    if self.ground_box_token_id in ids_h[i]:
+                        ious = _box_iou(_c2c(ground_boxes[i].cpu().float()), _c2c(sel_h[i]))
+                        matched = torch.max(ious, dim=-1).indices
+                        mask = ids_h[i] == self.ground_box_token_id
+                        ids_h[i].masked_scatter_(mask, box_ids[matched])
+                        if labels is not None:
+                            labels[i].masked_scatter_(mask.to(labels.device), box_ids[matched].to(labels.device))
+                assert len(refer_box_inds) == bs
+                if input_ids.is_cuda and need_boxes:
+                    input_ids.copy_(ids_h)  # the reference mutates the caller's input_ids (groma.py:295,307)
+                # region tokens (groma.py:312-315)
+                feats, S = self.region.fuse(hidden4[-3:])
+                n_reg = [b.shape[0] for b in selected_boxes]
+                boxes_cat = torch.cat(selected_boxes).contiguous()
+                img_idx = torch.cat([torch.full((n,), float(i)) for i, n in enumerate(n_reg)]).to(dev)
+                region_features = self.region.extract(feats, S, boxes_cat, img_idx)  # f32 [R, T]
+                # image tokens (groma.py:224-237, :361)
+                last = hidden4[self.config.perceiver_cfg.vis_output_layer]
+                s2d = ops.s2d_pack(last, self.vit.G)
+                n_img_tok = (self.vit.G // 2) ** 2
+                mid = ops.gemm(s2d, self.bridge["w0"], bias=self.bridge["b0"], act=1)
+                image_features = ops.gemm(mid, self.bridge["w2"], bias=self.bridge["b2"], out_f32=True)
+                # splice placeholders, embed, inject (groma.py:317-369)
+                new_ids_h, mask_h = self._splice(ids_h, n_img_tok, n_reg)
+                if labels is not None:
+                    labels = self._splice_labels(ids_h, labels.cpu(), n_img_tok, n_reg)
+                L = new_ids_h.shape[1]
+                new_ids = new_ids_h.to(dev)
+                emb = self.llm.embed(new_ids)  # f32 [bs*L, T]
+                flat = new_ids_h.reshape(-1)
+                img_rows = (flat == self.img_token_id).nonzero(as_tuple=True)[0].to(I32).to(dev)
+                reg_rows = (flat == self.reg_token_id).nonzero(as_tuple=True)[0].to(I32).to(dev)
+                assert img_rows.numel() == image_features.shape[0] and reg_rows.numel() == region_features.shape[0]
+                ops.scatter_rows(image_features, img_rows, emb)
+                ops.scatter_rows(region_features, reg_rows, emb)
+                ref_rows = (flat == self.refer_feat_token_id).nonzero(as_tuple=True)[0]
+                if ref_rows.numel() > 0:
+                    offs = [0]
+                    for n in n_reg:
+                        offs.append(offs[-1] + n)
+                    gather = torch.cat([torch.as_tensor(ind, dtype=I64) + offs[i] for i, ind in enumerate(refer_box_inds)
+                                        if len(ind) > 0])
+                    ops.scatter_rows(region_features.index_select(0, gather.to(dev)).contiguous(),
+                                     ref_rows.to(I32).to(dev), emb)
+                attention_mask = mask_h.to(dev)
+                kv_len = mask_h.sum(-1).to(I32).to(dev) if not bool(mask_h.all()) else None
+                cache = self.llm.new_cache(bs, L + max(int(_reserve), 0), dev)
+                vis_outputs = {'pred_boxes': selected_boxes,
+                               'image_features': image_features.view(bs, n_img_tok, -1),
+                               'region_features': region_features}
+                self._last_aux = aux
+            else:
+                cache = past_key_values
+                bs = cache.bs
+                L = 1 if inputs_embeds is None else inputs_embeds.shape[1]
+                if inputs_embeds is None:
+                    emb = self.llm.embed(input_ids[:, -1:].to(dev))
+                else:
+                    emb = inputs_embeds.to(dev, F32).reshape(bs * L, -1).contiguous()
+                kv_len = None  # the reference rebuilds an all-ones mask over past+1 (groma.py:376-379, T6)
+                attention_mask = torch.ones((bs, cache.seq_len + L), device=dev)
+            logits, hn = self.llm.forward(emb, bs, L, cache, kv_len=kv_len, all_logits=not _last_logits_only)
+
+        loss = None
+        if labels is not None:  # groma.py:404-415 (training-side convenience; not on the inference hot path)
+            lab = labels.to(dev)
+            loss = torch.nn.functional.cross_entropy(logits[..., :-1, :].reshape(-1, self.config.vocab_size).float(),
+                                                     lab[..., 1:].reshape(-1), ignore_index=IGNORE_INDEX)
+        hidden_states = (hn.view(bs, -1, hn.shape[-1]),) if output_hidden_states else None
+        if not return_dict:
+            output = (logits, cache)
+            return (loss,) + output if loss is not None else output
+        return CausalLMOutputWithPast(loss=loss, logits=logits, past_key_values=cache,
+                                      hidden_states=(hidden_states, vis_outputs), attentions=None)
+
+    __call__ = forward
+
+    def _splice_labels(self, ids_h, labels_h, n_img_tok, n_reg):
+        new_labels = []
+        for i in range(ids_h.shape[0]):
+            ids = ids_h[i]
+            img_pos = (ids == self.img_token_id).nonzero(as_tuple=True)[0]
+            reg_pos = (ids == self.reg_token_id).nonzero(as_tuple=True)[0]
+            pad_pos = (ids == self.pad_token_id).nonzero(as_tuple=True)[0]
+            pad_pos = pad_pos[0] if len(pad_pos) > 0 else len(ids)
+            new_labels.append(torch.cat((labels_h[i][:img_pos], torch.full((n_img_tok,), IGNORE_INDEX),
+                                         labels_h[i][img_pos + 1: reg_pos], torch.full((n_reg[i] * 2,), IGNORE_INDEX),
+                                         labels_h[i][reg_pos + 1: pad_pos])))
+        return torch.nn.utils.rnn.pad_sequence(new_labels, batch_first=True, padding_value=IGNORE_INDEX)
+
+    # ------------------------------------------------------------------ generate (HF 4.32 greedy_search semantics)
+    def generate(self, input_ids, images=None, refer_boxes=None, ground_boxes=None, use_cache=True, do_sample=False,
+                 max_new_tokens=None, return_dict_in_generate=False, output_hidden_states=False, generation_config=None,
+                 **kw):
+        """Greedy decoding as HF GenerationMixin.greedy_search drives the reference model
+        (groma/eval/eval_rec.py:93-104): the next token is the arg-max of the LAST position of the right-padded
+        expanded sequence; finished rows emit pad; `sequences` = original prompt + new ids."""
+        gc = generation_config if generation_config is not None else self.generation_config
+        if do_sample or getattr(gc, "do_sample", False) and do_sample is None:
+            raise NotImplementedError("only greedy decoding (do_sample=False) is implemented on the MI355X path")
+        if kw.get("num_beams", 1) != 1:
+            raise NotImplementedError("beam search is not implemented")
+        if max_new_tokens is None:
+            max_new_tokens = getattr(gc, "max_new_tokens", 20) or 20
+        eos = getattr(gc, "eos_token_id", None)
+        pad = getattr(gc, "pad_token_id", None)
+        if eos is not None and pad is None:
+            pad = eos
+        dev = self.device
+        seqs = input_ids.to(dev).clone()
+        ids_for_model = input_ids.to(dev)
+        out = self.forward(input_ids=ids_for_model, images=images, refer_boxes=refer_boxes, ground_boxes=ground_boxes,
+                           use_cache=True, output_hidden_states=output_hidden_states, return_dict=True,
+                           _last_logits_only=True, _reserve=max_new_tokens)
+        first = out
+        cache = out.past_key_values
+        logits = out.logits
+        unfinished = torch.ones(seqs.shape[0], dtype=I64, device=dev)
+        for step in range(max_new_tokens):
+            V = logits.shape[-1]
+            last = logits[:, -1, :]
+            # view into the padded logits buffer: pass its row stride to the arg-max kernel
+            nxt = ops.argmax_rows(last if last.is_contiguous() else last.contiguous(), V)
+            if eos is not None:
+                nxt = nxt * unfinished + pad * (1 - unfinished)
+            seqs = torch.cat([seqs, nxt[:, None]], dim=-1)
+            if eos is not None:
+                unfinished = unfinished * (nxt != eos).long()
+                if int(unfinished.max()) == 0:
+                    break
+            if step == max_new_tokens - 1:
+                break
+            o = self.forward(input_ids=nxt[:, None], past_key_values=cache, use_cache=True, return_dict=True)
+            logits = o.logits
+        if not return_dict_in_generate:
+            return seqs
+        hs = (first.hidden_states,) if output_hidden_states else None
+        return GenerateOutput(sequences=seqs, hidden_states=hs, past_key_values=cache)

@@ -1,0 +1,255 @@
+"""Reference-named parameters -> MI355X device layouts.
+
+The on-disk / state-dict contract is the reference's (HF 4.32 parameter names); everything the
+kernels want (bf16 [N,K] GEMM weights, fused QKV / gate-up rows, NHWC conv taps, padded K) is derived here once,
+at load time.  torch ops in this file are load-time plumbing, never on the forward path.
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+BF16, F32 = torch.bfloat16, torch.float32
+
+
+def _ru(x, m):
+    return (x + m - 1) // m * m
+
+
+class Source:
+    """get(name) -> fp32 tensor on `device`.  Backed by a CPU state dict or by the synthetic generator."""
+
+    def __init__(self, get, device):
+        self._get, self.device = get, device
+
+    def __call__(self, name):
+        return self._get(name).to(device=self.device, dtype=F32)
+
+    @classmethod
+    def from_state_dict(cls, sd, device):
+        def get(name):
+            if name in sd:
+                return sd[name]
+            # the reference registers bbox_embed / class_embed_* twice (decoder.* aliases): accept either
+            alt = name.replace("ddetr_transformer.", "ddetr_transformer.decoder.")
+            if alt in sd:
+                return sd[alt]
+            raise KeyError(f"missing parameter {name}")
+        return cls(get, device)
+
+    @classmethod
+    def synthetic(cls, cfg, seed, device):
+        from . import synth
+        spec = {n: (s, k) for n, s, k in synth.param_spec(cfg)}
+        names = {n: i for i, n in enumerate(spec)}
+
+        def get(name):
+            shape, kind = spec[name]
+            g = torch.Generator(device=device).manual_seed(seed * 1000003 + names[name])
+            return synth.materialize(shape, kind, g, device=device)
+        return cls(get, device)
+
+
+def bf(t):
+    return t.to(BF16).contiguous()
+
+
+def pad_k(w, K):
+    out = torch.zeros((w.shape[0], K), dtype=w.dtype, device=w.device)
+    out[:, : w.shape[1]] = w
+    return out
+
+
+def vit_pos_embed_4_32(pos, grid):
+    """HF 4.32 Dinov2Embeddings.interpolate_pos_encoding (bicubic, scale_factor (grid+0.1)/sqrt(N)).
+    Input-independent, so it is evaluated once at load (fp32, CPU)."""
+    pos = pos.detach().float().cpu()
+    n_pos = pos.shape[1] - 1
+    if n_pos == grid * grid:
+        return pos[0]
+    dim = pos.shape[-1]
+    side = int(math.sqrt(n_pos))
+    patch = pos[:, 1:].reshape(1, side, side, dim).permute(0, 3, 1, 2)
+    sf = (grid + 0.1) / math.sqrt(n_pos)
+    patch = F.interpolate(patch, scale_factor=(sf, sf), mode="bicubic", align_corners=False)
+    if patch.shape[-1] != grid or patch.shape[-2] != grid:
+        raise ValueError("position-embedding interpolation produced an unexpected grid")
+    patch = patch.permute(0, 2, 3, 1).reshape(-1, dim)
+    return torch.cat((pos[0, :1], patch), dim=0)
+
+
+def pack_vit(W, cfg):
+    vc = cfg.perceiver_cfg.vis_encoder_cfg
+    D, P = vc.hidden_size, vc.patch_size
+    grid = cfg.image_size // P
+    v = "perceiver.vis_encoder."
+    dev = W.device
+    Kp = _ru(3 * P * P, 64)
+    pw = W(v + "embeddings.patch_embeddings.projection.weight").reshape(D, -1)
+    pos = vit_pos_embed_4_32(W(v + "embeddings.position_embeddings"), grid).to(dev)
+    cls = W(v + "embeddings.cls_token").reshape(D)
+    out = dict(grid=grid, Kpad=Kp, patch_w=bf(pad_k(pw, Kp)), patch_b=W(v + "embeddings.patch_embeddings.projection.bias"),
+               cls_pos0=(cls + pos[0]).contiguous(), pos_patch=pos[1:].contiguous(), layers=[])
+    for i in range(vc.num_hidden_layers):
+        p = f"{v}encoder.layer.{i}."
+        a = p + "attention.attention."
+        out["layers"].append(dict(
+            ln1_g=W(p + "norm1.weight"), ln1_b=W(p + "norm1.bias"),
+            wqkv=bf(torch.cat([W(a + "query.weight"), W(a + "key.weight"), W(a + "value.weight")], 0)),
+            bqkv=torch.cat([W(a + "query.bias"), W(a + "key.bias"), W(a + "value.bias")], 0).contiguous(),
+            wo=bf(W(p + "attention.output.dense.weight")), bo=W(p + "attention.output.dense.bias"),
+            ls1=W(p + "layer_scale1.lambda1"),
+            ln2_g=W(p + "norm2.weight"), ln2_b=W(p + "norm2.bias"),
+            w1=bf(W(p + "mlp.fc1.weight")), b1=W(p + "mlp.fc1.bias"),
+            w2=bf(W(p + "mlp.fc2.weight")), b2=W(p + "mlp.fc2.bias"),
+            ls2=W(p + "layer_scale2.lambda1")))
+    return out
+
+
+def _sine_pos(h, w, d):
+    """DeformableDetrSinePositionEmbedding(normalize=True) on an all-valid mask: input independent."""
+    npf, eps, scale = d // 2, 1e-6, 2 * math.pi
+    ones = torch.ones((1, h, w), dtype=F32)
+    y, x = ones.cumsum(1), ones.cumsum(2)
+    y = (y - 0.5) / (y[:, -1:, :] + eps) * scale
+    x = (x - 0.5) / (x[:, :, -1:] + eps) * scale
+    dim_t = torch.arange(npf, dtype=F32)
+    dim_t = 10000 ** (2 * torch.div(dim_t, 2, rounding_mode="floor") / npf)
+    px, py = x[:, :, :, None] / dim_t, y[:, :, :, None] / dim_t
+    px = torch.stack((px[..., 0::2].sin(), px[..., 1::2].cos()), dim=4).flatten(3)
+    py = torch.stack((py[..., 0::2].sin(), py[..., 1::2].cos()), dim=4).flatten(3)
+    return torch.cat((py, px), dim=3).reshape(h * w, d)
+
+
+def pack_ddetr(W, cfg):
+    dc = cfg.perceiver_cfg.ddetr_cfg
+    D = cfg.perceiver_cfg.vis_encoder_cfg.hidden_size
+    d = dc.d_model
+    g = cfg.image_size // cfg.perceiver_cfg.vis_encoder_cfg.patch_size
+    dev = W.device
+    t = "perceiver.ddetr_transformer."
+    if dc.num_feature_levels != 1 or not dc.two_stage or not dc.with_box_refine:
+        raise NotImplementedError("only the reference's single-level two-stage box-refine DDETR is built")
+
+    def lin(name):
+        return W(name + ".weight").contiguous(), W(name + ".bias").contiguous()
+
+    def msda(p):
+        ow, ob = lin(p + "sampling_offsets")
+        aw, ab = lin(p + "attention_weights")
+        vw, vb = lin(p + "value_proj")
+        uw, ub = lin(p + "output_proj")
+        return dict(offw_w=torch.cat([ow, aw], 0).contiguous(), offw_b=torch.cat([ob, ab], 0).contiguous(), v_w=vw, v_b=vb,
+                    o_w=uw, o_b=ub)
+
+    def ln(name):
+        return W(name + ".weight"), W(name + ".bias")
+
+    def mlp3(p):
+        return [lin(f"{p}.layers.{k}") for k in range(3)]
+
+    out = dict(g=g, d=d)
+    out["proj_w"] = W("perceiver.input_proj.0.0.weight").reshape(d, D).contiguous()
+    out["proj_b"] = W("perceiver.input_proj.0.0.bias")
+    out["proj_ln"] = ln("perceiver.input_proj.0.1")
+    out["pos"] = (_sine_pos(g, g, d).to(dev) + W(t + "level_embed")[0].view(1, -1)).contiguous()
+    ry, rx = torch.meshgrid(torch.linspace(0.5, g - 0.5, g, dtype=F32), torch.linspace(0.5, g - 0.5, g, dtype=F32),
+                            indexing="ij")
+    out["enc_ref"] = torch.stack((rx.reshape(-1) / g, ry.reshape(-1) / g), -1).contiguous().to(dev)
+    # two-stage proposals (ddetr_transformer.py:383-423): input independent
+    gy, gx = torch.meshgrid(torch.linspace(0, g - 1, g, dtype=F32), torch.linspace(0, g - 1, g, dtype=F32), indexing="ij")
+    grid = (torch.stack([gx, gy], -1) + 0.5) / torch.tensor([g, g], dtype=F32)
+    prop = torch.cat((grid, torch.ones_like(grid) * 0.05), -1).view(-1, 4)
+    if not ((prop > 0.01) & (prop < 0.99)).all():
+        raise NotImplementedError("proposal validity mask is not all-true for this grid")
+    out["proposals"] = torch.log(prop / (1 - prop)).contiguous().to(dev)
+    out["enc"] = []
+    for i in range(dc.encoder_layers):
+        p = f"{t}encoder.layers.{i}."
+        out["enc"].append(dict(att=msda(p + "self_attn."), ln1=ln(p + "self_attn_layer_norm"), fc1=lin(p + "fc1"),
+                               fc2=lin(p + "fc2"), ln2=ln(p + "final_layer_norm")))
+    out["dec"] = []
+    for i in range(dc.decoder_layers):
+        p = f"{t}decoder.layers.{i}."
+        qw, qb = lin(p + "self_attn.q_proj")
+        kw, kb = lin(p + "self_attn.k_proj")
+        out["dec"].append(dict(qk_w=torch.cat([qw, kw], 0).contiguous(), qk_b=torch.cat([qb, kb], 0).contiguous(),
+                               v=lin(p + "self_attn.v_proj"), o=lin(p + "self_attn.out_proj"),
+                               ln1=ln(p + "self_attn_layer_norm"), att=msda(p + "encoder_attn."),
+                               ln2=ln(p + "encoder_attn_layer_norm"), fc1=lin(p + "fc1"), fc2=lin(p + "fc2"),
+                               ln3=ln(p + "final_layer_norm")))
+    n = dc.decoder_layers
+    out["enc_output"], out["enc_output_norm"] = lin(t + "enc_output"), ln(t + "enc_output_norm")
+    out["pos_trans"], out["pos_trans_norm"] = lin(t + "pos_trans"), ln(t + "pos_trans_norm")
+    out["class_enc"] = lin(t + "class_embed_enc")
+    out["bbox_enc"] = mlp3(f"{t}bbox_embed.{n}")
+    out["bbox_prev"] = mlp3(f"{t}bbox_embed.{n - 2}") if n > 1 else None
+    out["bbox_last"] = mlp3(f"{t}bbox_embed.{n - 1}")
+    out["class_coco"], out["class_sa1b"] = lin(f"{t}class_embed_coco.{n - 1}"), lin(f"{t}class_embed_sa1b.{n - 1}")
+    out["target"] = W(t + "query_position_embeddings.weight").contiguous()
+    return out
+
+
+def pack_region(W, cfg):
+    rc = cfg.region_cfg
+    D = cfg.perceiver_cfg.vis_encoder_cfg.hidden_size
+    m, ra = "region_encoder.mlvl_fuse.", "region_encoder.roi_align."
+    Cp = _ru(D + 2, 64)
+    out = dict(Cpad=Cp, in_w=[], in_b=[], fuse=[])
+    for l in range(rc.num_levels):
+        out["in_w"].append(bf(pad_k(W(f"{m}input_conv.{l}.weight").reshape(D, D + 2), Cp)))
+        out["in_b"].append(W(f"{m}input_conv.{l}.bias"))
+    for r in range(rc.num_fuse):
+        w = W(f"{m}fuse_convs.{r}.conv.weight")  # [D, D, 3, 3] -> [D, (ky,kx,c)]
+        out["fuse"].append(dict(w=bf(w.permute(0, 2, 3, 1).reshape(D, 9 * D)), g=W(f"{m}fuse_convs.{r}.gn.weight"),
+                                b=W(f"{m}fuse_convs.{r}.gn.bias")))
+    pw = [W(f"{ra}pconvs.{l}.weight").permute(0, 2, 3, 1).reshape(D, 9 * D) for l in range(rc.num_levels)]
+    out["pconv_w"] = bf(torch.cat(pw, 1))
+    out["pconv_b"] = sum(W(f"{ra}pconvs.{l}.bias") for l in range(rc.num_levels)).contiguous()
+    P2 = rc.roi_size ** 2
+    fw = W(ra + "flatten_linear.weight")  # [mid, D*P2] with k = c*P2 + hw  ->  k' = hw*D + c
+    out["flat_w"] = bf(fw.view(-1, D, P2).permute(0, 2, 1).reshape(-1, P2 * D))
+    out["flat_b"] = W(ra + "flatten_linear.bias")
+    out["pe0_w"] = pad_k(W(ra + "pos_embedd.0.weight"), 16).contiguous()
+    out["pe0_b"] = W(ra + "pos_embedd.0.bias")
+    out["pe_ln1"] = (W(ra + "pos_embedd.2.weight"), W(ra + "pos_embedd.2.bias"))
+    out["pe3_w"], out["pe3_b"] = W(ra + "pos_embedd.3.weight").contiguous(), W(ra + "pos_embedd.3.bias")
+    out["pe_ln2"] = (W(ra + "pos_embedd.5.weight"), W(ra + "pos_embedd.5.bias"))
+    out["up_w"], out["up_b"] = bf(W(ra + "updims.weight")), W(ra + "updims.bias")
+    return out
+
+
+def pack_llm(W, cfg):
+    lc = cfg.llm_cfg
+    T, I = lc.hidden_size, lc.intermediate_size
+    out = dict(layers=[])
+    out["embed"] = bf(W("llm.model.embed_tokens.weight"))
+    out["new_embed"] = bf(W("new_input_embs.weight"))
+    for i in range(lc.num_hidden_layers):
+        p = f"llm.model.layers.{i}."
+        gate, up = W(p + "mlp.gate_proj.weight"), W(p + "mlp.up_proj.weight")
+        out["layers"].append(dict(
+            n1=W(p + "input_layernorm.weight"),
+            wqkv=bf(torch.cat([W(p + "self_attn.q_proj.weight"), W(p + "self_attn.k_proj.weight"),
+                               W(p + "self_attn.v_proj.weight")], 0)),
+            wo=bf(W(p + "self_attn.o_proj.weight")),
+            n2=W(p + "post_attention_layernorm.weight"),
+            wgu=bf(torch.stack([gate, up], 1).reshape(2 * I, T)),  # interleaved rows: gate_0, up_0, gate_1, ...
+            wd=bf(W(p + "mlp.down_proj.weight"))))
+    out["norm"] = W("llm.model.norm.weight")
+    V = lc.vocab_size + cfg.num_new_token
+    Vp = _ru(V, 128)
+    head = torch.zeros((Vp, T), dtype=BF16, device=W.device)
+    head[: lc.vocab_size] = W("llm.lm_head.weight").to(BF16)
+    head[lc.vocab_size: V] = W("extra_lm_head.weight").to(BF16)
+    out["head"], out["V"], out["Vpad"] = head, V, Vp
+    hd = T // lc.num_attention_heads
+    inv = 1.0 / (lc.rope_theta ** (torch.arange(0, hd, 2, dtype=F32) / hd))
+    fr = torch.outer(torch.arange(lc.max_position_embeddings, dtype=F32), inv)
+    out["cos"], out["sin"] = fr.cos().contiguous().to(W.device), fr.sin().contiguous().to(W.device)
+    return out
+
+
+def pack_bridge(W, cfg):
+    return dict(w0=bf(W("img_txt_bridge.0.weight")), b0=W("img_txt_bridge.0.bias"), w2=bf(W("img_txt_bridge.2.weight")),
+                b2=W("img_txt_bridge.2.bias"))
