@@ -110,6 +110,7 @@ def main():
     ap.add_argument("--batch", type=int, default=4, help="images per GPU per step")
     ap.add_argument("--config", default="7b", choices=["7b", "tiny"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--gemm-breakdown", default=None, help="write a per-shape GEMM table (from the HIP-event hook) here")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -172,7 +173,24 @@ def main():
         step(args.warmup + i)
     torch.cuda.synchronize()
     ops.prof_enable(False)
-    gemm_ms, gemm_launches, gemm_flops = ops.prof_read()
+    if args.gemm_breakdown and rank == 0:
+        recs = ops.prof_read_launches()
+        agg = {}
+        for M_, N_, K_, tag, ms in recs:
+            a = agg.setdefault((M_, N_, K_, tag), [0, 0.0])
+            a[0] += 1
+            a[1] += ms
+        with open(args.gemm_breakdown, "w") as f:
+            f.write("M N K tag(1=conv,2=splitK) calls_per_step avg_us TFLOPs share_of_gemm_time\n")
+            tot = sum(v[1] for v in agg.values())
+            for (M_, N_, K_, tag), (c, ms) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+                f.write(f"{M_} {N_} {K_} {tag} {c / args.steps:.1f} {ms / c * 1e3:.1f} "
+                        f"{2.0 * M_ * N_ * K_ * c / (ms * 1e-3) / 1e12:.0f} {ms / tot:.3f}\n")
+        gemm_ms = sum(r[4] for r in recs)
+        gemm_launches = len(recs)
+        gemm_flops = sum(2.0 * r[0] * r[1] * r[2] for r in recs)
+    else:
+        gemm_ms, gemm_launches, gemm_flops = ops.prof_read()
     ips = world * args.batch * args.steps / elapsed
     peak = 2500.0
     achieved = gemm_flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0

@@ -27,6 +27,7 @@ class GemmDesc(ctypes.Structure):
         ("conv_seg_stride", c_long),
         ("resid_mod", c_int),
         ("c_group", c_int), ("c_group_stride", c_int), ("c_row_off", c_int),
+        ("tile", c_int),
     ]
 
 
@@ -36,6 +37,7 @@ SIGNATURES = {
     "gr_abi_version": [],
     "gr_prof_enable": [_I],
     "gr_prof_read": [_P, _P, _P],
+    "gr_prof_read_launches": [_L, _P, _P, _P],
     "gr_gemm_bf16": [ctypes.POINTER(GemmDesc), _P],
     "gr_gemm_f32": [_P, _P, _P, _P, _P, _I, _I, _I, _L, _L, _L, _I, _P],
     "gr_layernorm": [_P, _P, _P, _P, _P, _I, _I, _L, _L, _F, _I, _I, _P],
@@ -48,7 +50,8 @@ SIGNATURES = {
     "gr_s2d_pack": [_P, _P, _I, _I, _I, _P],
     "gr_upsample_coord_pack": [_P, _P, _I, _I, _I, _I, _I, _P],
     "gr_gn_stats": [_P, _P, _I, _I, _I, _P],
-    "gr_fuse_shuffle": [_P, _P, _I, _P, _P, _I, _P, _P, _I, _P, _P, _P, _I, _I, _I, _F, _I, _I, _P],
+    "gr_gn_finalize": [_P, _P, _P, _P, _I, _I, _I, _I, _F, _P],
+    "gr_fuse_shuffle": [_P, _P, _I, _P, _P, _I, _P, _P, _I, _P, _I, _I, _I, _I, _P],
     "gr_cast_f32_bf16": [_P, _P, _P, _L, _P],
     "gr_add_rows_f32": [_P, _P, _P, _L, _I, _I, _P],
     "gr_embed_gather": [_P, _P, _P, _P, _L, _I, _I, _I, _P],

@@ -9,7 +9,8 @@
 // kept TRANSPOSED so both MFMA operands of P.V read 16-B contiguous LDS chunks),
 // Out [B*Lq, H*hd] token-major.
 //
-// Block = 4 waves, 64 query rows (16 per wave), KV tile 64.  Scores are computed
+// Block = 4 waves, 128 query rows (2 tiles of 16 per wave, sharing every K / Vt fragment read), KV tile 64,
+// K/Vt tiles double-buffered in LDS (DMA of tile t+1 overlaps the MFMAs of tile t).  Scores are computed
 // transposed, S^T = K.Q^T (v_mfma_f32_16x16x32_bf16, K rows as the A operand) so that
 // a lane owns ONE query column: the row max/sum are in-lane + 2 shuffles, and P^T feeds
 // the second MFMA (O^T = Vt.P^T) straight from registers -- no LDS round trip for P.
@@ -32,163 +33,188 @@ struct AttnArgs {
 };
 
 template <int HD>
-__global__ __launch_bounds__(256) void attention_kernel(AttnArgs p) {
+__global__ __launch_bounds__(256, 2) void attention_kernel(AttnArgs p) {
   constexpr int KV = 64;
+  constexpr int QT = 2;               // 16-row query tiles per wave -> 32 query rows / wave, 128 / block
   constexpr int KROW = HD * 2;        // bytes per K row
   constexpr int KCH = KROW / 16;      // 16-B chunks per K row (8 or 16)
   constexpr int KTILE = KV * KROW;    // bytes
   constexpr int VTILE = HD * KV * 2;  // Vt tile [HD][64] bf16, 128-B rows
-  __shared__ __attribute__((aligned(16))) char smem[KTILE + VTILE];
-  char* ksm = smem;
-  char* vsm = smem + KTILE;
+  constexpr int STAGE = KTILE + VTILE;
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // 2 stages (double buffer)
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int fr = lane & 15, fg = lane >> 4;
   const int bh = blockIdx.y;
   const int b = bh / p.H, h = bh - b * p.H;
-  const int q0 = blockIdx.x * 64;
+  const int q0 = blockIdx.x * (64 * QT);
 
   const bf16_t* Qp = p.q + (long)bh * p.Lq * HD;
   const bf16_t* Kp = p.k + (long)bh * p.kv_stride * HD;
   const bf16_t* Vp = p.vt + (long)bh * HD * p.kv_stride;
 
-  // this lane's query row (B operand column) -- clamp the tail
-  int qi = q0 + wave * 16 + fr;
-  const bool q_valid = qi < p.Lq;
-  if (!q_valid) qi = p.Lq - 1;
-  bf16x8 qf[HD / 32];
-#pragma unroll
-  for (int kk = 0; kk < HD / 32; ++kk) qf[kk] = *(const bf16x8*)(Qp + (long)qi * HD + kk * 32 + fg * 8);
+  int kvmax = p.Skv;
+  if (p.kv_len) kvmax = min(kvmax, p.kv_len[b]);
 
-  int limit = p.Skv;  // keys [0, limit) visible to this lane's query
-  if (p.kv_len) limit = min(limit, p.kv_len[b]);
-  if (p.causal) limit = min(limit, p.q_pos0 + qi + 1);
-  // block-level loop bound: max over the block's queries
-  int blk_limit = p.Skv;
-  if (p.kv_len) blk_limit = min(blk_limit, p.kv_len[b]);
-  if (p.causal) blk_limit = min(blk_limit, p.q_pos0 + min(q0 + 63, p.Lq - 1) + 1);
+  // this lane's query rows (B-operand columns), one per q-tile -- clamp the tail
+  int qi[QT], limit[QT];
+  bool q_valid[QT];
+  bf16x8 qf[QT][HD / 32];
+#pragma unroll
+  for (int u = 0; u < QT; ++u) {
+    qi[u] = q0 + wave * (16 * QT) + u * 16 + fr;
+    q_valid[u] = qi[u] < p.Lq;
+    if (!q_valid[u]) qi[u] = p.Lq - 1;
+#pragma unroll
+    for (int kk = 0; kk < HD / 32; ++kk) qf[u][kk] = *(const bf16x8*)(Qp + (long)qi[u] * HD + kk * 32 + fg * 8);
+    limit[u] = p.causal ? min(kvmax, p.q_pos0 + qi[u] + 1) : kvmax;  // keys [0, limit) visible
+  }
+  // loop bounds: block-level (staging + barriers) and wave-level (compute)
+  const int blk_last = min(q0 + 64 * QT - 1, p.Lq - 1);
+  const int wav_last = min(q0 + wave * (16 * QT) + 16 * QT - 1, p.Lq - 1);
+  const int blk_limit = p.causal ? min(kvmax, p.q_pos0 + blk_last + 1) : kvmax;
+  const int wav_limit = p.causal ? min(kvmax, p.q_pos0 + wav_last + 1) : kvmax;
   const int ntiles = (blk_limit + KV - 1) / KV;
 
-  f32x4 o[HD / 16];
+  f32x4 o[QT][HD / 16];
+  float m_run[QT], l_run[QT];
 #pragma unroll
-  for (int n = 0; n < HD / 16; ++n) o[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  float m_run = -1e30f, l_run = 0.f;
+  for (int u = 0; u < QT; ++u) {
+    m_run[u] = -1e30f;
+    l_run[u] = 0.f;
+#pragma unroll
+    for (int n = 0; n < HD / 16; ++n) o[u][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
 
+  // stage K tile (lds chunk position pos holds logical chunk pos ^ (row&7)) and Vt tile of kv tile t into buffer t&1
+  auto stage = [&](int t) {
+    const int kv0 = t * KV;
+    char* ksm = smem + (t & 1) * STAGE;
+    char* vsm = ksm + KTILE;
+    constexpr int NCH = KV * KCH;
+#pragma unroll
+    for (int i = 0; i < NCH / 256; ++i) {
+      const int q = i * 256 + tid;
+      const int row = q / KCH, pos = q % KCH;
+      const int c = pos ^ (row & 7);
+      int kr = kv0 + row;
+      if (kr > p.Skv - 1) kr = p.Skv - 1;
+      __builtin_amdgcn_global_load_lds((gptr_t)(Kp + (long)kr * HD + c * 8), (lptr_t)(ksm + i * 4096 + wave * 1024), 16, 0, 0);
+    }
+    constexpr int NVC = HD * 8;
+#pragma unroll
+    for (int i = 0; i < NVC / 256; ++i) {
+      const int q = i * 256 + tid;
+      const int row = q >> 3, pos = q & 7;
+      const int c = pos ^ (row & 7);
+      __builtin_amdgcn_global_load_lds((gptr_t)(Vp + (long)row * p.kv_stride + kv0 + c * 8),
+                                       (lptr_t)(vsm + i * 4096 + wave * 1024), 16, 0, 0);
+    }
+  };
+
+  if (ntiles > 0) stage(0);
   for (int t = 0; t < ntiles; ++t) {
     const int kv0 = t * KV;
-    __syncthreads();  // previous tile fully consumed
-    // ---- stage K tile: KV rows x KCH chunks; lds chunk position p holds logical chunk p ^ (row&7)
-    {
-      constexpr int NCH = KV * KCH;  // 512 or 1024 chunks
-#pragma unroll
-      for (int i = 0; i < NCH / 256; ++i) {
-        const int q = i * 256 + tid;
-        const int row = q / KCH, pos = q % KCH;
-        const int c = pos ^ (row & 7);
-        int kr = kv0 + row;
-        if (kr > p.Skv - 1) kr = p.Skv - 1;
-        __builtin_amdgcn_global_load_lds((gptr_t)(Kp + (long)kr * HD + c * 8), (lptr_t)(ksm + i * 4096 + wave * 1024), 16,
-                                         0, 0);
-      }
-      // ---- stage Vt tile: HD rows x 8 chunks (64 keys)
-      constexpr int NVC = HD * 8;
-#pragma unroll
-      for (int i = 0; i < NVC / 256; ++i) {
-        const int q = i * 256 + tid;
-        const int row = q >> 3, pos = q & 7;
-        const int c = pos ^ (row & 7);
-        __builtin_amdgcn_global_load_lds((gptr_t)(Vp + (long)row * p.kv_stride + kv0 + c * 8),
-                                         (lptr_t)(vsm + i * 4096 + wave * 1024), 16, 0, 0);
-      }
-    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    __syncthreads();  // tile t landed for every wave; everyone finished reading the other buffer
+    if (t + 1 < ntiles) stage(t + 1);
+    if (kv0 >= wav_limit) continue;  // wave-uniform: every key of this tile is masked for all of this wave's rows
+    const char* ksm = smem + (t & 1) * STAGE;
+    const char* vsm = ksm + KTILE;
 
-    // ---- S^T tile: rows = keys (4 tiles of 16), col = this lane's query
-    f32x4 s[4];
+    // ---- S^T tiles: rows = keys (4 sub-tiles of 16), col = this lane's query (per q-tile); K fragments shared
+    f32x4 s[QT][4];
+#pragma unroll
+    for (int u = 0; u < QT; ++u)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) s[u][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      s[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
       const int row = j * 16 + fr;
 #pragma unroll
       for (int kk = 0; kk < HD / 32; ++kk) {
         const int c = kk * 4 + fg;
         const bf16x8 kf = *(const bf16x8*)(ksm + row * KROW + ((c ^ (row & 7)) << 4));
-        s[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[kk], s[j], 0, 0, 0);
+#pragma unroll
+        for (int u = 0; u < QT; ++u) s[u][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[u][kk], s[u][j], 0, 0, 0);
       }
     }
-    // lane holds keys kv0 + j*16 + fg*4 + r for query fr
-    float mx = -1e30f;
+    // ---- online softmax; lane holds keys kv0 + j*16 + fg*4 + r of query fr (per q-tile)
+    union PB { bf16x8 v; uint32_t w[4]; };
+    PB pb[QT][2];
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int u = 0; u < QT; ++u) {
+      float mx = -1e30f;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int key = kv0 + j * 16 + fg * 4 + r;
-        float v = s[j][r] * p.scale_log2;
-        v = key < limit ? v : -1e30f;
-        s[j][r] = v;
-        mx = fmaxf(mx, v);
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int key = kv0 + j * 16 + fg * 4 + r;
+          float v = s[u][j][r] * p.scale_log2;
+          v = key < limit[u] ? v : -1e30f;
+          s[u][j][r] = v;
+          mx = fmaxf(mx, v);
+        }
+      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float m_new = fmaxf(m_run[u], mx);
+      const float alpha = exp2f(m_run[u] - m_new);
+      float rs = 0.f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int key = kv0 + j * 16 + fg * 4 + r;
+          const float e = key < limit[u] ? exp2f(s[u][j][r] - m_new) : 0.f;
+          s[u][j][r] = e;
+          rs += e;
+        }
+      rs += __shfl_xor(rs, 16, 64);
+      rs += __shfl_xor(rs, 32, 64);
+      l_run[u] = l_run[u] * alpha + rs;
+      m_run[u] = m_new;
+#pragma unroll
+      for (int n = 0; n < HD / 16; ++n) o[u][n] *= alpha;
+      // P^T as the B operand; k-slot (fg,e): e<4 -> key 32*tt + fg*4 + e ; e>=4 -> key 32*tt + 16 + fg*4 + (e-4)
+#pragma unroll
+      for (int tt = 0; tt < 2; ++tt) {
+        pb[u][tt].w[0] = pack2bf(s[u][2 * tt][0], s[u][2 * tt][1]);
+        pb[u][tt].w[1] = pack2bf(s[u][2 * tt][2], s[u][2 * tt][3]);
+        pb[u][tt].w[2] = pack2bf(s[u][2 * tt + 1][0], s[u][2 * tt + 1][1]);
+        pb[u][tt].w[3] = pack2bf(s[u][2 * tt + 1][2], s[u][2 * tt + 1][3]);
       }
-    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    const float m_new = fmaxf(m_run, mx);
-    const float alpha = exp2f(m_run - m_new);
-    float rs = 0.f;
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int key = kv0 + j * 16 + fg * 4 + r;
-        const float e = key < limit ? exp2f(s[j][r] - m_new) : 0.f;
-        s[j][r] = e;
-        rs += e;
-      }
-    rs += __shfl_xor(rs, 16, 64);
-    rs += __shfl_xor(rs, 32, 64);
-    l_run = l_run * alpha + rs;
-    m_run = m_new;
-#pragma unroll
-    for (int n = 0; n < HD / 16; ++n) o[n] *= alpha;
-
-    // ---- O^T += Vt . P^T ; k-slot (fg,e): e<4 -> key 32*tt + fg*4 + e ; e>=4 -> key 32*tt + 16 + fg*4 + (e-4)
+    }
+    // ---- O^T += Vt . P^T ; Vt fragments shared by the q-tiles
 #pragma unroll
     for (int tt = 0; tt < 2; ++tt) {
-      union {
-        bf16x8 v;
-        uint32_t u[4];
-      } pb;
-      pb.u[0] = pack2bf(s[2 * tt][0], s[2 * tt][1]);
-      pb.u[1] = pack2bf(s[2 * tt][2], s[2 * tt][3]);
-      pb.u[2] = pack2bf(s[2 * tt + 1][0], s[2 * tt + 1][1]);
-      pb.u[3] = pack2bf(s[2 * tt + 1][2], s[2 * tt + 1][3]);
 #pragma unroll
       for (int n = 0; n < HD / 16; ++n) {
         const int row = n * 16 + fr;  // d index
-        // keys 32*tt + fg*4 .. +3  -> byte offset within the 128-B row
         const int off0 = (tt * 32 + fg * 4) * 2;
         const int off1 = (tt * 32 + 16 + fg * 4) * 2;
         const int sw = (row & 7) << 4;
         const char* base = vsm + row * 128;
-        union {
-          bf16x8 v;
-          uint2 h[2];
-        } vf;
-        vf.h[0] = *(const uint2*)(base + (((off0 & ~15) ^ sw) | (off0 & 15)));
-        vf.h[1] = *(const uint2*)(base + (((off1 & ~15) ^ sw) | (off1 & 15)));
-        o[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf.v, pb.v, o[n], 0, 0, 0);
+        union { bf16x8 v; uint2 hh[2]; } vf;
+        vf.hh[0] = *(const uint2*)(base + (((off0 & ~15) ^ sw) | (off0 & 15)));
+        vf.hh[1] = *(const uint2*)(base + (((off1 & ~15) ^ sw) | (off1 & 15)));
+#pragma unroll
+        for (int u = 0; u < QT; ++u) o[u][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf.v, pb[u][tt].v, o[u][n], 0, 0, 0);
       }
     }
   }
 
   // ---- epilogue: lane holds d = n*16 + fg*4 + r for query fr
-  if (q_valid) {
-    const float inv = 1.0f / l_run;
-    bf16_t* orow = p.out + ((long)b * p.Lq + qi) * (p.H * HD) + h * HD;
+#pragma unroll
+  for (int u = 0; u < QT; ++u) {
+    if (!q_valid[u]) continue;
+    const float inv = l_run[u] > 0.f ? 1.0f / l_run[u] : 0.f;
+    bf16_t* orow = p.out + ((long)b * p.Lq + qi[u]) * (p.H * HD) + h * HD;
 #pragma unroll
     for (int n = 0; n < HD / 16; ++n) {
       uint2 pk;
-      pk.x = pack2bf(o[n][0] * inv, o[n][1] * inv);
-      pk.y = pack2bf(o[n][2] * inv, o[n][3] * inv);
+      pk.x = pack2bf(o[u][n][0] * inv, o[u][n][1] * inv);
+      pk.y = pack2bf(o[u][n][2] * inv, o[u][n][3] * inv);
       *(uint2*)(orow + n * 16 + fg * 4) = pk;
     }
   }
@@ -205,9 +231,16 @@ extern "C" int gr_attention_bf16(const void* q, const void* k, const void* vt, v
   p.B = B; p.H = H; p.Lq = Lq; p.Skv = Skv; p.kv_stride = kv_stride;
   p.causal = causal; p.q_pos0 = q_pos0;
   p.scale_log2 = scale * 1.44269504088896340736f;
-  dim3 grid(gr_cdiv(Lq, 64), B * H);
-  if (head_dim == 128) hipLaunchKernelGGL(attention_kernel<128>, grid, dim3(256), 0, stream, p);
-  else if (head_dim == 64) hipLaunchKernelGGL(attention_kernel<64>, grid, dim3(256), 0, stream, p);
+  dim3 grid(gr_cdiv(Lq, 128), B * H);
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)attention_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536) != hipSuccess ||
+        hipFuncSetAttribute((const void*)attention_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 32768) != hipSuccess)
+      return GR_EINVAL;
+    attr_set = true;
+  }
+  if (head_dim == 128) hipLaunchKernelGGL(attention_kernel<128>, grid, dim3(256), 65536, stream, p);
+  else if (head_dim == 64) hipLaunchKernelGGL(attention_kernel<64>, grid, dim3(256), 32768, stream, p);
   else return GR_EINVAL;
   GR_CHECK_LAUNCH();
   return GR_OK;

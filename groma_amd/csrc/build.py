@@ -8,6 +8,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 SOURCES = {
     "gemm_bf16.hip": [],
+    "gemm_bf16_256.hip": [],
     "gemm_f32.hip": [],
     "attention.hip": [],
     "norm.hip": [],
@@ -29,7 +30,7 @@ def _stale(target, deps):
 
 
 def build(force=False, verbose=True):
-    hdrs = [os.path.join(HERE, "gr_common.h"), os.path.join(HERE, "..", "..", "include", "groma_hip.h"),
+    hdrs = [os.path.join(HERE, "gr_common.h"), os.path.join(HERE, "gemm_common.h"), os.path.join(HERE, "..", "..", "include", "groma_hip.h"),
             os.path.abspath(__file__)]
     objs, jobs = [], []
     for src, extra in SOURCES.items():

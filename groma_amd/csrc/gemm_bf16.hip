@@ -13,60 +13,15 @@
 // source-side XOR swizzle (chunk ^= row&7) mirrored on the ds_read_b128 side.
 // The MFMA is issued "swapped" (W as the A operand) so each lane ends up with 4
 // consecutive output columns of one row -> vector epilogue loads/stores.
-#include "gr_common.h"
-#include "../../include/groma_hip.h"
+#include "gemm_common.h"
 
 #define BM 128
 #define BN 128
 #define BK 64
 #define NTHREADS 256
-
-typedef const __attribute__((address_space(1))) void* gptr_t;
-typedef __attribute__((address_space(3))) void* lptr_t;
-
-__device__ __forceinline__ void glds16(const void* g, void* l) {
-  __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)l, 16, 0, 0);
-}
-
-struct GemmArgs {
-  const bf16_t* A;
-  const bf16_t* W;
-  void* C;
-  const float* bias;
-  const float* scale;
-  const float* resid;
-  float* ws;
-  int M, N, K;
-  long lda, ldw, ldc, ldr;
-  int act, out_f32, splits;
-  int conv_H, conv_W, conv_C;
-  long conv_seg_stride;
-  int resid_mod;
-  int c_group, c_group_stride, c_row_off;
-  int tiles_m, tiles_n;
-};
-
-// XCD-aware, L2-friendly tile order: consecutive ids on one XCD (block b runs on XCD b%8),
-// grouped so 8 row-tiles share each W panel.
-__device__ __forceinline__ void tile_of_block(int bid, int nwg, int tiles_m, int tiles_n, int& tm, int& tn) {
-  const int q = nwg >> 3, r = nwg & 7;
-  const int xcd = bid & 7, idx = bid >> 3;
-  int pid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-  const int GROUP = 8;
-  const int per_group = GROUP * tiles_n;
-  const int g = pid / per_group;
-  const int first_m = g * GROUP;
-  const int gsize = min(tiles_m - first_m, GROUP);
-  const int in_g = pid - g * per_group;
-  tm = first_m + in_g % gsize;
-  tn = in_g / gsize;
-}
-
-__device__ __forceinline__ float act_apply(float v, int act) {
-  if (act == 1) return gelu_erf(v);
-  if (act == 2) return fmaxf(v, 0.f);
-  return v;
-}
+// time of one 256^2 K-step on a CU relative to one 128^2 K-step of two co-resident blocks (4x the MACs of one
+// block = 2x the work per CU-interval, executed ~1.45x faster per flop)
+#define G256_COST 1.65
 
 __global__ __launch_bounds__(NTHREADS) void gemm_bf16_kernel(GemmArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -99,18 +54,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16_kernel(GemmArgs p) {
     const int kc = (q & 7) ^ (row & 7);
     int m = m0 + row;
     if (m > p.M - 1) m = p.M - 1;
-    long abase;
-    if (p.conv_C > 0) {
-      const int hw = p.conv_H * p.conv_W;
-      const int img = m / hw;
-      const int rem = m - img * hw;
-      const int y = rem / p.conv_W;
-      const int x = rem - y * p.conv_W;
-      abase = ((long)(img * (p.conv_H + 2) + y) * (p.conv_W + 2) + x) * p.conv_C;
-    } else {
-      abase = (long)m * p.lda;
-    }
-    a_src[i] = p.A + abase + kc * 8;
+    a_src[i] = p.A + a_row_base(p, m) + kc * 8;
     int n = n0 + row;
     if (n > p.N - 1) n = p.N - 1;
     w_src[i] = p.W + (long)n * p.ldw + kc * 8;
@@ -119,17 +63,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16_kernel(GemmArgs p) {
 
   auto stage = [&](int ks, int buf) {
     const long k0 = (long)ks * BK;
-    long aoff;
-    if (p.conv_C > 0) {
-      const int tapc = (int)(k0 / p.conv_C);  // segment*9 + tap
-      const int c0 = (int)(k0 - (long)tapc * p.conv_C);
-      const int seg = tapc / 9;
-      const int tap = tapc - seg * 9;
-      const int ky = tap / 3, kx = tap - ky * 3;
-      aoff = (long)seg * p.conv_seg_stride + (long)(ky * (p.conv_W + 2) + kx) * p.conv_C + c0;
-    } else {
-      aoff = k0;
-    }
+    const long aoff = a_k_off(p, ks);
     char* abuf = smem + buf * 32768;
     char* wbuf = abuf + 16384;
 #pragma unroll
@@ -178,55 +112,14 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16_kernel(GemmArgs p) {
   }
 
   // ---- epilogue: lane holds n = nb + fg*4 + {0..3}, m = mb + fr ----
-  const bool partial = p.splits > 1;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int m = m0 + wm * 64 + i * 16 + fr;
     if (m >= p.M) continue;
-    long orow = m;
-    if (p.c_group > 0) orow = (long)(m / p.c_group) * p.c_group_stride + p.c_row_off + (m % p.c_group);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int n = n0 + wn * 64 + j * 16 + fg * 4;
-      if (n >= p.N) continue;
-      f32x4 v = acc[j][i];
-      if (partial) {
-        float* dst = p.ws + ((long)z * p.M + m) * p.N + n;
-        *(f32x4*)dst = v;
-        continue;
-      }
-      if (p.bias) {
-        const f32x4 b = *(const f32x4*)(p.bias + n);
-        v += b;
-      }
-      if (p.act == 3) {  // SwiGLU on interleaved (gate, up) pairs
-        const float o0 = silu_f(v[0]) * v[1];
-        const float o1 = silu_f(v[2]) * v[3];
-        bf16_t* dst = (bf16_t*)p.C + orow * p.ldc + (n >> 1);
-        *(uint32_t*)dst = pack2bf(o0, o1);
-        continue;
-      }
-      if (p.act) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = act_apply(v[e], p.act);
-      }
-      if (p.scale) {
-        const f32x4 s = *(const f32x4*)(p.scale + n);
-        v *= s;
-      }
-      if (p.resid) {
-        const long rrow = p.resid_mod > 0 ? (long)(m % p.resid_mod) : orow;
-        const f32x4 r = *(const f32x4*)(p.resid + rrow * p.ldr + n);
-        v += r;
-      }
-      if (p.out_f32) {
-        *(f32x4*)((float*)p.C + orow * p.ldc + n) = v;
-      } else {
-        uint2 pk;
-        pk.x = pack2bf(v[0], v[1]);
-        pk.y = pack2bf(v[2], v[3]);
-        *(uint2*)((bf16_t*)p.C + orow * p.ldc + n) = pk;
-      }
+      if (n < p.N) epi_store(p, acc[j][i], m, n, z);
     }
   }
 }
@@ -270,7 +163,7 @@ __global__ void gemm_splitk_reduce_kernel(GemmArgs p) {
 // ---- timing hook (bench.py roofline leg): HIP events on the launch stream around every GEMM launch ----
 #include <vector>
 static bool g_prof_on = false;
-struct ProfRec { hipEvent_t a, b; double flops; };
+struct ProfRec { hipEvent_t a, b; double flops; int M, N, K, tag; };
 static std::vector<ProfRec> g_prof;
 
 extern "C" int gr_abi_version(void) { return GROMA_HIP_ABI_VERSION; }
@@ -293,6 +186,26 @@ extern "C" int gr_prof_read(double* total_ms, long* launches, double* flops) {
   if (total_ms) *total_ms = ms;
   if (launches) *launches = n;
   if (flops) *flops = fl;
+  return GR_OK;
+}
+
+// per-launch variant of gr_prof_read: fills mnk[4*i..] = (M, N, K, tag) and ms[i]; drains the records
+extern "C" int gr_prof_read_launches(long cap, int* mnk, float* ms, long* n_out) {
+  long n = 0;
+  for (auto& r : g_prof) {
+    if (hipEventSynchronize(r.b) != hipSuccess) return GR_EINVAL;
+    float t = 0.f;
+    if (hipEventElapsedTime(&t, r.a, r.b) != hipSuccess) return GR_EINVAL;
+    if (n < cap && mnk && ms) {
+      mnk[4 * n] = r.M; mnk[4 * n + 1] = r.N; mnk[4 * n + 2] = r.K; mnk[4 * n + 3] = r.tag;
+      ms[n] = t;
+    }
+    ++n;
+    (void)hipEventDestroy(r.a);
+    (void)hipEventDestroy(r.b);
+  }
+  g_prof.clear();
+  if (n_out) *n_out = n;
   return GR_OK;
 }
 
@@ -319,8 +232,19 @@ extern "C" int gr_gemm_bf16(const gr_gemm_desc* d, hipStream_t stream) {
   p.conv_seg_stride = d->conv_seg_stride;
   p.resid_mod = d->resid_mod;
   p.c_group = d->c_group; p.c_group_stride = d->c_group_stride; p.c_row_off = d->c_row_off;
-  p.tiles_m = gr_cdiv(p.M, BM);
-  p.tiles_n = gr_cdiv(p.N, BN);
+  // ---- kernel choice: estimated time = rounds x per-slot tile time (slots: 512 for 128^2 at 2 blocks/CU, 256 for
+  // 256^2 at 1 block/CU; per-CU throughput ratio measured on MI355X) ----
+  bool use256 = false;
+  if (d->tile == 256) use256 = true;
+  else if (d->tile == 0) {
+    const long t128 = (long)gr_cdiv(p.M, 128) * gr_cdiv(p.N, 128), t256 = (long)gr_cdiv(p.M, 256) * gr_cdiv(p.N, 256);
+    const double ksteps = (double)(p.K / 64) / splits;
+    const double e128 = (double)((t128 * splits + 511) / 512) * (ksteps * 1.00 + 6.0);         // 2 tiles of 128^2 per CU
+    const double e256 = (double)((t256 * splits + 255) / 256) * (ksteps * 1.00 * G256_COST + 22.0);
+    use256 = e256 < e128;
+  }
+  p.tiles_m = gr_cdiv(p.M, use256 ? 256 : BM);
+  p.tiles_n = gr_cdiv(p.N, use256 ? 256 : BN);
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
@@ -333,9 +257,15 @@ extern "C" int gr_gemm_bf16(const gr_gemm_desc* d, hipStream_t stream) {
     (void)hipEventCreate(&rec.a);
     (void)hipEventCreate(&rec.b);
     rec.flops = 2.0 * p.M * (double)p.N * p.K;
+    rec.M = p.M; rec.N = p.N; rec.K = p.K; rec.tag = (p.conv_C > 0 ? 1 : 0) | (splits > 1 ? 2 : 0) | (use256 ? 4 : 0);
     (void)hipEventRecord(rec.a, stream);
   }
-  hipLaunchKernelGGL(gemm_bf16_kernel, grid, dim3(NTHREADS), 65536, stream, p);
+  if (use256) {
+    const int rc = gr_launch_gemm256(p, stream);
+    if (rc != GR_OK) return rc;
+  } else {
+    hipLaunchKernelGGL(gemm_bf16_kernel, grid, dim3(NTHREADS), 65536, stream, p);
+  }
   if (g_prof_on) {
     (void)hipEventRecord(rec.b, stream);
     g_prof.push_back(rec);

@@ -1,0 +1,267 @@
+// 256x256x64 bf16 MFMA GEMM for gfx950 -- "ping-pong" schedule.
+//
+// Why a second kernel: at 128x128 a CU at full MFMA rate pulls 64 B/clk of operands through L2 (2/128 bytes per
+// flop), more than the ~34 TB/s the eight L2s deliver, so that structure tops out near 0.9 PF
+// (cdna_hip_programming.md §5 ladder).  A 256x256 tile halves the operand traffic per flop.
+//
+// Structure (8 waves = 2(M) x 4(N), each wave a 128x64 output block = 8x4 tiles of v_mfma_f32_16x16x32_bf16):
+//  * the two wave groups (wm = 0 / 1) that share each SIMD run one barrier interval apart: while one group issues
+//    its 16 MFMAs of a phase, the other does that phase's LDS fragment reads and global->LDS DMA issue, then they
+//    swap ("8-phase" template of the guide, 4 phases per K-tile);
+//  * a phase computes one 64x32 quadrant of the wave's block over K=64.  Quadrant order (A0,B0) (A0,B1) (A1,B1)
+//    (A1,B0) keeps every fragment in registers after its single LDS read: A0,B0 are read in phase 0, B1 in phase 1,
+//    A1 in phase 2, nothing in phase 3;
+//  * LDS = 2 stages x (A 256x64 + B 256x64) bf16 = 128 KB.  Each stage is four 16 KB "half-tiles"
+//    {A0, B0, B1, A1} (the rows every wave needs for that fragment).  One half-tile (2 x global_load_lds_dwordx4 per
+//    lane) is issued per phase, in the order its LDS region becomes dead:
+//        phase 0 of tile t: A1(t+1)   phase 1: A0(t+2)   phase 2: B0(t+2)   phase 3: B1(t+2)
+//    so every half-tile has >= 6 phases of flight time, and ONE counted wait  s_waitcnt vmcnt(8)  at the top of each
+//    phase (4 younger half-tiles may stay in flight) retires exactly the half-tile read in the NEXT phase; the
+//    barrier that ends the phase publishes it to the other waves.  LDS reads are waited (lgkmcnt(0)) before that
+//    barrier, so a region is overwritten only >= 1 barrier after its last reader finished (both groups).
+//  * LDS image: 128-B rows, 16-B chunk position = k-chunk ^ (row & 7): written lane-linearly by the DMA with the
+//    XOR applied to the per-lane SOURCE address, mirrored on the ds_read_b128 side (conflict-free).
+#include "gemm_common.h"
+
+#define T256 256
+#define NT 512
+#define STAGE_BYTES 65536
+#define B_OFF 32768
+
+enum { HT_A0 = 0, HT_B0 = 1, HT_B1 = 2, HT_A1 = 3 };
+
+#define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0)
+
+__global__ __launch_bounds__(NT) void gemm_bf16_256_kernel(GemmArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+
+  int tm, tn;
+  tile_of_block(blockIdx.x, gridDim.x, p.tiles_m, p.tiles_n, tm, tn);
+  const int m0 = tm * T256, n0 = tn * T256;
+
+  const int ksteps_total = p.K / 64;
+  const int z = blockIdx.y;
+  const int ks_per = (ksteps_total + p.splits - 1) / p.splits;
+  const int ks_begin = z * ks_per;
+  const int nt = min(ksteps_total, ks_begin + ks_per) - ks_begin;
+
+  // ---- staging geometry.  Half-tile = 128 rows x 8 chunks; chunk q = i*512 + tid (i = 0,1): hrow = q>>3.
+  // physical row inside the 256-row region:  A0: (hrow>>6)*128 + (hrow&63)   A1: +64
+  //                                          B0: (hrow>>5)*64  + (hrow&31)   B1: +32
+  const int lrow = lane >> 3, lpos = lane & 7;
+  const bf16_t* src[4][2];  // [half-tile][i] : per-lane global source (row base + swizzled chunk), k-offset added later
+  int ldsoff[4][2];         // wave-uniform LDS byte offset inside a stage
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int ra = i * 128 + wave * 8;                            // A0 row of lane 0
+    const int rb = (i * 2 + (wave >> 2)) * 64 + (wave & 3) * 8;   // B0 row of lane 0
+    const int rows[4] = {ra, rb, rb + 32, ra + 64};
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {
+      const int r = rows[h] + lrow;
+      const int kc = lpos ^ (r & 7);
+      const bool isA = (h == HT_A0 || h == HT_A1);
+      if (isA) {
+        int m = m0 + r;
+        if (m > p.M - 1) m = p.M - 1;
+        src[h][i] = p.A + a_row_base(p, m) + kc * 8;
+      } else {
+        int n = n0 + r;
+        if (n > p.N - 1) n = p.N - 1;
+        src[h][i] = p.W + (long)n * p.ldw + kc * 8;
+      }
+      ldsoff[h][i] = (isA ? 0 : B_OFF) + rows[h] * 128;
+    }
+  }
+
+  // A-operand k offsets of K-tiles t+1 and t+2 are carried incrementally (the conv gather's (segment, tap, channel)
+  // decomposition needs integer divisions otherwise -- too slow for the 16-MFMA shadow of a phase)
+  long aoff1 = a_k_off(p, ks_begin + 1), aoff2 = a_k_off(p, ks_begin + 2);
+  int cv_c = 0, cv_kx = 0, cv_ky = 0;
+  long cv_base = 0;  // state of tile t+2
+  if (p.conv_C > 0) {
+    const long k0 = (long)(ks_begin + 2) * 64;
+    const int tapc = (int)(k0 / p.conv_C);
+    cv_c = (int)(k0 - (long)tapc * p.conv_C);
+    const int seg = tapc / 9, tap = tapc - seg * 9;
+    cv_ky = tap / 3;
+    cv_kx = tap - cv_ky * 3;
+    cv_base = (long)seg * p.conv_seg_stride;
+  }
+  auto advance = [&]() {  // (aoff1, aoff2) <- (aoff2, offset of the following K-tile)
+    aoff1 = aoff2;
+    if (p.conv_C > 0) {
+      cv_c += 64;
+      if (cv_c == p.conv_C) {
+        cv_c = 0;
+        if (++cv_kx == 3) {
+          cv_kx = 0;
+          if (++cv_ky == 3) { cv_ky = 0; cv_base += p.conv_seg_stride; }
+        }
+      }
+      aoff2 = cv_base + (long)(cv_ky * (p.conv_W + 2) + cv_kx) * p.conv_C + cv_c;
+    } else {
+      aoff2 += 64;
+    }
+  };
+
+  auto issue_at = [&](int h, int tile, long koff) {  // one half-tile of K-tile `tile` into stage tile&1
+    if (tile >= nt) return;
+    char* st = smem + (tile & 1) * STAGE_BYTES;
+    glds16(src[h][0] + koff, st + ldsoff[h][0]);
+    glds16(src[h][1] + koff, st + ldsoff[h][1]);
+  };
+  auto issue = [&](int h, int tile) {  // prologue form (offset from the tile index)
+    const bool isA = (h == HT_A0 || h == HT_A1);
+    issue_at(h, tile, isA ? a_k_off(p, ks_begin + tile) : (long)(ks_begin + tile) * 64);
+  };
+
+  f32x4 acc[8][4];  // [mi][ni]
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int fr = lane & 15, fg = lane >> 4;
+  const int off0 = (fg ^ (fr & 7)) << 4;  // chunk fg of a row with (row&7) == (fr&7); the kk=1 chunk is off0 ^ 64
+  const int a_lane = (wm * 128 + fr) * 128;
+  const int b_lane = B_OFF + (wn * 64 + fr) * 128;
+
+  // ---- prologue: A0(0) B0(0) B1(0) A1(0) A0(1) B0(1) B1(1)
+  issue(HT_A0, 0); issue(HT_B0, 0); issue(HT_B1, 0); issue(HT_A1, 0);
+  issue(HT_A0, 1); issue(HT_B0, 1); issue(HT_B1, 1);
+  if (nt >= 2) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");  // A0(0), B0(0) landed
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  if (wm == 1) __builtin_amdgcn_s_barrier();  // stagger the second wave group by one interval
+
+  bf16x8 af[4][2], b0f[2][2], b1f[2][2];
+
+  for (int t = 0; t < nt; ++t) {
+    const char* st = smem + (t & 1) * STAGE_BYTES;
+    const bool steady = t + 2 < nt;  // every half-tile of the uniform schedule was really issued
+    // ================= phase 0 : reads A0,B0 ; computes A0 x B0 ; issues A1(t+1)
+    if (steady) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    issue_at(HT_A1, t + 1, aoff1);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      b0f[j][0] = *(const bf16x8*)(st + b_lane + j * 2048 + off0);
+      b0f[j][1] = *(const bf16x8*)(st + b_lane + j * 2048 + (off0 ^ 64));
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      af[i][0] = *(const bf16x8*)(st + a_lane + i * 2048 + off0);
+      af[i][1] = *(const bf16x8*)(st + a_lane + i * 2048 + (off0 ^ 64));
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = MFMA16(b0f[j][kk], af[i][kk], acc[i][j]);
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    // ================= phase 1 : reads B1 ; computes A0 x B1 ; issues A0(t+2)
+    if (steady) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    issue_at(HT_A0, t + 2, aoff2);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      b1f[j][0] = *(const bf16x8*)(st + b_lane + (2 + j) * 2048 + off0);
+      b1f[j][1] = *(const bf16x8*)(st + b_lane + (2 + j) * 2048 + (off0 ^ 64));
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][2 + j] = MFMA16(b1f[j][kk], af[i][kk], acc[i][2 + j]);
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    // ================= phase 2 : reads A1 ; computes A1 x B1 ; issues B0(t+2)
+    if (steady) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    issue_at(HT_B0, t + 2, (long)(ks_begin + t + 2) * 64);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      af[i][0] = *(const bf16x8*)(st + a_lane + (4 + i) * 2048 + off0);
+      af[i][1] = *(const bf16x8*)(st + a_lane + (4 + i) * 2048 + (off0 ^ 64));
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[4 + i][2 + j] = MFMA16(b1f[j][kk], af[i][kk], acc[4 + i][2 + j]);
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    // ================= phase 3 : no LDS reads ; computes A1 x B0 ; issues B1(t+2)
+    if (steady) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    issue_at(HT_B1, t + 2, (long)(ks_begin + t + 2) * 64);
+    advance();
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[4 + i][j] = MFMA16(b0f[j][kk], af[i][kk], acc[4 + i][j]);
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  if (wm == 0) __builtin_amdgcn_s_barrier();  // re-align the groups (same barrier count for every wave)
+
+  // ---- epilogue: lane holds n = nb + fg*4 + {0..3}, m = mb + fr ----
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int m = m0 + wm * 128 + i * 16 + fr;
+    if (m >= p.M) continue;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n = n0 + wn * 64 + j * 16 + fg * 4;
+      if (n < p.N) epi_store(p, acc[i][j], m, n, z);
+    }
+  }
+}
+
+int gr_launch_gemm256(const GemmArgs& p, hipStream_t stream) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       2 * STAGE_BYTES);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  dim3 grid(p.tiles_m * p.tiles_n, p.splits);
+  hipLaunchKernelGGL(gemm_bf16_256_kernel, grid, dim3(NT), 2 * STAGE_BYTES, stream, p);
+  GR_CHECK_LAUNCH();
+  return GR_OK;
+}

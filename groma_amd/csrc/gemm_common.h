@@ -1,0 +1,114 @@
+// Shared pieces of the bf16 MFMA GEMM kernels (128x128 two-barrier kernel, 256x256 ping-pong kernel).
+#pragma once
+#include "gr_common.h"
+#include "../../include/groma_hip.h"
+
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+__device__ __forceinline__ void glds16(const void* g, void* l) {
+  __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)l, 16, 0, 0);
+}
+
+struct GemmArgs {
+  const bf16_t* A;
+  const bf16_t* W;
+  void* C;
+  const float* bias;
+  const float* scale;
+  const float* resid;
+  float* ws;
+  int M, N, K;
+  long lda, ldw, ldc, ldr;
+  int act, out_f32, splits;
+  int conv_H, conv_W, conv_C;
+  long conv_seg_stride;
+  int resid_mod;
+  int c_group, c_group_stride, c_row_off;
+  int tiles_m, tiles_n;
+};
+
+// XCD-aware, L2-friendly tile order: consecutive ids on one XCD (block b runs on XCD b%8),
+// grouped so 8 row-tiles share each W panel.
+__device__ __forceinline__ void tile_of_block(int bid, int nwg, int tiles_m, int tiles_n, int& tm, int& tn) {
+  const int q = nwg >> 3, r = nwg & 7;
+  const int xcd = bid & 7, idx = bid >> 3;
+  int pid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  const int GROUP = 8;
+  const int per_group = GROUP * tiles_n;
+  const int g = pid / per_group;
+  const int first_m = g * GROUP;
+  const int gsize = min(tiles_m - first_m, GROUP);
+  const int in_g = pid - g * per_group;
+  tm = first_m + in_g % gsize;
+  tn = in_g / gsize;
+}
+
+__device__ __forceinline__ float act_apply(float v, int act) {
+  if (act == 1) return gelu_erf(v);
+  if (act == 2) return fmaxf(v, 0.f);
+  return v;
+}
+
+// A-operand row base (elements) of output row m: plain row-major, or the top-left tap of the 3x3 window in the
+// zero-bordered NHWC map (implicit-GEMM convolution)
+__device__ __forceinline__ long a_row_base(const GemmArgs& p, int m) {
+  if (p.conv_C > 0) {
+    const int hw = p.conv_H * p.conv_W;
+    const int img = m / hw;
+    const int rem = m - img * hw;
+    const int y = rem / p.conv_W;
+    const int x = rem - y * p.conv_W;
+    return ((long)(img * (p.conv_H + 2) + y) * (p.conv_W + 2) + x) * p.conv_C;
+  }
+  return (long)m * p.lda;
+}
+// A-operand K offset (elements) of K-step ks (64 wide): plain k, or (segment, tap, channel) of the conv gather
+__device__ __forceinline__ long a_k_off(const GemmArgs& p, int ks) {
+  const long k0 = (long)ks * 64;
+  if (p.conv_C > 0) {
+    const int tapc = (int)(k0 / p.conv_C);  // segment*9 + tap
+    const int c0 = (int)(k0 - (long)tapc * p.conv_C);
+    const int seg = tapc / 9;
+    const int tap = tapc - seg * 9;
+    const int ky = tap / 3, kx = tap - ky * 3;
+    return (long)seg * p.conv_seg_stride + (long)(ky * (p.conv_W + 2) + kx) * p.conv_C + c0;
+  }
+  return k0;
+}
+
+// Epilogue for one lane-owned vector: 4 consecutive columns n..n+3 of row m (the swapped-operand MFMA layout).
+__device__ __forceinline__ void epi_store(const GemmArgs& p, f32x4 v, int m, int n, int z) {
+  if (p.splits > 1) {
+    *(f32x4*)(p.ws + ((long)z * p.M + m) * p.N + n) = v;
+    return;
+  }
+  long orow = m;
+  if (p.c_group > 0) orow = (long)(m / p.c_group) * p.c_group_stride + p.c_row_off + (m % p.c_group);
+  if (p.bias) v += *(const f32x4*)(p.bias + n);
+  if (p.act == 3) {  // SwiGLU on interleaved (gate, up) pairs
+    bf16_t* dst = (bf16_t*)p.C + orow * p.ldc + (n >> 1);
+    *(uint32_t*)dst = pack2bf(silu_f(v[0]) * v[1], silu_f(v[2]) * v[3]);
+    return;
+  }
+  if (p.act) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = act_apply(v[e], p.act);
+  }
+  if (p.scale) v *= *(const f32x4*)(p.scale + n);
+  if (p.resid) {
+    const long rrow = p.resid_mod > 0 ? (long)(m % p.resid_mod) : orow;
+    v += *(const f32x4*)(p.resid + rrow * p.ldr + n);
+  }
+  if (p.out_f32) {
+    *(f32x4*)((float*)p.C + orow * p.ldc + n) = v;
+  } else {
+    uint2 pk;
+    pk.x = pack2bf(v[0], v[1]);
+    pk.y = pack2bf(v[2], v[3]);
+    *(uint2*)((bf16_t*)p.C + orow * p.ldc + n) = pk;
+  }
+}
+
+// 256x256x64 ping-pong kernel (gemm_bf16_256.hip)
+int gr_launch_gemm256(const GemmArgs& p, hipStream_t stream);

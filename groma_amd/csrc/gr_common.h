@@ -28,8 +28,17 @@ __device__ __forceinline__ uint32_t pack2bf(float a, float b) {
   return (uint32_t)f2bf(a) | ((uint32_t)f2bf(b) << 16);
 }
 
+// erf via Abramowitz-Stegun 7.1.26 (|abs err| <= 1.5e-7, i.e. fp32-roundoff class): ~14 VALU ops instead of the
+// ~60 of ocml erff -- the exact-erf GELU (HF "gelu") epilogue of the ViT fc1 / bridge GEMMs is VALU-visible otherwise.
+__device__ __forceinline__ float erf_as(float x) {
+  const float ax = fabsf(x);
+  const float t = 1.0f / (1.0f + 0.3275911f * ax);
+  const float poly = ((((1.061405429f * t - 1.453152027f) * t + 1.421413741f) * t - 0.284496736f) * t + 0.254829592f) * t;
+  const float r = 1.0f - poly * __expf(-ax * ax);
+  return x < 0.f ? -r : r;
+}
 __device__ __forceinline__ float gelu_erf(float x) {
-  return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+  return 0.5f * x * (1.0f + erf_as(x * 0.70710678118654752440f));
 }
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
 __device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + expf(-x)); }

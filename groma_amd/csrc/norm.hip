@@ -9,7 +9,9 @@
 
 #define MAXV 16  // up to 16 float4 per lane -> C <= 4096
 
-template <bool RMS>
+// NV = float4 per lane (compile-time: keeps the row in exactly NV*4 registers so 6-8 waves/SIMD stay resident and
+// the HBM latency of one row is hidden behind the others)
+template <bool RMS, int NV>
 __global__ __launch_bounds__(256) void norm_rows_kernel(const float* __restrict__ x, const float* __restrict__ add,
                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
                                                         void* __restrict__ out, float* __restrict__ sum_out, int rows, int C,
@@ -19,11 +21,11 @@ __global__ __launch_bounds__(256) void norm_rows_kernel(const float* __restrict_
   if (row >= rows) return;
   const float* xr = x + (long)row * ldx;
   const float* ar = add ? add + (long)row * ldx : nullptr;
-  const int nv = C >> 8;  // float4 per lane (C multiple of 256)
-  f32x4 v[MAXV];
+  constexpr int nv = NV;  // float4 per lane (C == NV*256)
+  f32x4 v[NV];
   float s = 0.f;
 #pragma unroll
-  for (int i = 0; i < MAXV; ++i) {
+  for (int i = 0; i < NV; ++i) {
     if (i < nv) {
       v[i] = *(const f32x4*)(xr + i * 256 + lane * 4);
       if (ar) v[i] += *(const f32x4*)(ar + i * 256 + lane * 4);
@@ -43,7 +45,7 @@ __global__ __launch_bounds__(256) void norm_rows_kernel(const float* __restrict_
     mean = s / (float)C;
     float q = 0.f;
 #pragma unroll
-    for (int i = 0; i < MAXV; ++i) {
+    for (int i = 0; i < NV; ++i) {
       if (i < nv) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -58,11 +60,11 @@ __global__ __launch_bounds__(256) void norm_rows_kernel(const float* __restrict_
   if (sum_out) {  // optionally keep the (added) pre-norm row: residual stream update for post-LN blocks
     float* so = sum_out + (long)row * ldx;
 #pragma unroll
-    for (int i = 0; i < MAXV; ++i)
+    for (int i = 0; i < NV; ++i)
       if (i < nv) *(f32x4*)(so + i * 256 + lane * 4) = v[i];
   }
 #pragma unroll
-  for (int i = 0; i < MAXV; ++i) {
+  for (int i = 0; i < NV; ++i) {
     if (i < nv) {
       const int c = i * 256 + lane * 4;
       const f32x4 g = *(const f32x4*)(gamma + c);
@@ -88,18 +90,37 @@ __global__ __launch_bounds__(256) void norm_rows_kernel(const float* __restrict_
 extern "C" int gr_layernorm(const float* x, const float* add, const float* gamma, const float* beta, void* out,
                             int rows, int C, long ldx, long ldo, float eps, int out_bf16, int relu_in,
                             hipStream_t stream) {
-  if (!x || !gamma || !out || rows <= 0 || C <= 0 || C % 256 != 0 || C > 256 * MAXV) return GR_EINVAL;
-  hipLaunchKernelGGL(norm_rows_kernel<false>, dim3(gr_cdiv(rows, 4)), dim3(256), 0, stream, x, add, gamma, beta, out,
-                     (float*)nullptr, rows, C, ldx, ldo, eps, out_bf16, relu_in);
+  if (!x || !gamma || !out || rows <= 0 || C <= 0 || C % 256 != 0 || C > 256 * MAXV || ((C >> 8) & ((C >> 8) - 1))) return GR_EINVAL;
+#define LAUNCH_LN(NVAL)                                                                                            \
+  hipLaunchKernelGGL((norm_rows_kernel<false, NVAL>), dim3(gr_cdiv(rows, 4)), dim3(256), 0, stream, x, add, gamma, \
+                     beta, out, (float*)nullptr, rows, C, ldx, ldo, eps, out_bf16, relu_in)
+  switch (C >> 8) {
+    case 1: LAUNCH_LN(1); break;
+    case 2: LAUNCH_LN(2); break;
+    case 4: LAUNCH_LN(4); break;
+    case 8: LAUNCH_LN(8); break;
+    case 16: LAUNCH_LN(16); break;
+    default: return GR_EINVAL;
+  }
   GR_CHECK_LAUNCH();
   return GR_OK;
 }
 
 extern "C" int gr_rmsnorm(const float* x, const float* gamma, void* out, int rows, int C, long ldx, long ldo, float eps,
                           int out_bf16, hipStream_t stream) {
-  if (!x || !gamma || !out || rows <= 0 || C <= 0 || C % 256 != 0 || C > 256 * MAXV) return GR_EINVAL;
-  hipLaunchKernelGGL(norm_rows_kernel<true>, dim3(gr_cdiv(rows, 4)), dim3(256), 0, stream, x, (const float*)nullptr,
-                     gamma, (const float*)nullptr, out, (float*)nullptr, rows, C, ldx, ldo, eps, out_bf16, 0);
+  if (!x || !gamma || !out || rows <= 0 || C <= 0 || C % 256 != 0 || C > 256 * MAXV || ((C >> 8) & ((C >> 8) - 1))) return GR_EINVAL;
+#define LAUNCH_RMS(NVAL)                                                                                          \
+  hipLaunchKernelGGL((norm_rows_kernel<true, NVAL>), dim3(gr_cdiv(rows, 4)), dim3(256), 0, stream, x,             \
+                     (const float*)nullptr, gamma, (const float*)nullptr, out, (float*)nullptr, rows, C, ldx, ldo, eps, \
+                     out_bf16, 0)
+  switch (C >> 8) {
+    case 1: LAUNCH_RMS(1); break;
+    case 2: LAUNCH_RMS(2); break;
+    case 4: LAUNCH_RMS(4); break;
+    case 8: LAUNCH_RMS(8); break;
+    case 16: LAUNCH_RMS(16); break;
+    default: return GR_EINVAL;
+  }
   GR_CHECK_LAUNCH();
   return GR_OK;
 }

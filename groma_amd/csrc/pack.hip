@@ -18,63 +18,68 @@ __global__ __launch_bounds__(256) void qkv_split_kernel(const bf16_t* __restrict
                                                         bf16_t* __restrict__ k, bf16_t* __restrict__ vt,
                                                         const float* __restrict__ cosT, const float* __restrict__ sinT,
                                                         int B, int H, int L, int pos0, int kv_stride) {
-  __shared__ bf16_t vs[64][HD + 2];
+  __shared__ __attribute__((aligned(16))) bf16_t vs[64][HD + 8];
   const int t0 = blockIdx.x * 64;
   const int h = blockIdx.y, b = blockIdx.z;
   const int tid = threadIdx.x;
   const long row_stride = 3L * H * HD;
   constexpr int HALF = HD / 2;
-  // each thread: token tt = tid/4 (+0), quarter of the head dim per thread
-  const int tt = tid >> 2, part = tid & 3;
-  constexpr int PER = HD / 4;  // elements per thread (16 or 32)
-  const int t = t0 + tt;
-  if (t < L) {
+  constexpr int CH = HD / 8;  // 16-B chunks per head row
+  // ---- q, k (+ RoPE) and v -> LDS: one 16-B chunk per work item ----
+  for (int it = tid; it < 64 * CH; it += 256) {
+    const int tt = it / CH, d = (it - tt * CH) * 8;
+    const int t = t0 + tt;
+    if (t >= L) {
+      *(bf16x8*)&vs[tt][d] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+      continue;
+    }
     const bf16_t* src = qkv + ((long)b * L + t) * row_stride + h * HD;
     const int pos = pos0 + t;
-    // q and k with optional rope
+    *(bf16x8*)&vs[tt][d] = *(const bf16x8*)(src + 2L * H * HD + d);
+#pragma unroll
     for (int which = 0; which < 2; ++which) {
-      const bf16_t* s = src + (long)which * H * HD;
+      const bf16_t* sp = src + (long)which * H * HD;
       bf16_t* dst = which == 0 ? q + (((long)b * H + h) * L + t) * HD : k + (((long)b * H + h) * kv_stride + pos) * HD;
+      const bf16x8 x = *(const bf16x8*)(sp + d);
+      if (cosT) {
+        const int dp = d < HALF ? d + HALF : d - HALF;  // rotate_half partner
+        const bf16x8 y = *(const bf16x8*)(sp + dp);
+        const int dc = d < HALF ? d : d - HALF;
+        const float sgn = d < HALF ? -1.f : 1.f;
+        const f32x4 c0 = *(const f32x4*)(cosT + (long)pos * HALF + dc), c1 = *(const f32x4*)(cosT + (long)pos * HALF + dc + 4);
+        const f32x4 s0 = *(const f32x4*)(sinT + (long)pos * HALF + dc), s1 = *(const f32x4*)(sinT + (long)pos * HALF + dc + 4);
+        union { bf16x8 v; uint32_t u[4]; } o;
 #pragma unroll
-      for (int e = 0; e < PER; e += 8) {
-        const int d = part * PER + e;
-        const bf16x8 x = *(const bf16x8*)(s + d);
-        if (cosT) {
-          const int dp = d < HALF ? d + HALF : d - HALF;  // partner
-          const bf16x8 y = *(const bf16x8*)(s + dp);
-          const int dc = d < HALF ? d : d - HALF;
-          const float sgn = d < HALF ? -1.f : 1.f;
-          union { bf16x8 v; uint32_t u[4]; } o;
-#pragma unroll
-          for (int i = 0; i < 8; i += 2) {
-            const float c0 = cosT[(long)pos * HALF + dc + i], s0 = sinT[(long)pos * HALF + dc + i];
-            const float c1 = cosT[(long)pos * HALF + dc + i + 1], s1 = sinT[(long)pos * HALF + dc + i + 1];
-            const float r0 = bf2f((bf16_t)x[i]) * c0 + sgn * bf2f((bf16_t)y[i]) * s0;
-            const float r1 = bf2f((bf16_t)x[i + 1]) * c1 + sgn * bf2f((bf16_t)y[i + 1]) * s1;
-            o.u[i >> 1] = pack2bf(r0, r1);
-          }
-          *(bf16x8*)(dst + d) = o.v;
-        } else {
-          *(bf16x8*)(dst + d) = x;
+        for (int i = 0; i < 8; i += 2) {
+          const float ca = i < 4 ? c0[i] : c1[i - 4], cb = i < 4 ? c0[i + 1] : c1[i - 3];
+          const float sa = i < 4 ? s0[i] : s1[i - 4], sb = i < 4 ? s0[i + 1] : s1[i - 3];
+          const float r0 = bf2f((bf16_t)x[i]) * ca + sgn * bf2f((bf16_t)y[i]) * sa;
+          const float r1 = bf2f((bf16_t)x[i + 1]) * cb + sgn * bf2f((bf16_t)y[i + 1]) * sb;
+          o.u[i >> 1] = pack2bf(r0, r1);
         }
+        *(bf16x8*)(dst + d) = o.v;
+      } else {
+        *(bf16x8*)(dst + d) = x;
       }
     }
-    // v -> LDS
-    const bf16_t* s = src + 2L * H * HD;
-#pragma unroll
-    for (int e = 0; e < PER; ++e) vs[tt][part * PER + e] = s[part * PER + e];
-  } else {
-#pragma unroll
-    for (int e = 0; e < PER; ++e) vs[tt][part * PER + e] = 0;
   }
   __syncthreads();
-  // transpose out: thread -> (d, 16-token segment)
-  for (int idx = tid; idx < HD * 4; idx += 256) {
-    const int d = idx >> 2, seg = idx & 3;
-    bf16_t* dst = vt + (((long)b * H + h) * HD + d) * kv_stride + pos0 + t0 + seg * 16;
+  // ---- transposed write of V: work item = (d, 8-token group) -> one 16-B store when aligned ----
+  const bool aligned = ((pos0 + t0) & 7) == 0;
+  for (int it = tid; it < HD * 8; it += 256) {
+    const int d = it >> 3, seg = it & 7;
+    const int tb = t0 + seg * 8;
+    if (tb >= L) continue;
+    bf16_t* dst = vt + (((long)b * H + h) * HD + d) * kv_stride + pos0 + tb;
+    if (aligned && tb + 8 <= L) {
+      union { bf16x8 v; bf16_t e[8]; } o;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      if (t0 + seg * 16 + i < L) dst[i] = vs[seg * 16 + i][d];
+      for (int i = 0; i < 8; ++i) o.e[i] = vs[seg * 8 + i][d];
+      *(bf16x8*)dst = o.v;
+    } else {
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+        if (tb + i < L) dst[i] = vs[seg * 8 + i][d];
     }
   }
 }
@@ -310,39 +315,56 @@ extern "C" int gr_gn_stats(const void* x, float* sums, int imgs, int HW, int C, 
   return GR_OK;
 }
 
+// sums [imgs, C, 2] -> coef [imgs, 2, C]: y = x*a[c] + b[c]  (a = rstd*gamma, b = beta - mean*rstd*gamma);
+// torch.group_norm semantics: biased variance over (HW x C/groups) elements, eps inside the sqrt.
+__global__ void gn_finalize_kernel(const float* __restrict__ sums, const float* __restrict__ gamma,
+                                   const float* __restrict__ beta, float* __restrict__ coef, int imgs, int C, int cpg,
+                                   float n, float eps) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= imgs * C) return;
+  const int img = idx / C, ch = idx - img * C;
+  const int g0 = (ch / cpg) * cpg;
+  float sm = 0.f, sq = 0.f;
+  for (int k = 0; k < cpg; ++k) {
+    sm += sums[((long)img * C + g0 + k) * 2];
+    sq += sums[((long)img * C + g0 + k) * 2 + 1];
+  }
+  const float mean = sm / n;
+  const float var = fmaxf(sq / n - mean * mean, 0.f);
+  const float rstd = 1.0f / sqrtf(var + eps);
+  const float a = rstd * gamma[ch];
+  coef[((long)img * 2 + 0) * C + ch] = a;
+  coef[((long)img * 2 + 1) * C + ch] = beta[ch] - mean * a;
+}
+extern "C" int gr_gn_finalize(const float* sums, const float* gamma, const float* beta, float* coef, int imgs, int HW,
+                              int C, int groups, float eps, hipStream_t stream) {
+  if (!sums || !gamma || !beta || !coef || groups <= 0 || C % groups != 0) return GR_EINVAL;
+  const int cpg = C / groups;
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(gr_cdiv((long)imgs * C, 256)), dim3(256), 0, stream, sums, gamma, beta, coef,
+                     imgs, C, cpg, (float)HW * (float)cpg, eps);
+  GR_CHECK_LAUNCH();
+  return GR_OK;
+}
+
 // ---------------------------------------------------------------------------------------
 // GroupNorm + ReLU + cross-level channel shuffle (groma/model/roi_align.py:150-178), producing the
 // zero-bordered NHWC bf16 input of the next 3x3 conv for ONE target level:
 //   ch [0, C/2)        <- tar   [0, C/2)       same pixel
 //   ch [C/2, 3C/4)     <- top   [3C/4, C)      bilinear align_corners=True resize to the target size
 //   ch [3C/4, C)       <- down  [C/2, 3C/4)    bilinear align_corners=True resize to the target size
-// Each source is relu(gn(conv_out)) when its sums pointer is non-null, else the raw map (round 0).
+// Each source is relu(gn(conv_out)) when its coef pointer (gr_gn_finalize) is non-null, else the raw map (round 0).
 // shuffle==0: plain relu(gn(.)) of tar for all channels (final round -> RoIAlign input, pad=0 layout allowed).
 struct ShufSrc {
   const bf16_t* x;    // [imgs*S*S, C]
-  const float* sums;  // [imgs, C, 2] or null
+  const float* coef;  // [imgs, 2, C] from gr_gn_finalize, or null (raw map, round 0)
   int S;
 };
-__device__ __forceinline__ void gn_coeff(const ShufSrc& s, const float* gamma, const float* beta, int img, int c, int C,
-                                         int cpg, float eps, float* a, float* bb) {
-  // 8 consecutive channels starting at c: per-channel scale/shift so y = x*a + b
-  const float n = (float)s.S * (float)s.S * (float)cpg;
+__device__ __forceinline__ void load_coef(const ShufSrc& s, int img, int c, int C, float* a, float* bb) {
+  const float* pa = s.coef + ((long)img * 2) * C + c;
+  const f32x4 a0 = *(const f32x4*)pa, a1 = *(const f32x4*)(pa + 4);
+  const f32x4 b0 = *(const f32x4*)(pa + C), b1 = *(const f32x4*)(pa + C + 4);
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int ch = c + i;
-    const int g0 = (ch / cpg) * cpg;
-    float sm = 0.f, sq = 0.f;
-    for (int k = 0; k < cpg; ++k) {
-      sm += s.sums[((long)img * C + g0 + k) * 2];
-      sq += s.sums[((long)img * C + g0 + k) * 2 + 1];
-    }
-    const float mean = sm / n;
-    float var = sq / n - mean * mean;
-    var = fmaxf(var, 0.f);
-    const float rstd = 1.0f / sqrtf(var + eps);
-    a[i] = rstd * gamma[ch];
-    bb[i] = beta[ch] - mean * rstd * gamma[ch];
-  }
+  for (int i = 0; i < 4; ++i) { a[i] = a0[i]; a[4 + i] = a1[i]; bb[i] = b0[i]; bb[4 + i] = b1[i]; }
 }
 __device__ __forceinline__ void load8(const ShufSrc& s, bool norm, const float* a, const float* bb, int img, int y, int x,
                                       int c, int C, float* o) {
@@ -354,10 +376,8 @@ __device__ __forceinline__ void load8(const ShufSrc& s, bool norm, const float* 
     o[i] = f;
   }
 }
-__global__ __launch_bounds__(256) void fuse_shuffle_kernel(ShufSrc tar, ShufSrc top, ShufSrc down,
-                                                           const float* __restrict__ gamma,
-                                                           const float* __restrict__ beta, bf16_t* __restrict__ out,
-                                                           int imgs, int C, int cpg, float eps, int shuffle, int pad) {
+__global__ __launch_bounds__(256) void fuse_shuffle_kernel(ShufSrc tar, ShufSrc top, ShufSrc down, bf16_t* __restrict__ out,
+                                                           int imgs, int C, int shuffle, int pad) {
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;  // 8-channel chunk
   const int c8 = C >> 3;
   const int S = tar.S;
@@ -369,15 +389,15 @@ __global__ __launch_bounds__(256) void fuse_shuffle_kernel(ShufSrc tar, ShufSrc 
   float o[8];
   float a[8], bb[8];
   if (!shuffle || c < C / 2) {
-    const bool norm = tar.sums != nullptr;
-    if (norm) gn_coeff(tar, gamma, beta, img, c, C, cpg, eps, a, bb);
+    const bool norm = tar.coef != nullptr;
+    if (norm) load_coef(tar, img, c, C, a, bb);
     load8(tar, norm, a, bb, img, y, x, c, C, o);
   } else {
     const bool is_top = c < 3 * C / 4;
     const ShufSrc& src = is_top ? top : down;
     const int sc = is_top ? c + C / 4 : c - C / 4;  // source channel
-    const bool norm = src.sums != nullptr;
-    if (norm) gn_coeff(src, gamma, beta, img, sc, C, cpg, eps, a, bb);
+    const bool norm = src.coef != nullptr;
+    if (norm) load_coef(src, img, sc, C, a, bb);
     const int Ss = src.S;
     if (Ss == S) {
       load8(src, norm, a, bb, img, y, x, sc, C, o);
@@ -402,18 +422,16 @@ __global__ __launch_bounds__(256) void fuse_shuffle_kernel(ShufSrc tar, ShufSrc 
   const int Sp = S + 2 * pad;
   *(bf16x8*)(out + (((long)img * Sp + y + pad) * Sp + x + pad) * C + c) = pk.v;
 }
-extern "C" int gr_fuse_shuffle(const void* tar, const float* tar_sums, int tarS, const void* top, const float* top_sums,
-                               int topS, const void* down, const float* down_sums, int downS, const float* gamma,
-                               const float* beta, void* out, int imgs, int C, int groups, float eps, int shuffle, int pad,
-                               hipStream_t stream) {
-  if (!tar || !out || C % 32 != 0 || groups <= 0 || C % groups != 0) return GR_EINVAL;
+extern "C" int gr_fuse_shuffle(const void* tar, const float* tar_coef, int tarS, const void* top, const float* top_coef,
+                               int topS, const void* down, const float* down_coef, int downS, void* out, int imgs, int C,
+                               int shuffle, int pad, hipStream_t stream) {
+  if (!tar || !out || C % 32 != 0) return GR_EINVAL;
   if (shuffle && (!top || !down)) return GR_EINVAL;
-  if ((tar_sums || top_sums || down_sums) && (!gamma || !beta)) return GR_EINVAL;
-  ShufSrc a{(const bf16_t*)tar, tar_sums, tarS}, b{(const bf16_t*)top, top_sums, topS},
-      c{(const bf16_t*)down, down_sums, downS};
+  ShufSrc a{(const bf16_t*)tar, tar_coef, tarS}, b{(const bf16_t*)top, top_coef, topS},
+      c{(const bf16_t*)down, down_coef, downS};
   const long total = (long)imgs * tarS * tarS * (C >> 3);
-  hipLaunchKernelGGL(fuse_shuffle_kernel, dim3(gr_cdiv(total, 256)), dim3(256), 0, stream, a, b, c, gamma, beta,
-                     (bf16_t*)out, imgs, C, C / groups, eps, shuffle, pad);
+  hipLaunchKernelGGL(fuse_shuffle_kernel, dim3(gr_cdiv(total, 256)), dim3(256), 0, stream, a, b, c, (bf16_t*)out, imgs, C,
+                     shuffle, pad);
   GR_CHECK_LAUNCH();
   return GR_OK;
 }

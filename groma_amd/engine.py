@@ -190,25 +190,23 @@ class RegionEngine:
         for l in range(3):
             a = ops.upsample_coord_pack(hidden3[l], G, S[l], w["Cpad"])
             maps.append(ops.gemm(a, w["in_w"][l], bias=w["in_b"][l], out=ws.get(f"reg_in{l}", (bs * S[l] * S[l], D), BF16)))
-        gamma = beta = None
         for r in range(rc.num_fuse):
-            new_maps, new_sums = [], []
+            new_maps, new_coef = [], []
             for l in range(3):
                 top, dow = min(l + 1, 2), max(l - 1, 0)
                 pad = ws.get(f"reg_pad{l}", (bs, S[l] + 2, S[l] + 2, D), BF16)
                 ops.fuse_shuffle((maps[l], sums[l], S[l]), (maps[top], sums[top], S[top]), (maps[dow], sums[dow], S[dow]),
-                                 gamma, beta, pad, imgs=bs, C=D, groups=rc.gn_groups, eps=1e-5, shuffle=True, pad=1)
+                                 pad, imgs=bs, C=D, shuffle=True, pad=1)
                 out = ws.get(f"reg_conv{l}_{r & 1}", (bs * S[l] * S[l], D), BF16)
                 ops.gemm(pad, w["fuse"][r]["w"], conv=(bs, S[l], S[l], D, 0), out=out)
                 new_maps.append(out)
-                new_sums.append(ops.gn_stats(out, bs, S[l] * S[l], D))
-            maps, sums = new_maps, new_sums
-            gamma, beta = w["fuse"][r]["g"], w["fuse"][r]["b"]
+                # GN of THIS round's conv (fuse_convs[r].gn), applied where the map is consumed next
+                new_coef.append(ops.gn_coef(out, bs, S[l] * S[l], D, rc.gn_groups, w["fuse"][r]["g"], w["fuse"][r]["b"], 1e-5))
+            maps, sums = new_maps, new_coef
         feats = []
         for l in range(3):
             f = ws.get(f"reg_feat{l}", (bs, S[l], S[l], D), BF16)
-            ops.fuse_shuffle((maps[l], sums[l], S[l]), None, None, gamma, beta, f, imgs=bs, C=D, groups=rc.gn_groups,
-                             eps=1e-5, shuffle=False, pad=0)
+            ops.fuse_shuffle((maps[l], sums[l], S[l]), None, None, f, imgs=bs, C=D, shuffle=False, pad=0)
             feats.append(f)
         return feats, S
 

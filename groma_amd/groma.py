@@ -94,6 +94,19 @@ class GromaModel:
         self.llm = engine.LlamaEngine(weights.pack_llm(source, cfg), cfg, self._ws)
         self._loaded = True
 
+    def _side_stream(self):
+        if getattr(self, "_side", None) is None:
+            self._side = torch.cuda.Stream(device=self.device)
+        return self._side
+
+    def _scratch_cache(self, bs, L):
+        c = getattr(self, "_kv_scratch", None)
+        if c is None or c.bs != bs or c.smax < L:
+            c = self.llm.new_cache(bs, L, self.device)
+            self._kv_scratch = c
+        c.seq_len = 0
+        return c
+
     @classmethod
     def from_state_dict(cls, config, state_dict, device="cuda"):
         return cls(config, weights.Source.from_state_dict(state_dict, torch.device(device)), device)
@@ -166,10 +179,15 @@ class GromaModel:
     def perceive(self, images, refer_boxes=None, ground_boxes=None, debug=None):
         """Steps A-E (groma.py:218-280): ViT -> proposer -> NMS -> shuffle.  Returns (hidden4, selected_boxes list of
         device f32 [N_i,4], aux dict)."""
-        cfg = self.config
         images = images.to(device=self.device, dtype=F32).contiguous()
-        bs = images.shape[0]
         hidden4 = self.vit.forward(images)
+        selected, aux = self.propose(hidden4, refer_boxes, ground_boxes, debug)
+        return hidden4, selected, aux
+
+    def propose(self, hidden4, refer_boxes=None, ground_boxes=None, debug=None):
+        """Steps C-E: DDETR proposer -> fused scores -> on-device NMS -> host randperm (one D2H of <1 KB/image)."""
+        cfg = self.config
+        bs = hidden4[0].shape[0]
         pred_boxes, scores, topk_idx = self.proposer.forward(hidden4, debug=debug)
         Q = pred_boxes.shape[1]
         dev = self.device
@@ -208,7 +226,7 @@ class GromaModel:
             selected.append(boxes_all[i].index_select(0, inds.to(dev)))
         aux = dict(pred_boxes=pred_boxes, scores=scores, topk_idx=topk_idx, nms_keep=[keep_h[i, :int(n_keep_h[i])] for i in range(bs)],
                    sel_idx=sel_idx)
-        return hidden4, selected, aux
+        return selected, aux
 
     def _splice(self, input_ids_h, n_img_tok, n_reg):
         """groma.py:317-357 on the host (index bookkeeping only)."""
@@ -240,7 +258,22 @@ class GromaModel:
         vis_outputs = None
         with torch.no_grad():
             if past_key_values is None:
-                hidden4, selected_boxes, aux = self.perceive(images, refer_boxes, ground_boxes)
+                images = images.to(device=dev, dtype=F32).contiguous()
+                hidden4 = self.vit.forward(images)
+                # Two HIP streams: the region-encoder pyramid (5 rounds of MFMA-bound 3x3 convs) and the bridge MLP only
+                # need the ViT states, so they run beside the launch-latency-bound fp32 proposer + NMS + host sync.
+                main = torch.cuda.current_stream()
+                side = self._side_stream()
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    feats, S = self.region.fuse(hidden4[-3:])
+                    last = hidden4[self.config.perceiver_cfg.vis_output_layer]
+                    s2d = ops.s2d_pack(last, self.vit.G)
+                    mid = ops.gemm(s2d, self.bridge["w0"], bias=self.bridge["b0"], act=1)
+                    image_features = ops.gemm(mid, self.bridge["w2"], bias=self.bridge["b2"], out_f32=True)
+                    image_features.record_stream(main)
+                selected_boxes, aux = self.propose(hidden4, refer_boxes, ground_boxes)
+                main.wait_stream(side)
                 bs = len(selected_boxes)
                 ids_h = input_ids.cpu()
                 # replace <refer_box>/<ground_box> placeholders by matched <r_k> ids (groma.py:283-309), in place
@@ -267,17 +300,11 @@ class GromaModel:
                 if input_ids.is_cuda and need_boxes:
                     input_ids.copy_(ids_h)  # the reference mutates the caller's input_ids (groma.py:295,307)
                 # region tokens (groma.py:312-315)
-                feats, S = self.region.fuse(hidden4[-3:])
                 n_reg = [b.shape[0] for b in selected_boxes]
                 boxes_cat = torch.cat(selected_boxes).contiguous()
                 img_idx = torch.cat([torch.full((n,), float(i)) for i, n in enumerate(n_reg)]).to(dev)
                 region_features = self.region.extract(feats, S, boxes_cat, img_idx)  # f32 [R, T]
-                # image tokens (groma.py:224-237, :361)
-                last = hidden4[self.config.perceiver_cfg.vis_output_layer]
-                s2d = ops.s2d_pack(last, self.vit.G)
-                n_img_tok = (self.vit.G // 2) ** 2
-                mid = ops.gemm(s2d, self.bridge["w0"], bias=self.bridge["b0"], act=1)
-                image_features = ops.gemm(mid, self.bridge["w2"], bias=self.bridge["b2"], out_f32=True)
+                n_img_tok = (self.vit.G // 2) ** 2  # image tokens: groma.py:224-237, :361 (computed on the side stream)
                 # splice placeholders, embed, inject (groma.py:317-369)
                 new_ids_h, mask_h = self._splice(ids_h, n_img_tok, n_reg)
                 if labels is not None:
@@ -302,7 +329,10 @@ class GromaModel:
                                      ref_rows.to(I32).to(dev), emb)
                 attention_mask = mask_h.to(dev)
                 kv_len = mask_h.sum(-1).to(I32).to(dev) if not bool(mask_h.all()) else None
-                cache = self.llm.new_cache(bs, L + max(int(_reserve), 0), dev)
+                if use_cache or _reserve:
+                    cache = self.llm.new_cache(bs, L + max(int(_reserve), 0), dev)
+                else:  # no cache requested: recycle one scratch KV buffer instead of zero-filling 2x32 tensors per call
+                    cache = self._scratch_cache(bs, L)
                 vis_outputs = {'pred_boxes': selected_boxes,
                                'image_features': image_features.view(bs, n_img_tok, -1),
                                'region_features': region_features}

@@ -32,7 +32,7 @@ def _chk(t, dtype, name):
 
 
 def gemm(a, w, *, out=None, bias=None, scale=None, resid=None, act=0, out_f32=False, splits=1, ws=None,
-         M=None, lda=None, conv=None, resid_mod=0, row_map=None, ldc=None, ldr=None):
+         M=None, lda=None, conv=None, resid_mod=0, row_map=None, ldc=None, ldr=None, tile=0):
     """out[M,N] = epilogue(a[M,K] @ w[N,K]^T).  `conv=(imgs,H,W,C,seg_stride)` switches A to the implicit
     3x3 gather over zero-bordered NHWC maps (then M = imgs*H*W, K = w.shape[1])."""
     lib = _lib.load()
@@ -67,6 +67,7 @@ def gemm(a, w, *, out=None, bias=None, scale=None, resid=None, act=0, out_f32=Fa
     d.ldr = ldr if ldr is not None else (resid.shape[-1] if resid is not None else 0)
     d.act, d.out_f32, d.splits = act, int(out_f32), splits
     d.resid_mod = resid_mod
+    d.tile = tile
     if row_map is not None:
         d.c_group, d.c_group_stride, d.c_row_off = row_map
     _lib.check(lib.gr_gemm_bf16(ctypes.byref(d), _stream()), "gr_gemm_bf16")
@@ -174,20 +175,24 @@ def upsample_coord_pack(h, G, Ho, Cpad):
     return out
 
 
-def gn_stats(x, imgs, HW, C):
+def gn_coef(x, imgs, HW, C, groups, gamma, beta, eps):
+    """GroupNorm statistics of a conv output x bf16 [imgs*HW, C] -> per-(image, channel) affine y = x*a + b,
+    f32 [imgs, 2, C] (consumed by fuse_shuffle)."""
     lib = _lib.load()
     sums = torch.zeros((imgs, C, 2), dtype=F32, device=x.device)
     _lib.check(lib.gr_gn_stats(_p(x), _p(sums), imgs, HW, C, _stream()), "gr_gn_stats")
-    return sums
+    coef = torch.empty((imgs, 2, C), dtype=F32, device=x.device)
+    _lib.check(lib.gr_gn_finalize(_p(sums), _p(gamma), _p(beta), _p(coef), imgs, HW, C, groups, eps, _stream()),
+               "gr_gn_finalize")
+    return coef
 
 
-def fuse_shuffle(tar, top, down, gamma, beta, out, *, imgs, C, groups, eps, shuffle, pad):
-    """each of tar/top/down = (map bf16 [imgs*S*S, C], sums or None, S)"""
+def fuse_shuffle(tar, top, down, out, *, imgs, C, shuffle, pad):
+    """each of tar/top/down = (map bf16 [imgs*S*S, C], coef or None, S)"""
     lib = _lib.load()
     t, tp, dn = tar, top or (None, None, 0), down or (None, None, 0)
     _lib.check(lib.gr_fuse_shuffle(_p(t[0]), _p(t[1]), t[2], _p(tp[0]), _p(tp[1]), tp[2], _p(dn[0]), _p(dn[1]), dn[2],
-                                   _p(gamma), _p(beta), _p(out), imgs, C, groups, eps, int(shuffle), pad, _stream()),
-               "gr_fuse_shuffle")
+                                   _p(out), imgs, C, int(shuffle), pad, _stream()), "gr_fuse_shuffle")
     return out
 
 
@@ -312,3 +317,15 @@ def prof_read():
     ms, n, fl = ctypes.c_double(), ctypes.c_long(), ctypes.c_double()
     _lib.check(_lib.load().gr_prof_read(ctypes.byref(ms), ctypes.byref(n), ctypes.byref(fl)), "gr_prof_read")
     return ms.value, n.value, fl.value
+
+
+def prof_read_launches(cap=65536):
+    """-> list of (M, N, K, tag, ms) per gr_gemm_bf16 launch since prof_enable(True) (drains the records)"""
+    import numpy as np
+    mnk = np.zeros((cap, 4), dtype=np.int32)
+    ms = np.zeros((cap,), dtype=np.float32)
+    n = ctypes.c_long()
+    _lib.check(_lib.load().gr_prof_read_launches(cap, mnk.ctypes.data, ms.ctypes.data, ctypes.byref(n)),
+               "gr_prof_read_launches")
+    k = min(n.value, cap)
+    return [(int(mnk[i, 0]), int(mnk[i, 1]), int(mnk[i, 2]), int(mnk[i, 3]), float(ms[i])) for i in range(k)]

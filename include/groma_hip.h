@@ -32,6 +32,7 @@ int gr_abi_version(void);
  * events on its own stream; gr_prof_read drains them (sync) and returns total ms + launch count. */
 int gr_prof_enable(int on);
 int gr_prof_read(double* total_ms, long* launches, double* flops);
+int gr_prof_read_launches(long cap, int* mnk, float* ms, long* n_out);
 
 /* ------------------------------------------------------------------ dense contractions (MFMA) -- */
 /* C[M,N] = epilogue(A[M,K] . W[N,K]^T).  Replaces every nn.Linear / nn.Conv2d on the path:
@@ -59,6 +60,7 @@ typedef struct gr_gemm_desc {
   int resid_mod;      /* > 0: residual row = m % resid_mod (position-embedding broadcast)          */
   /* output row remap: row(m) = (m / c_group)*c_group_stride + c_row_off + m % c_group (c_group > 0) */
   int c_group, c_group_stride, c_row_off;
+  int tile;           /* 0 = choose per shape; 128 / 256 force the 128x128 / 256x256 kernel          */
 } gr_gemm_desc;
 int gr_gemm_bf16(const gr_gemm_desc* d, hipStream_t stream);
 
@@ -92,9 +94,11 @@ int gr_mean4_tokens(const float* h0, const float* h1, const float* h2, const flo
 int gr_s2d_pack(const float* h, void* out, int B, int G, int C, hipStream_t stream);
 int gr_upsample_coord_pack(const float* h, void* out, int B, int G, int Ho, int C, int Cpad, hipStream_t stream);
 int gr_gn_stats(const void* x, float* sums, int imgs, int HW, int C, hipStream_t stream);
-int gr_fuse_shuffle(const void* tar, const float* tar_sums, int tarS, const void* top, const float* top_sums, int topS,
-                    const void* down, const float* down_sums, int downS, const float* gamma, const float* beta, void* out,
-                    int imgs, int C, int groups, float eps, int shuffle, int pad, hipStream_t stream);
+int gr_gn_finalize(const float* sums, const float* gamma, const float* beta, float* coef, int imgs, int HW, int C,
+                   int groups, float eps, hipStream_t stream);
+int gr_fuse_shuffle(const void* tar, const float* tar_coef, int tarS, const void* top, const float* top_coef, int topS,
+                    const void* down, const float* down_coef, int downS, void* out, int imgs, int C, int shuffle, int pad,
+                    hipStream_t stream);
 int gr_cast_f32_bf16(const float* a, const float* b, void* out, long n, hipStream_t stream);
 int gr_add_rows_f32(const float* a, const float* b, float* out, long rows, int C, int b_mod, hipStream_t stream);
 int gr_embed_gather(const long* ids, const void* table0, const void* table1, float* out, long n, int C, int V0, int V1,

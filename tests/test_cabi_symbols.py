@@ -1,0 +1,48 @@
+"""The C-ABI library loads and exports every symbol include/groma_hip.h declares (no compute calls: CPU suite)."""
+import ctypes
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    src = open(os.path.join(ROOT, "include", "groma_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\bint\s+(gr_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_symbols_are_exported_and_typed():
+    import __graft_entry__ as g
+    g.build()
+    from groma_amd import _lib
+    names = _declared()
+    assert len(names) >= 25
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/groma_hip.h but not exported"
+    assert set(names) == set(_lib.SIGNATURES), "ctypes signature table out of sync with the header"
+    assert _lib.load().gr_abi_version() == 1
+
+
+def test_bad_arguments_are_rejected_without_a_gpu():
+    """argument validation happens before any launch: EINVAL (22), never a crash"""
+    from groma_amd import _lib
+    lib = _lib.load()
+    assert lib.gr_gemm_bf16(None, None) == 22
+    d = _lib.GemmDesc()
+    assert lib.gr_gemm_bf16(ctypes.byref(d), None) == 22
+    assert lib.gr_topk_desc(None, None, 1, 10, 5, 10, None) == 22
+    assert lib.gr_nms_f32(None, None, 1, 10, 0.5, 0.0, 10, None, None, None, None) == 22
+    assert lib.gr_roi_align_pack(None, None, None, 0, 8, 4, 4, 14, 14, 1.0, 2, 1, 1, 0, None) == 0  # empty ROI set is fine
+    assert lib.gr_roi_align_pack(None, None, None, 3, 8, 4, 4, 14, 14, 1.0, 2, 1, 1, 0, None) == 22
+    assert lib.gr_attention_bf16(None, None, None, None, None, 1, 1, 1, 1, 64, 64, 0, 0, 1.0, None) == 22
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    from groma_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libgroma_hip.so")
+    import pytest
+    with pytest.raises(RuntimeError, match="no CPU / eager fallback"):
+        _lib.load()

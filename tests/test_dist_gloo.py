@@ -1,0 +1,37 @@
+"""world_size-2 gloo run of the multi-GPU exchange step used by bench.py: shard, compute locally,
+one all-gather of the per-image rows."""
+import os
+
+import torch
+import torch.multiprocessing as mp
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    from groma_amd import dist as gdist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    B = 5  # ragged: rank 0 gets 3 images, rank 1 gets 2
+    lo, hi = gdist.shard_range(B, world, rank)
+    full = torch.arange(B * 100, dtype=torch.float32).view(B, 100)
+    local = full[lo:hi] * 2.0  # "forward" of the local shard
+    counts = [gdist.shard_range(B, world, r)[1] - gdist.shard_range(B, world, r)[0] for r in range(world)]
+    got = gdist.all_gather_rows(local, counts)
+    even = gdist.all_gather_rows(torch.full((2, 4), float(rank)))
+    q.put((rank, torch.equal(got, full * 2.0), even[:, 0].tolist()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_shard_and_all_gather_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29650 + os.getpid() % 200
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(2)]
+    for p in procs:
+        p.join(60)
+    assert all(ok for _, ok, _ in res)
+    assert all(ev == [0.0, 0.0, 1.0, 1.0] for _, _, ev in res)

@@ -1,0 +1,110 @@
+"""Host-side logic of the drop-in boundary (no GPU): configs, token table, synthetic spec, placeholder splice,
+KV-cache view contract, flop model, shard arithmetic."""
+import os
+
+import torch
+
+from groma_amd import config as gconfig
+from groma_amd import constants, synth
+from groma_amd.dist import shard_range
+from oracle import groma_oracle as O
+from tests import util
+
+
+def test_token_table_matches_survey():
+    ids = constants.derived_token_ids()
+    assert ids["[PAD]"] == 32000 and ids["<image>"] == 32008 and ids["<region>"] == 32009
+    assert ids["<refer_box>"] == 32010 and ids["<ground_box>"] == 32011 and ids["<refer_feat>"] == 32012
+    assert ids["<r0>"] == 32014 and ids["<r99>"] == 32113
+    assert len(constants.SyntheticTokenizer()) == 32114
+
+
+def test_config_roundtrip(tmp_path):
+    cfg = gconfig.groma_7b(box_score_thres=0.0)
+    assert cfg.vocab_size == 32114 and cfg.llm_cfg.hidden_size == 4096
+    assert cfg.perceiver_cfg.ddetr_cfg.two_stage_num_proposals == 300
+    cfg.save_pretrained(tmp_path)
+    back = gconfig.GromaConfig.from_pretrained(tmp_path)
+    assert back.to_dict() == cfg.to_dict()
+    cfg.box_score_thres = 0.3  # mutable like the reference (eval_rec.py:71)
+    assert cfg.box_score_thres == 0.3
+
+
+def test_param_spec_uses_reference_names():
+    names = {n for n, _, _ in synth.param_spec(gconfig.groma_tiny())}
+    for n in ["perceiver.vis_encoder.embeddings.position_embeddings",
+              "perceiver.vis_encoder.encoder.layer.0.attention.attention.query.weight",
+              "perceiver.input_proj.0.0.weight", "perceiver.input_proj.0.1.bias",
+              "perceiver.ddetr_transformer.encoder.layers.0.self_attn.sampling_offsets.weight",
+              "perceiver.ddetr_transformer.decoder.layers.1.self_attn.out_proj.weight",
+              "perceiver.ddetr_transformer.decoder.layers.0.encoder_attn.value_proj.bias",
+              "perceiver.ddetr_transformer.level_embed", "perceiver.ddetr_transformer.query_position_embeddings.weight",
+              "perceiver.ddetr_transformer.class_embed_coco.1.weight", "perceiver.ddetr_transformer.bbox_embed.2.layers.2.bias",
+              "llm.model.layers.1.mlp.gate_proj.weight", "llm.lm_head.weight", "img_txt_bridge.2.weight",
+              "region_encoder.mlvl_fuse.input_conv.2.weight", "region_encoder.mlvl_fuse.fuse_convs.1.gn.weight",
+              "region_encoder.roi_align.pconvs.0.bias", "region_encoder.roi_align.pos_embedd.5.weight",
+              "region_encoder.roi_align.flatten_linear.weight", "extra_lm_head.weight", "new_input_embs.weight"]:
+        assert n in names, n
+    import math
+    n7 = sum(math.prod(s) for _, s, _ in synth.param_spec(gconfig.groma_7b()))
+    assert 7.3e9 < n7 < 7.5e9
+
+
+def test_splice_matches_oracle_including_padding_and_ragged_regions():
+    from groma_amd.groma import GromaModel
+    cfg = gconfig.groma_tiny()
+    m = GromaModel(cfg)  # no weights needed for host logic
+    m.init_special_token_id(constants.SyntheticTokenizer())
+    tk = util.TokenIds()
+    _, ids = synth.make_inputs(cfg, tk, 3, seed=3, prompt_len=40, k1=5, k2=3)
+    ids[1, -6:] = tk.pad_token_id
+    n_reg = [100, 1, 37]
+    got_ids, got_mask = m._splice(ids, 256, n_reg)
+    exp_ids, exp_mask = O.splice_placeholders(ids, 256, n_reg, util.tok_dict(tk))
+    assert torch.equal(got_ids, exp_ids) and torch.equal(got_mask, exp_mask)
+    assert got_ids.shape[1] == 40 - 2 + 256 + 200
+    import pytest
+    bad = ids.clone()
+    bad[0][bad[0] == tk.img_token_id] = 5
+    with pytest.raises(AssertionError):
+        m._splice(bad, 256, n_reg)
+
+
+def test_prepare_inputs_for_generation_contract():
+    from groma_amd.groma import GromaModel
+    m = GromaModel(gconfig.groma_tiny())
+    ids = torch.arange(12).view(2, 6)
+    a = m.prepare_inputs_for_generation(ids, images="img", use_cache=True)
+    assert a["input_ids"] is ids and a["images"] == "img" and a["past_key_values"] is None
+    b = m.prepare_inputs_for_generation(ids, past_key_values=[1], use_cache=True)
+    assert b["input_ids"].shape == (2, 1)
+    import pytest
+    with pytest.raises(RuntimeError, match="no weights"):
+        m.forward(input_ids=ids)
+
+
+def test_kv_cache_legacy_view():
+    from groma_amd.engine import KVCache
+    c = KVCache(2, 3, 4, 128, 64, "cpu")
+    c.seq_len = 10
+    assert tuple(c[0][0].shape) == (3, 4, 10, 128) and tuple(c[1][1].shape) == (3, 4, 10, 128)
+    assert len(c) == 2 and bool(c)
+    c.k[0][:, :, 5] = 1
+    c.grow(128)
+    assert c.smax == 128 and c.k[0].shape[2] == 128 and c.k[0][0, 0, 5, 0] == 1 and c.vt[0].shape[3] == 128
+
+
+def test_flop_model_matches_survey_totals():
+    import bench
+    f = bench.flops_per_image(gconfig.groma_7b(), 100, 128)
+    assert f["L"] == 582
+    assert abs(f["vit"] / 1e9 - 723.6) < 8 and abs(f["llm"] / 1e9 - 7868.8) < 40
+    assert abs(f["region"] / 1e9 - 3226.4) < 40 and abs(f["total"] / 1e9 - 11850) < 120
+
+
+def test_shard_range_covers_batch():
+    for B in (1, 7, 32):
+        for W in (1, 2, 4, 8):
+            spans = [shard_range(B, W, r) for r in range(W)]
+            assert spans[0][0] == 0 and spans[-1][1] == B
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(W - 1))

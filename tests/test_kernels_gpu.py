@@ -25,9 +25,10 @@ def relerr(a, b):
     return ((a - b).norm() / b.norm().clamp_min(1e-12)).item()
 
 
+@pytest.mark.parametrize("tile", [128, 256])
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 512), (582, 4096, 1024), (100, 260, 192), (1, 128, 4096),
-                                   (1025, 3072, 1024)])
-def test_gemm_plain(dev, M, N, K):
+                                   (1025, 3072, 1024), (700, 520, 128), (2328, 1024, 2048)])
+def test_gemm_plain(dev, M, N, K, tile):
     ops = _ops()
     a = rnd((M, K), dev, seed=1).bfloat16()
     w = rnd((N, K), dev, seed=2).bfloat16()
@@ -35,15 +36,20 @@ def test_gemm_plain(dev, M, N, K):
     a[:, 0] += 3.0
     w[0, :] -= 2.0
     ref = a.float() @ w.float().t()
-    out = ops.gemm(a, w, out_f32=True)
+    out = ops.gemm(a, w, out_f32=True, tile=tile)
     assert out.shape == (M, N)
     assert relerr(out, ref) < 1e-5
-    out16 = ops.gemm(a, w)
+    out16 = ops.gemm(a, w, tile=tile)
     assert relerr(out16, ref) < 4e-3
+    # the two kernels accumulate in the same k order per output element -> bitwise equal fp32 results
+    assert torch.equal(out, ops.gemm(a, w, out_f32=True, tile=384 - tile))
 
 
-def test_gemm_epilogues(dev):
+@pytest.mark.parametrize("tile", [128, 256])
+def test_gemm_epilogues(dev, tile):
+    import functools
     ops = _ops()
+    ops = type("O", (), {"gemm": staticmethod(functools.partial(ops.gemm, tile=tile))})
     M, N, K = 300, 512, 256
     a = rnd((M, K), dev, seed=1).bfloat16()
     w = rnd((N, K), dev, 0.1, seed=2).bfloat16()
@@ -74,8 +80,9 @@ def test_gemm_epilogues(dev):
     assert buf.view(3, 101, N)[:, 0].abs().max().item() == 0.0
 
 
+@pytest.mark.parametrize("tile", [128, 256])
 @pytest.mark.parametrize("imgs,H,C,Cout,segs", [(2, 16, 64, 128, 1), (1, 32, 128, 64, 1), (3, 14, 64, 64, 3)])
-def test_gemm_conv3x3(dev, imgs, H, C, Cout, segs):
+def test_gemm_conv3x3(dev, imgs, H, C, Cout, segs, tile):
     ops = _ops()
     xs = [rnd((imgs, C, H, H), dev, seed=10 + s).bfloat16() for s in range(segs)]
     ws = [rnd((Cout, C, 3, 3), dev, 0.1, seed=20 + s).bfloat16() for s in range(segs)]
@@ -86,7 +93,7 @@ def test_gemm_conv3x3(dev, imgs, H, C, Cout, segs):
         pad[s, :, 1:-1, 1:-1] = xs[s].permute(0, 2, 3, 1)
     # weight [Cout, segs*9*C], k = (s*9 + ky*3+kx)*C + c
     wk = torch.cat([w.permute(0, 2, 3, 1).reshape(Cout, 9 * C) for w in ws], dim=1).contiguous()
-    out = ops.gemm(pad, wk, conv=(imgs, H, H, C, imgs * (H + 2) * (H + 2) * C), out_f32=True)
+    out = ops.gemm(pad, wk, conv=(imgs, H, H, C, imgs * (H + 2) * (H + 2) * C), out_f32=True, tile=tile)
     assert relerr(out, ref) < 1e-5
 
 
@@ -225,7 +232,7 @@ def test_gn_shuffle(dev):
     xs = [rnd((imgs, C, s, s), dev, 1.5, seed=30 + i).bfloat16() for i, s in enumerate(S)]
     gamma, beta = rnd((C,), dev, seed=1), rnd((C,), dev, seed=2)
     flat = [x.permute(0, 2, 3, 1).reshape(-1, C).contiguous() for x in xs]
-    sums = [ops.gn_stats(f, imgs, s * s, C) for f, s in zip(flat, S)]
+    coef = [ops.gn_coef(f, imgs, s * s, C, groups, gamma, beta, 1e-5) for f, s in zip(flat, S)]
     act = [F.relu(F.group_norm(x.float(), groups, gamma, beta, 1e-5)) for x in xs]
     rc, sh = C // 2, C // 4
     for lvl in range(3):
@@ -236,14 +243,13 @@ def test_gn_shuffle(dev):
             fd = F.interpolate(src[dow][:, rc:][:, :sh], size=(S[lvl], S[lvl]), mode="bilinear", align_corners=True)
             ref = torch.cat([src[lvl][:, :rc], ft, fd], 1).permute(0, 2, 3, 1)
             out = torch.zeros((imgs, S[lvl] + 2, S[lvl] + 2, C), dtype=torch.bfloat16, device=dev)
-            sm = sums if normed else [None] * 3
-            ops.fuse_shuffle((flat[lvl], sm[lvl], S[lvl]), (flat[top], sm[top], S[top]), (flat[dow], sm[dow], S[dow]),
-                             gamma, beta, out, imgs=imgs, C=C, groups=groups, eps=1e-5, shuffle=True, pad=1)
+            cf = coef if normed else [None] * 3
+            ops.fuse_shuffle((flat[lvl], cf[lvl], S[lvl]), (flat[top], cf[top], S[top]), (flat[dow], cf[dow], S[dow]),
+                             out, imgs=imgs, C=C, shuffle=True, pad=1)
             assert relerr(out[:, 1:-1, 1:-1], ref) < 6e-3, (lvl, normed)
             assert out[:, 0].abs().max().item() == 0 and out[:, :, -1].abs().max().item() == 0
     out = torch.zeros((imgs, S[0], S[0], C), dtype=torch.bfloat16, device=dev)
-    ops.fuse_shuffle((flat[0], sums[0], S[0]), None, None, gamma, beta, out, imgs=imgs, C=C, groups=groups, eps=1e-5,
-                     shuffle=False, pad=0)
+    ops.fuse_shuffle((flat[0], coef[0], S[0]), None, None, out, imgs=imgs, C=C, shuffle=False, pad=0)
     assert relerr(out, act[0].permute(0, 2, 3, 1)) < 6e-3
 
 
