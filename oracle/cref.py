@@ -51,3 +51,46 @@ def roi_align_avg(inp_nchw, rois, pooled, spatial_scale, sampling_ratio, aligned
         _load().oracle_roi_align_avg(x.ctypes.data, r.ctypes.data, out.ctypes.data, r.shape[0], C, H, W, ph, pw,
                                      float(spatial_scale), int(sampling_ratio), int(bool(aligned)))
     return out
+
+
+# ---- the reference's own CPU ops (oracle/_ref/libmmcv_ref.so, built by oracle/build_ref.py from /root/reference) ----
+_REF = os.path.join(_HERE, "_ref", "libmmcv_ref.so")
+_ref = None
+
+
+def ref_available():
+    return os.path.exists(_REF)
+
+
+def _load_ref():
+    global _ref
+    if _ref is None:
+        import torch  # noqa: F401  (libtorch must be loaded first)
+        _ref = ctypes.CDLL(_REF)
+        _ref.ref_nms.restype = ctypes.c_int
+        _ref.ref_nms.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_int, ctypes.c_void_p]
+        _ref.ref_roi_align_avg.restype = ctypes.c_int
+        _ref.ref_roi_align_avg.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_int] * 7 + [ctypes.c_float, ctypes.c_int, ctypes.c_int]
+    return _ref
+
+
+def ref_nms(boxes_xyxy, scores, iou_threshold, offset=0):
+    """mmcv `_ext.nms` (CPU) itself -- note: its sort is unstable, compare on tie-free scores"""
+    b = np.ascontiguousarray(boxes_xyxy, dtype=np.float32).reshape(-1, 4)
+    s = np.ascontiguousarray(scores, dtype=np.float32).reshape(-1)
+    keep = np.empty((max(len(s), 1),), dtype=np.int64)
+    k = _load_ref().ref_nms(b.ctypes.data, s.ctypes.data, len(s), float(iou_threshold), int(offset), keep.ctypes.data)
+    if k < 0:
+        raise RuntimeError("reference nms raised")
+    return keep[:k].copy()
+
+
+def ref_roi_align_avg(inp_nchw, rois, pooled, spatial_scale, sampling_ratio, aligned=True):
+    """mmcv `_ext.roi_align_forward` (CPU) itself; returns None when the reference asserts (negative-width ROI)"""
+    x = np.ascontiguousarray(inp_nchw, dtype=np.float32)
+    r = np.ascontiguousarray(rois, dtype=np.float32).reshape(-1, 5)
+    N, C, H, W = x.shape
+    out = np.zeros((r.shape[0], C, pooled[0], pooled[1]), dtype=np.float32)
+    rc = _load_ref().ref_roi_align_avg(x.ctypes.data, r.ctypes.data, out.ctypes.data, N, C, H, W, r.shape[0], pooled[0],
+                                       pooled[1], float(spatial_scale), int(sampling_ratio), int(bool(aligned)))
+    return out if rc == 0 else None
