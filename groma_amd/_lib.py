@@ -7,7 +7,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libgroma_hip.so")
+LIB_PATH = os.environ.get("GROMA_HIP_LIB") or os.path.join(_HERE, "csrc", "libgroma_hip.so")  # override: A/B builds
 
 c_void_p = ctypes.c_void_p
 c_int = ctypes.c_int

@@ -111,15 +111,30 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16_kernel(GemmArgs p) {
     }
   }
 
-  // ---- epilogue: lane holds n = nb + fg*4 + {0..3}, m = mb + fr ----
+  // ---- epilogue through LDS (coalesced; see gemm_common.h) ----
+  __syncthreads();  // every wave is done reading the last K-tile
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int m = m0 + wm * 64 + i * 16 + fr;
-    if (m >= p.M) continue;
+  for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int n = n0 + wn * 64 + j * 16 + fg * 4;
-      if (n < p.N) epi_store(p, acc[j][i], m, n, z);
+    for (int j = 0; j < 4; ++j) stage_write4<BN>(smem, wm * 64 + i * 16 + fr, wn * 16 + j * 4 + fg, acc[j][i]);
+  __syncthreads();
+  if (p.act == 3) {
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int idx = it * NTHREADS + tid;
+      epi_from_stage<BN, 4>(p, smem, idx >> 3, (idx & 7) * 4, m0 + (idx >> 3), n0, z);
+    }
+  } else if (!p.out_f32 && p.splits == 1) {
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int idx = it * NTHREADS + tid;
+      epi_from_stage<BN, 2>(p, smem, idx >> 4, (idx & 15) * 2, m0 + (idx >> 4), n0, z);
+    }
+  } else {
+#pragma unroll
+    for (int it = 0; it < 16; ++it) {
+      const int idx = it * NTHREADS + tid;
+      epi_from_stage<BN, 1>(p, smem, idx >> 5, idx & 31, m0 + (idx >> 5), n0, z);
     }
   }
 }

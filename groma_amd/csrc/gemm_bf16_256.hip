@@ -14,11 +14,13 @@
 //  * LDS = 2 stages x (A 256x64 + B 256x64) bf16 = 128 KB.  Each stage is four 16 KB "half-tiles"
 //    {A0, B0, B1, A1} (the rows every wave needs for that fragment).  One half-tile (2 x global_load_lds_dwordx4 per
 //    lane) is issued per phase, in the order its LDS region becomes dead:
-//        phase 0 of tile t: A1(t+1)   phase 1: A0(t+2)   phase 2: B0(t+2)   phase 3: B1(t+2)
-//    so every half-tile has >= 6 phases of flight time, and ONE counted wait  s_waitcnt vmcnt(8)  at the top of each
-//    phase (4 younger half-tiles may stay in flight) retires exactly the half-tile read in the NEXT phase; the
-//    barrier that ends the phase publishes it to the other waves.  LDS reads are waited (lgkmcnt(0)) before that
-//    barrier, so a region is overwritten only >= 1 barrier after its last reader finished (both groups).
+//        phase 0 of tile t: A1(t+1)   phase 1: B1(t+1)   phase 2: A0(t+2)   phase 3: B0(t+2)
+//    -- every region is re-staged >= 2 phases after its last ds_read (so the reads' lgkmcnt wait can sit after the
+//    barrier) and every half-tile has 4-6 phases of flight time.  Counted waits retire exactly the half-tile(s) read
+//    in the NEXT phase: vmcnt(4) in phase 0 (B1), vmcnt(8) in phase 1 (A1), none in phase 2, vmcnt(6) in phase 3
+//    (A0,B0 of the next tile); the barrier that ends the phase publishes them to the other waves.  The DMA queue is
+//    never drained in steady state.  Within a phase's load segment the ds_reads are issued FIRST so they complete in
+//    the shadow of the DMA wait/issue.
 //  * LDS image: 128-B rows, 16-B chunk position = k-chunk ^ (row & 7): written lane-linearly by the DMA with the
 //    XOR applied to the per-lane SOURCE address, mirrored on the ds_read_b128 side (conflict-free).
 #include "gemm_common.h"
@@ -131,22 +133,42 @@ __global__ __launch_bounds__(NT) void gemm_bf16_256_kernel(GemmArgs p) {
   const int a_lane = (wm * 128 + fr) * 128;
   const int b_lane = B_OFF + (wn * 64 + fr) * 128;
 
-  // ---- prologue: A0(0) B0(0) B1(0) A1(0) A0(1) B0(1) B1(1)
-  issue(HT_A0, 0); issue(HT_B0, 0); issue(HT_B1, 0); issue(HT_A1, 0);
-  issue(HT_A0, 1); issue(HT_B0, 1); issue(HT_B1, 1);
-  if (nt >= 2) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");  // A0(0), B0(0) landed
+  // ---- prologue: A0(0) B0(0) A1(0) B1(0) A0(1) | wait | B0(1)
+  issue(HT_A0, 0); issue(HT_B0, 0); issue(HT_A1, 0); issue(HT_B1, 0);
+  issue(HT_A0, 1);
+  if (nt >= 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");  // A0(0), B0(0) landed
   else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  issue(HT_B0, 1);
   __builtin_amdgcn_s_barrier();
   if (wm == 1) __builtin_amdgcn_s_barrier();  // stagger the second wave group by one interval
 
   bf16x8 af[4][2], b0f[2][2], b1f[2][2];
 
+#define WAIT_VM(N)                                                      \
+  do {                                                                  \
+    if (steady) asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory");   \
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               \
+  } while (0)
+// barrier -> 16 MFMAs (A sub-block rows I0.., B sub-block cols J0.. with fragment set BF) -> barrier
+#define COMPUTE_PHASE(I0, J0, BF)                                                                         \
+  __builtin_amdgcn_sched_barrier(0);                                                                      \
+  __builtin_amdgcn_s_barrier();                                                                           \
+  __builtin_amdgcn_sched_barrier(0);                                                                      \
+  __builtin_amdgcn_s_setprio(1);                                                                          \
+  _Pragma("unroll") for (int kk = 0; kk < 2; ++kk)                                                        \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                         \
+      _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                       \
+        acc[I0 + i][J0 + j] = MFMA16(BF[j][kk], af[i][kk], acc[I0 + i][J0 + j]);                          \
+  __builtin_amdgcn_s_setprio(0);                                                                          \
+  __builtin_amdgcn_sched_barrier(0);                                                                      \
+  __builtin_amdgcn_s_barrier();                                                                           \
+  __builtin_amdgcn_sched_barrier(0);
+
   for (int t = 0; t < nt; ++t) {
     const char* st = smem + (t & 1) * STAGE_BYTES;
-    const bool steady = t + 2 < nt;  // every half-tile of the uniform schedule was really issued
-    // ================= phase 0 : reads A0,B0 ; computes A0 x B0 ; issues A1(t+1)
-    if (steady) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    issue_at(HT_A1, t + 1, aoff1);
+    const bool steady = t + 2 < nt;  // every half-tile of the schedule up to this tile's issues really exists
+    // ===== phase 0 : reads A0,B0 ; computes A0 x B0 ; issues A1(t+1) ; retires B1(t) (read in phase 1)
+    // (ds_reads first: they complete in the shadow of the DMA wait + issue, before the barrier)
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       b0f[j][0] = *(const bf16x8*)(st + b_lane + j * 2048 + off0);
@@ -157,97 +179,67 @@ __global__ __launch_bounds__(NT) void gemm_bf16_256_kernel(GemmArgs p) {
       af[i][0] = *(const bf16x8*)(st + a_lane + i * 2048 + off0);
       af[i][1] = *(const bf16x8*)(st + a_lane + i * 2048 + (off0 ^ 64));
     }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = MFMA16(b0f[j][kk], af[i][kk], acc[i][j]);
-    __builtin_amdgcn_s_setprio(0);
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-    // ================= phase 1 : reads B1 ; computes A0 x B1 ; issues A0(t+2)
-    if (steady) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    issue_at(HT_A0, t + 2, aoff2);
+    WAIT_VM(4);
+    issue_at(HT_A1, t + 1, aoff1);
+    COMPUTE_PHASE(0, 0, b0f)
+    // ===== phase 1 : reads B1 ; computes A0 x B1 ; issues B1(t+1) ; retires A1(t) (read in phase 2)
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       b1f[j][0] = *(const bf16x8*)(st + b_lane + (2 + j) * 2048 + off0);
       b1f[j][1] = *(const bf16x8*)(st + b_lane + (2 + j) * 2048 + (off0 ^ 64));
     }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][2 + j] = MFMA16(b1f[j][kk], af[i][kk], acc[i][2 + j]);
-    __builtin_amdgcn_s_setprio(0);
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-    // ================= phase 2 : reads A1 ; computes A1 x B1 ; issues B0(t+2)
-    if (steady) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    issue_at(HT_B0, t + 2, (long)(ks_begin + t + 2) * 64);
+    WAIT_VM(8);
+    issue_at(HT_B1, t + 1, (long)(ks_begin + t + 1) * 64);
+    COMPUTE_PHASE(0, 2, b1f)
+    // ===== phase 2 : reads A1 ; computes A1 x B1 ; issues A0(t+2) ; nothing to retire (phase 3 reads nothing)
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       af[i][0] = *(const bf16x8*)(st + a_lane + (4 + i) * 2048 + off0);
       af[i][1] = *(const bf16x8*)(st + a_lane + (4 + i) * 2048 + (off0 ^ 64));
     }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) acc[4 + i][2 + j] = MFMA16(b1f[j][kk], af[i][kk], acc[4 + i][2 + j]);
-    __builtin_amdgcn_s_setprio(0);
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-    // ================= phase 3 : no LDS reads ; computes A1 x B0 ; issues B1(t+2)
-    if (steady) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    issue_at(HT_B1, t + 2, (long)(ks_begin + t + 2) * 64);
+    if (!steady) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    issue_at(HT_A0, t + 2, aoff2);
+    COMPUTE_PHASE(4, 2, b1f)
+    // ===== phase 3 : no LDS reads ; computes A1 x B0 ; issues B0(t+2) ; retires A0(t+1), B0(t+1) (next phase 0)
+    WAIT_VM(6);
+    issue_at(HT_B0, t + 2, (long)(ks_begin + t + 2) * 64);
     advance();
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) acc[4 + i][j] = MFMA16(b0f[j][kk], af[i][kk], acc[4 + i][j]);
-    __builtin_amdgcn_s_setprio(0);
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
+    COMPUTE_PHASE(4, 0, b0f)
   }
   if (wm == 0) __builtin_amdgcn_s_barrier();  // re-align the groups (same barrier count for every wave)
 
-  // ---- epilogue: lane holds n = nb + fg*4 + {0..3}, m = mb + fr ----
+  // ---- epilogue through LDS in 4 passes of 64 rows (2 m-tiles per wave), double-buffered over the two stages ----
+  __syncthreads();
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int m = m0 + wm * 128 + i * 16 + fr;
-    if (m >= p.M) continue;
+  for (int q = 0; q < 4; ++q) {
+    char* buf = smem + (q & 1) * STAGE_BYTES;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int n = n0 + wn * 64 + j * 16 + fg * 4;
-      if (n < p.N) epi_store(p, acc[i][j], m, n, z);
+    for (int e = 0; e < 2; ++e)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) stage_write4<T256>(buf, wm * 32 + e * 16 + fr, wn * 16 + j * 4 + fg, acc[2 * q + e][j]);
+    __syncthreads();
+    // staged row sr -> tile row (sr>>5)*128 + q*32 + (sr&31)
+    if (p.act == 3) {
+#pragma unroll
+      for (int it = 0; it < 2; ++it) {
+        const int idx = it * NT + tid, sr = idx >> 4;
+        epi_from_stage<T256, 4>(p, buf, sr, (idx & 15) * 4, m0 + (sr >> 5) * 128 + q * 32 + (sr & 31), n0, z);
+      }
+    } else if (!p.out_f32 && p.splits == 1) {
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int idx = it * NT + tid, sr = idx >> 5;
+        epi_from_stage<T256, 2>(p, buf, sr, (idx & 31) * 2, m0 + (sr >> 5) * 128 + q * 32 + (sr & 31), n0, z);
+      }
+    } else {
+#pragma unroll
+      for (int it = 0; it < 8; ++it) {
+        const int idx = it * NT + tid, sr = idx >> 6;
+        epi_from_stage<T256, 1>(p, buf, sr, idx & 63, m0 + (sr >> 5) * 128 + q * 32 + (sr & 31), n0, z);
+      }
     }
   }
 }

@@ -110,5 +110,90 @@ __device__ __forceinline__ void epi_store(const GemmArgs& p, f32x4 v, int m, int
   }
 }
 
+// ---- coalesced epilogue -------------------------------------------------------------------------------------
+// The MFMA accumulator layout gives each lane 4 columns of ONE row, so a direct store touches 16 rows x 32 B per
+// wave-instruction (store-issue bound: the bf16 output of a K=1024..4096 GEMM is its largest HBM stream).  Instead
+// the tile goes through LDS once (free after the K loop): accumulators are written as float4 into an XOR-swizzled
+// [rows][COLS] fp32 image (conflict-free ds_write_b128), then re-read row-contiguously so that every lane applies
+// the epilogue to 4/8/16 consecutive columns and stores 16 B, 16-32 lanes covering one full row segment.
+template <int COLS>  // fp32 columns per staged row (128 or 256)
+__device__ __forceinline__ void stage_write4(char* base, int row, int n4, f32x4 v) {
+  *(f32x4*)(base + ((long)row * COLS * 4) + (((n4 ^ (row & 7))) << 4)) = v;
+}
+template <int COLS>
+__device__ __forceinline__ f32x4 stage_read4(const char* base, int row, int n4) {
+  return *(const f32x4*)(base + ((long)row * COLS * 4) + (((n4 ^ (row & 7))) << 4));
+}
+__device__ __forceinline__ f32x4 epi_math4(const GemmArgs& p, f32x4 v, int m, long orow, int n) {
+  if (p.bias) v += *(const f32x4*)(p.bias + n);
+  if (p.act == 1 || p.act == 2) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = act_apply(v[e], p.act);
+  }
+  if (p.scale) v *= *(const f32x4*)(p.scale + n);
+  if (p.resid) {
+    const long rrow = p.resid_mod > 0 ? (long)(m % p.resid_mod) : orow;
+    v += *(const f32x4*)(p.resid + rrow * p.ldr + n);
+  }
+  return v;
+}
+// One thread's share of a staged row: W4 consecutive float4 starting at tile column c4*4 (tile-relative), row m.
+template <int COLS, int W4>
+__device__ __forceinline__ void epi_from_stage(const GemmArgs& p, const char* base, int srow, int c4, int m, int n0, int z) {
+  if (m >= p.M) return;
+  f32x4 v[W4];
+#pragma unroll
+  for (int w = 0; w < W4; ++w) v[w] = stage_read4<COLS>(base, srow, c4 + w);
+  const int n = n0 + c4 * 4;
+  if (p.splits > 1) {
+#pragma unroll
+    for (int w = 0; w < W4; ++w)
+      if (n + 4 * w < p.N) *(f32x4*)(p.ws + ((long)z * p.M + m) * p.N + n + 4 * w) = v[w];
+    return;
+  }
+  long orow = m;
+  if (p.c_group > 0) orow = (long)(m / p.c_group) * p.c_group_stride + p.c_row_off + (m % p.c_group);
+  if (p.act == 3) {  // SwiGLU over interleaved (gate, up) columns: 4*W4 fused columns -> 2*W4 outputs
+    uint32_t o[W4];
+#pragma unroll
+    for (int w = 0; w < W4; ++w) {
+      f32x4 x = v[w];
+      if (p.bias && n + 4 * w < p.N) x += *(const f32x4*)(p.bias + n + 4 * w);
+      o[w] = pack2bf(silu_f(x[0]) * x[1], silu_f(x[2]) * x[3]);
+    }
+    bf16_t* dst = (bf16_t*)p.C + orow * p.ldc + (n >> 1);
+    if (W4 == 4 && n + 16 <= p.N && (p.ldc & 7) == 0) {
+      *(uint4*)dst = make_uint4(o[0], o[1], o[2], o[3]);
+    } else {
+#pragma unroll
+      for (int w = 0; w < W4; ++w)
+        if (n + 4 * w < p.N) *(uint32_t*)(dst + 2 * w) = o[w];
+    }
+    return;
+  }
+#pragma unroll
+  for (int w = 0; w < W4; ++w)
+    if (n + 4 * w < p.N) v[w] = epi_math4(p, v[w], m, orow, n + 4 * w);
+  if (p.out_f32) {
+#pragma unroll
+    for (int w = 0; w < W4; ++w)
+      if (n + 4 * w < p.N) *(f32x4*)((float*)p.C + orow * p.ldc + n + 4 * w) = v[w];
+  } else {
+    bf16_t* dst = (bf16_t*)p.C + orow * p.ldc + n;
+    if (W4 == 2 && n + 8 <= p.N && (p.ldc & 7) == 0) {
+      *(uint4*)dst = make_uint4(pack2bf(v[0][0], v[0][1]), pack2bf(v[0][2], v[0][3]), pack2bf(v[1][0], v[1][1]),
+                                pack2bf(v[1][2], v[1][3]));
+    } else {
+#pragma unroll
+      for (int w = 0; w < W4; ++w)
+        if (n + 4 * w < p.N) {
+          uint2 pk;
+          pk.x = pack2bf(v[w][0], v[w][1]);
+          pk.y = pack2bf(v[w][2], v[w][3]);
+          *(uint2*)(dst + 4 * w) = pk;
+        }
+    }
+  }
+}
 // 256x256x64 ping-pong kernel (gemm_bf16_256.hip)
 int gr_launch_gemm256(const GemmArgs& p, hipStream_t stream);
