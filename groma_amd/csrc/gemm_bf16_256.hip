@@ -213,6 +213,12 @@ __global__ __launch_bounds__(NT) void gemm_bf16_256_kernel(GemmArgs p) {
 
   // ---- epilogue through LDS in 4 passes of 64 rows (2 m-tiles per wave), double-buffered over the two stages ----
   __syncthreads();
+  EpiCols<4> ec4;
+  EpiCols<2> ec2;
+  EpiCols<1> ec1;
+  if (p.act == 3) ec4.load(p, n0 + (tid & 15) * 16);
+  else if (!p.out_f32 && p.splits == 1) ec2.load(p, n0 + (tid & 31) * 8);
+  else ec1.load(p, n0 + (tid & 63) * 4);
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     char* buf = smem + (q & 1) * STAGE_BYTES;
@@ -226,19 +232,19 @@ __global__ __launch_bounds__(NT) void gemm_bf16_256_kernel(GemmArgs p) {
 #pragma unroll
       for (int it = 0; it < 2; ++it) {
         const int idx = it * NT + tid, sr = idx >> 4;
-        epi_from_stage<T256, 4>(p, buf, sr, (idx & 15) * 4, m0 + (sr >> 5) * 128 + q * 32 + (sr & 31), n0, z);
+        epi_from_stage<T256, 4>(p, buf, sr, (idx & 15) * 4, m0 + (sr >> 5) * 128 + q * 32 + (sr & 31), n0, z, ec4);
       }
     } else if (!p.out_f32 && p.splits == 1) {
 #pragma unroll
       for (int it = 0; it < 4; ++it) {
         const int idx = it * NT + tid, sr = idx >> 5;
-        epi_from_stage<T256, 2>(p, buf, sr, (idx & 31) * 2, m0 + (sr >> 5) * 128 + q * 32 + (sr & 31), n0, z);
+        epi_from_stage<T256, 2>(p, buf, sr, (idx & 31) * 2, m0 + (sr >> 5) * 128 + q * 32 + (sr & 31), n0, z, ec2);
       }
     } else {
 #pragma unroll
       for (int it = 0; it < 8; ++it) {
         const int idx = it * NT + tid, sr = idx >> 6;
-        epi_from_stage<T256, 1>(p, buf, sr, idx & 63, m0 + (sr >> 5) * 128 + q * 32 + (sr & 31), n0, z);
+        epi_from_stage<T256, 1>(p, buf, sr, idx & 63, m0 + (sr >> 5) * 128 + q * 32 + (sr & 31), n0, z, ec1);
       }
     }
   }

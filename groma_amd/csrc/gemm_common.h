@@ -124,22 +124,37 @@ template <int COLS>
 __device__ __forceinline__ f32x4 stage_read4(const char* base, int row, int n4) {
   return *(const f32x4*)(base + ((long)row * COLS * 4) + (((n4 ^ (row & 7))) << 4));
 }
-__device__ __forceinline__ f32x4 epi_math4(const GemmArgs& p, f32x4 v, int m, long orow, int n) {
-  if (p.bias) v += *(const f32x4*)(p.bias + n);
+__device__ __forceinline__ f32x4 epi_math4(const GemmArgs& p, f32x4 v, int m, long orow, int n, f32x4 bias, f32x4 scale) {
+  v += bias;
   if (p.act == 1 || p.act == 2) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) v[e] = act_apply(v[e], p.act);
   }
-  if (p.scale) v *= *(const f32x4*)(p.scale + n);
+  v *= scale;
   if (p.resid) {
     const long rrow = p.resid_mod > 0 ? (long)(m % p.resid_mod) : orow;
     v += *(const f32x4*)(p.resid + rrow * p.ldr + n);
   }
   return v;
 }
+// Per-thread column constants: a thread's tile columns are the same for every row it finishes, so bias / LayerScale
+// are loaded ONCE per thread (zero / one when absent).
+template <int W4>
+struct EpiCols {
+  f32x4 bias[W4], scale[W4];
+  __device__ __forceinline__ void load(const GemmArgs& p, int n) {
+#pragma unroll
+    for (int w = 0; w < W4; ++w) {
+      const bool in = n + 4 * w < p.N;
+      bias[w] = (p.bias && in) ? *(const f32x4*)(p.bias + n + 4 * w) : (f32x4){0.f, 0.f, 0.f, 0.f};
+      scale[w] = (p.scale && in) ? *(const f32x4*)(p.scale + n + 4 * w) : (f32x4){1.f, 1.f, 1.f, 1.f};
+    }
+  }
+};
 // One thread's share of a staged row: W4 consecutive float4 starting at tile column c4*4 (tile-relative), row m.
 template <int COLS, int W4>
-__device__ __forceinline__ void epi_from_stage(const GemmArgs& p, const char* base, int srow, int c4, int m, int n0, int z) {
+__device__ __forceinline__ void epi_from_stage(const GemmArgs& p, const char* base, int srow, int c4, int m, int n0, int z,
+                                               const EpiCols<W4>& ec) {
   if (m >= p.M) return;
   f32x4 v[W4];
 #pragma unroll
@@ -157,8 +172,7 @@ __device__ __forceinline__ void epi_from_stage(const GemmArgs& p, const char* ba
     uint32_t o[W4];
 #pragma unroll
     for (int w = 0; w < W4; ++w) {
-      f32x4 x = v[w];
-      if (p.bias && n + 4 * w < p.N) x += *(const f32x4*)(p.bias + n + 4 * w);
+      const f32x4 x = v[w] + ec.bias[w];
       o[w] = pack2bf(silu_f(x[0]) * x[1], silu_f(x[2]) * x[3]);
     }
     bf16_t* dst = (bf16_t*)p.C + orow * p.ldc + (n >> 1);
@@ -173,7 +187,7 @@ __device__ __forceinline__ void epi_from_stage(const GemmArgs& p, const char* ba
   }
 #pragma unroll
   for (int w = 0; w < W4; ++w)
-    if (n + 4 * w < p.N) v[w] = epi_math4(p, v[w], m, orow, n + 4 * w);
+    if (n + 4 * w < p.N) v[w] = epi_math4(p, v[w], m, orow, n + 4 * w, ec.bias[w], ec.scale[w]);
   if (p.out_f32) {
 #pragma unroll
     for (int w = 0; w < W4; ++w)

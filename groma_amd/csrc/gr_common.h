@@ -13,34 +13,34 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 #define GR_OK 0
 #define GR_EINVAL 22
 
-// round-to-nearest-even f32 -> bf16 (same rule as torch .to(bfloat16))
-__device__ __forceinline__ bf16_t f2bf(float f) {
-  uint32_t u = __builtin_bit_cast(uint32_t, f);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);  // NaN
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return (bf16_t)(u >> 16);
-}
+// f32 -> bf16, round-to-nearest-even (same rule as torch .to(bfloat16)): the __bf16 casts lower to ONE
+// v_cvt_pk_bf16_f32 per pair on gfx950 (the bit-twiddling form costs ~7 VALU ops per element).
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_hw;
+__device__ __forceinline__ bf16_t f2bf(float f) { return __builtin_bit_cast(bf16_t, (__bf16)f); }
 __device__ __forceinline__ float bf2f(bf16_t h) {
   uint32_t u = ((uint32_t)h) << 16;
   return __builtin_bit_cast(float, u);
 }
 __device__ __forceinline__ uint32_t pack2bf(float a, float b) {
-  return (uint32_t)f2bf(a) | ((uint32_t)f2bf(b) << 16);
+  const bf16x2_hw v = {(__bf16)a, (__bf16)b};
+  return __builtin_bit_cast(uint32_t, v);
 }
 
 // erf via Abramowitz-Stegun 7.1.26 (|abs err| <= 1.5e-7, i.e. fp32-roundoff class): ~14 VALU ops instead of the
 // ~60 of ocml erff -- the exact-erf GELU (HF "gelu") epilogue of the ViT fc1 / bridge GEMMs is VALU-visible otherwise.
 __device__ __forceinline__ float erf_as(float x) {
   const float ax = fabsf(x);
-  const float t = 1.0f / (1.0f + 0.3275911f * ax);
+  const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * ax);  // v_rcp_f32: 1 ulp, plenty under the 1.5e-7 bound
   const float poly = ((((1.061405429f * t - 1.453152027f) * t + 1.421413741f) * t - 0.284496736f) * t + 0.254829592f) * t;
-  const float r = 1.0f - poly * __expf(-ax * ax);
+  const float r = 1.0f - poly * __builtin_amdgcn_exp2f(-1.4426950408889634f * ax * ax);
   return x < 0.f ? -r : r;
 }
 __device__ __forceinline__ float gelu_erf(float x) {
   return 0.5f * x * (1.0f + erf_as(x * 0.70710678118654752440f));
 }
-__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float silu_f(float x) {  // x * sigmoid(x); v_exp + v_rcp (~2 ulp), bf16 output downstream
+  return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
+}
 __device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + expf(-x)); }
 
 __device__ __forceinline__ float wave_sum(float v) {
