@@ -49,6 +49,7 @@ SIGNATURES = {
     "gr_mean4_tokens": [_P, _P, _P, _P, _P, _I, _I, _I, _P],
     "gr_s2d_pack": [_P, _P, _I, _I, _I, _P],
     "gr_upsample_coord_pack": [_P, _P, _I, _I, _I, _I, _I, _P],
+    "gr_gn_stats_blocks": [_I],
     "gr_gn_stats": [_P, _P, _I, _I, _I, _P],
     "gr_gn_finalize": [_P, _P, _P, _P, _I, _I, _I, _I, _F, _P],
     "gr_fuse_shuffle": [_P, _P, _I, _P, _P, _I, _P, _P, _I, _P, _I, _I, _I, _I, _P],

@@ -256,7 +256,9 @@ extern "C" int gr_upsample_coord_pack(const float* h, void* out, int B, int G, i
 }
 
 // ---------------------------------------------------------------------------------------
-// GroupNorm statistics of a conv output: x bf16 [imgs*HW, C] -> sums f32 [imgs, C, 2] (sum, sumsq), atomics.
+// GroupNorm statistics of a conv output: x bf16 [imgs*HW, C] -> per-row-block partial sums f32 [imgs, nblk, C, 2]
+// (sum, sumsq).  No atomics: the finalize kernel adds the nblk partials in a fixed order, so the statistics -- and
+// everything downstream -- are bit-reproducible run to run and independent of the batch composition.
 // (mmcv ConvModule norm = GN(64 groups), mmcv/cnn/bricks/conv_module.py:196-206)
 __global__ __launch_bounds__(256) void gn_stats_kernel(const bf16_t* __restrict__ x, float* __restrict__ sums, int HW,
                                                        int C, int rows_per_block) {
@@ -303,9 +305,10 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const bf16_t* __restrict_
     float t = 0.f;
 #pragma unroll
     for (int w = 0; w < 4; ++w) t += red[w][l8][which * 8 + i];
-    atomicAdd(sums + ((long)img * C + cblk * 64 + cc) * 2 + which, t);
+    sums[(((long)img * gridDim.x + blockIdx.x) * C + cblk * 64 + cc) * 2 + which] = t;
   }
 }
+extern "C" int gr_gn_stats_blocks(int HW) { return gr_cdiv(HW, 512); }
 extern "C" int gr_gn_stats(const void* x, float* sums, int imgs, int HW, int C, hipStream_t stream) {
   if (!x || !sums || C % 64 != 0) return GR_EINVAL;
   const int rpb = 512;
@@ -319,16 +322,17 @@ extern "C" int gr_gn_stats(const void* x, float* sums, int imgs, int HW, int C, 
 // torch.group_norm semantics: biased variance over (HW x C/groups) elements, eps inside the sqrt.
 __global__ void gn_finalize_kernel(const float* __restrict__ sums, const float* __restrict__ gamma,
                                    const float* __restrict__ beta, float* __restrict__ coef, int imgs, int C, int cpg,
-                                   float n, float eps) {
+                                   int nblk, float n, float eps) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= imgs * C) return;
   const int img = idx / C, ch = idx - img * C;
   const int g0 = (ch / cpg) * cpg;
   float sm = 0.f, sq = 0.f;
-  for (int k = 0; k < cpg; ++k) {
-    sm += sums[((long)img * C + g0 + k) * 2];
-    sq += sums[((long)img * C + g0 + k) * 2 + 1];
-  }
+  for (int bk = 0; bk < nblk; ++bk)
+    for (int k = 0; k < cpg; ++k) {
+      sm += sums[(((long)img * nblk + bk) * C + g0 + k) * 2];
+      sq += sums[(((long)img * nblk + bk) * C + g0 + k) * 2 + 1];
+    }
   const float mean = sm / n;
   const float var = fmaxf(sq / n - mean * mean, 0.f);
   const float rstd = 1.0f / sqrtf(var + eps);
@@ -341,7 +345,7 @@ extern "C" int gr_gn_finalize(const float* sums, const float* gamma, const float
   if (!sums || !gamma || !beta || !coef || groups <= 0 || C % groups != 0) return GR_EINVAL;
   const int cpg = C / groups;
   hipLaunchKernelGGL(gn_finalize_kernel, dim3(gr_cdiv((long)imgs * C, 256)), dim3(256), 0, stream, sums, gamma, beta, coef,
-                     imgs, C, cpg, (float)HW * (float)cpg, eps);
+                     imgs, C, cpg, gr_cdiv(HW, 512), (float)HW * (float)cpg, eps);
   GR_CHECK_LAUNCH();
   return GR_OK;
 }

@@ -179,7 +179,7 @@ def gn_coef(x, imgs, HW, C, groups, gamma, beta, eps):
     """GroupNorm statistics of a conv output x bf16 [imgs*HW, C] -> per-(image, channel) affine y = x*a + b,
     f32 [imgs, 2, C] (consumed by fuse_shuffle)."""
     lib = _lib.load()
-    sums = torch.zeros((imgs, C, 2), dtype=F32, device=x.device)
+    sums = torch.empty((imgs, lib.gr_gn_stats_blocks(HW), C, 2), dtype=F32, device=x.device)
     _lib.check(lib.gr_gn_stats(_p(x), _p(sums), imgs, HW, C, _stream()), "gr_gn_stats")
     coef = torch.empty((imgs, 2, C), dtype=F32, device=x.device)
     _lib.check(lib.gr_gn_finalize(_p(sums), _p(gamma), _p(beta), _p(coef), imgs, HW, C, groups, eps, _stream()),

@@ -93,6 +93,8 @@ int gr_mean4_tokens(const float* h0, const float* h1, const float* h2, const flo
                     hipStream_t stream);
 int gr_s2d_pack(const float* h, void* out, int B, int G, int C, hipStream_t stream);
 int gr_upsample_coord_pack(const float* h, void* out, int B, int G, int Ho, int C, int Cpad, hipStream_t stream);
+/* sums: f32 [imgs, gr_gn_stats_blocks(HW), C, 2] partials (no atomics: bit-reproducible) */
+int gr_gn_stats_blocks(int HW);
 int gr_gn_stats(const void* x, float* sums, int imgs, int HW, int C, hipStream_t stream);
 int gr_gn_finalize(const float* sums, const float* gamma, const float* beta, float* coef, int imgs, int HW, int C,
                    int groups, float eps, hipStream_t stream);
