@@ -9,6 +9,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 SOURCES = {
     "gemm_bf16.hip": [],
     "gemm_bf16_256.hip": [],
+    "gemv_bf16.hip": [],
     "gemm_f32.hip": [],
     "attention.hip": [],
     "norm.hip": [],

@@ -256,6 +256,8 @@ extern "C" int gr_gemm_bf16(const gr_gemm_desc* d, hipStream_t stream) {
   // ---- kernel choice: estimated time = rounds x per-slot tile time (slots: 512 for 128^2 at 2 blocks/CU, 256 for
   // 256^2 at 1 block/CU; per-CU throughput ratio measured on MI355X) ----
   bool use256 = false;
+  const bool gemv = d->tile == 1;  // decode-step shape: weights streamed once, no MFMA (gemv_bf16.hip)
+  if (gemv && (p.M > 8 || p.conv_C > 0 || splits != gr_cdiv(p.K, 512) || !p.ws)) return GR_EINVAL;
   if (d->tile == 256) use256 = true;
   else if (d->tile == 0) {
     const long t128 = (long)gr_cdiv(p.M, 128) * gr_cdiv(p.N, 128), t256 = (long)gr_cdiv(p.M, 256) * gr_cdiv(p.N, 256);
@@ -278,10 +280,13 @@ extern "C" int gr_gemm_bf16(const gr_gemm_desc* d, hipStream_t stream) {
     (void)hipEventCreate(&rec.a);
     (void)hipEventCreate(&rec.b);
     rec.flops = 2.0 * p.M * (double)p.N * p.K;
-    rec.M = p.M; rec.N = p.N; rec.K = p.K; rec.tag = (p.conv_C > 0 ? 1 : 0) | (splits > 1 ? 2 : 0) | (use256 ? 4 : 0);
+    rec.M = p.M; rec.N = p.N; rec.K = p.K; rec.tag = (p.conv_C > 0 ? 1 : 0) | (splits > 1 ? 2 : 0) | (use256 ? 4 : 0) | (gemv ? 8 : 0);
     (void)hipEventRecord(rec.a, stream);
   }
-  if (use256) {
+  if (gemv) {
+    const int rc = gr_launch_gemv(p, stream);
+    if (rc != GR_OK) return rc;
+  } else if (use256) {
     const int rc = gr_launch_gemm256(p, stream);
     if (rc != GR_OK) return rc;
   } else {
@@ -292,7 +297,7 @@ extern "C" int gr_gemm_bf16(const gr_gemm_desc* d, hipStream_t stream) {
     g_prof.push_back(rec);
   }
   GR_CHECK_LAUNCH();
-  if (splits > 1) {
+  if (splits > 1 || gemv) {
     const long tot = (long)p.M * (p.N >> 2);
     hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3(gr_cdiv(tot, 256)), dim3(256), 0, stream, p);
     GR_CHECK_LAUNCH();

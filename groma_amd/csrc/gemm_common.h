@@ -209,5 +209,7 @@ __device__ __forceinline__ void epi_from_stage(const GemmArgs& p, const char* ba
     }
   }
 }
+// skinny M<=8 streaming kernel (gemv_bf16.hip): requires p.splits == ceil(K/512) and p.ws
+int gr_launch_gemv(const GemmArgs& p, hipStream_t stream);
 // 256x256x64 ping-pong kernel (gemm_bf16_256.hip)
 int gr_launch_gemm256(const GemmArgs& p, hipStream_t stream);

@@ -31,6 +31,18 @@ def _chk(t, dtype, name):
     return t
 
 
+_GEMV_WS = {}
+
+
+def _gemv_ws(splits, M, N, device):
+    key = (splits, M, N, str(device))
+    t = _GEMV_WS.get(key)
+    if t is None:
+        t = torch.empty((splits, M, N), dtype=F32, device=device)
+        _GEMV_WS[key] = t
+    return t
+
+
 def gemm(a, w, *, out=None, bias=None, scale=None, resid=None, act=0, out_f32=False, splits=1, ws=None,
          M=None, lda=None, conv=None, resid_mod=0, row_map=None, ldc=None, ldr=None, tile=0):
     """out[M,N] = epilogue(a[M,K] @ w[N,K]^T).  `conv=(imgs,H,W,C,seg_stride)` switches A to the implicit
@@ -50,6 +62,9 @@ def gemm(a, w, *, out=None, bias=None, scale=None, resid=None, act=0, out_f32=Fa
         d.lda = lda if lda is not None else a.shape[-1]
         if a.shape[-1] != K and lda is None:
             raise ValueError(f"gemm: K mismatch {a.shape[-1]} vs {K}")
+    if tile == 0 and conv is None and M <= 8 and splits == 1 and N * K >= (1 << 20):
+        tile, splits = 1, (K + 511) // 512  # decode step: weight-streaming kernel + deterministic split-K reduce
+        ws = _gemv_ws(splits, M, N, a.device)
     n_out = N // 2 if act == 3 else N
     if out is None:
         out = torch.empty((M, n_out), dtype=F32 if out_f32 else BF16, device=a.device)

@@ -60,7 +60,8 @@ typedef struct gr_gemm_desc {
   int resid_mod;      /* > 0: residual row = m % resid_mod (position-embedding broadcast)          */
   /* output row remap: row(m) = (m / c_group)*c_group_stride + c_row_off + m % c_group (c_group > 0) */
   int c_group, c_group_stride, c_row_off;
-  int tile;           /* 0 = choose per shape; 128 / 256 force the 128x128 / 256x256 kernel          */
+  int tile;           /* 0 = choose per shape; 128 / 256 force the 128x128 / 256x256 kernel; 1 = skinny decode
+                         kernel (M <= 8; requires splits == ceil(K/512) and ws)                        */
 } gr_gemm_desc;
 int gr_gemm_bf16(const gr_gemm_desc* d, hipStream_t stream);
 

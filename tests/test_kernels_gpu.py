@@ -80,6 +80,25 @@ def test_gemm_epilogues(dev, tile):
     assert buf.view(3, 101, N)[:, 0].abs().max().item() == 0.0
 
 
+@pytest.mark.parametrize("M,N,K", [(1, 4096, 4096), (3, 1024, 11008), (8, 2816, 512), (4, 32128, 4096)])
+def test_gemm_decode_shape(dev, M, N, K):
+    """M <= 8 takes the weight-streaming kernel + deterministic split-K reduce (ops.gemm picks it automatically)"""
+    ops = _ops()
+    a = rnd((M, K), dev, seed=1).bfloat16()
+    w = rnd((N, K), dev, 0.05, seed=2).bfloat16()
+    a[:, 0] += 2.0
+    w[0, :] -= 1.0
+    base = a.float() @ w.float().t()
+    assert relerr(ops.gemm(a, w, out_f32=True), base) < 1e-5
+    assert relerr(ops.gemm(a, w, out_f32=True), ops.gemm(a, w, out_f32=True, tile=128)) < 1e-5
+    resid = rnd((M, N), dev, seed=3)
+    r2 = resid.clone()
+    ops.gemm(a, w, resid=r2, out=r2, out_f32=True)
+    assert relerr(r2, resid + base) < 1e-5
+    assert relerr(ops.gemm(a, w, act=3), F.silu(base[:, 0::2]) * base[:, 1::2]) < 4e-3
+    assert torch.equal(ops.gemm(a, w, out_f32=True), ops.gemm(a, w, out_f32=True))  # bit-reproducible
+
+
 @pytest.mark.parametrize("tile", [128, 256])
 @pytest.mark.parametrize("imgs,H,C,Cout,segs", [(2, 16, 64, 128, 1), (1, 32, 128, 64, 1), (3, 14, 64, 64, 3)])
 def test_gemm_conv3x3(dev, imgs, H, C, Cout, segs, tile):
