@@ -107,7 +107,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=4, help="images per GPU per step")
+    ap.add_argument("--batch", type=int, default=7, help="images per GPU per step (7*582 = 4074 rows ~ 16 GEMM row-tiles of 256)")
     ap.add_argument("--config", default="7b", choices=["7b", "tiny"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--gemm-breakdown", default=None, help="write a per-shape GEMM table (from the HIP-event hook) here")
@@ -191,6 +191,16 @@ def main():
         gemm_flops = sum(2.0 * r[0] * r[1] * r[2] for r in recs)
     else:
         gemm_ms, gemm_launches, gemm_flops = ops.prof_read()
+    # HBM-side traffic of the dominant kernel: rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE, separate runs, gfx950
+    # correction applied) of THIS command, summarised under profiles/ -- bench.py cannot drive the profiler itself
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic_b7.json")) as f:
+            pm = json.load(f)["kernels"]
+        if args.config == "7b" and args.batch == 7:
+            traffic = pm["gemm_bf16_256_kernel(GemmArgs)"]["traffic_bytes_per_launch"]
+    except Exception:
+        traffic = None
     ips = world * args.batch * args.steps / elapsed
     peak = 2500.0
     achieved = gemm_flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
@@ -206,7 +216,9 @@ def main():
                    "llm_seq_len": fl["L"], "regions_per_image": sum(n_reg) / len(n_reg),
                    "parallelism": f"dp{world} (image batch sharded, full replica per GPU)"},
         "roofline": {"bound": "mfma", "kernel": "gemm_bf16_kernel (all dense contractions incl. implicit-GEMM 3x3 convs)",
-                     "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": None,
+                     "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
+                     "traffic_note": "bytes/launch of gemm_bf16_256_kernel at the L2<->fabric boundary (Infinity-Cache hits "
+                                     "included), rocprofv3 PMC, profiles/r01_pmc_traffic_b7.json" if traffic else None,
                      "launches_per_step": gemm_launches / max(args.steps, 1),
                      "avg_launch_us": gemm_ms * 1e3 / max(gemm_launches, 1),
                      "flops_per_launch": gemm_flops / max(gemm_launches, 1),
