@@ -107,7 +107,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=7, help="images per GPU per step (7*582 = 4074 rows ~ 16 GEMM row-tiles of 256)")
+    ap.add_argument("--batch", type=int, default=14, help="images per GPU per step (14*582 = 8148 rows ~ 32 GEMM row-tiles of 256)")
     ap.add_argument("--config", default="7b", choices=["7b", "tiny"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--gemm-breakdown", default=None, help="write a per-shape GEMM table (from the HIP-event hook) here")

@@ -41,6 +41,11 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(AttnArgs p) {
   constexpr int KTILE = KV * KROW;    // bytes
   constexpr int VTILE = HD * KV * 2;  // Vt tile [HD][64] bf16, 128-B rows
   constexpr int STAGE = KTILE + VTILE;
+  // Key order inside a 64-key tile: MFMA row i of score sub-tile j holds key (j>>1)*32 + (i>>2)*8 + (j&1)*4 + (i&3),
+  // so that after S^T = K.Q^T a lane (k-group fg) owns keys 32*tt + fg*8 + {0..7} of query fr: exactly the 8
+  // CONTIGUOUS keys of the standard MFMA k-slot, and the Vt fragment is ONE 16-B LDS read (ds_read_b128).
+  // K-tile chunk swizzle (conflict-free for the 16 rows {0-3, 8-11, 16-19, 24-27}(+4) one ds_read_b128 touches):
+  auto kswz = [](int row) { return KCH == 16 ? ((row & 3) | (((row >> 3) & 3) << 2)) : (((row >> 1) & 1) | (((row >> 3) & 3) << 1)); };
   extern __shared__ __attribute__((aligned(16))) char smem[];  // 2 stages (double buffer)
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -97,7 +102,7 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(AttnArgs p) {
     for (int i = 0; i < NCH / 256; ++i) {
       const int q = i * 256 + tid;
       const int row = q / KCH, pos = q % KCH;
-      const int c = pos ^ (row & 7);
+      const int c = pos ^ kswz(row);
       int kr = kv0 + row;
       if (kr > p.Skv - 1) kr = p.Skv - 1;
       __builtin_amdgcn_global_load_lds((gptr_t)(Kp + (long)kr * HD + c * 8), (lptr_t)(ksm + i * 4096 + wave * 1024), 16, 0, 0);
@@ -131,16 +136,16 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(AttnArgs p) {
       for (int j = 0; j < 4; ++j) s[u][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const int row = j * 16 + fr;
+      const int row = (j >> 1) * 32 + (fr >> 2) * 8 + (j & 1) * 4 + (fr & 3);
 #pragma unroll
       for (int kk = 0; kk < HD / 32; ++kk) {
         const int c = kk * 4 + fg;
-        const bf16x8 kf = *(const bf16x8*)(ksm + row * KROW + ((c ^ (row & 7)) << 4));
+        const bf16x8 kf = *(const bf16x8*)(ksm + row * KROW + ((c ^ kswz(row)) << 4));
 #pragma unroll
         for (int u = 0; u < QT; ++u) s[u][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[u][kk], s[u][j], 0, 0, 0);
       }
     }
-    // ---- online softmax; lane holds keys kv0 + j*16 + fg*4 + r of query fr (per q-tile)
+    // ---- online softmax; lane holds keys kv0 + (j>>1)*32 + fg*8 + (j&1)*4 + r of query fr (per q-tile)
     union PB { bf16x8 v; uint32_t w[4]; };
     PB pb[QT][2];
 #pragma unroll
@@ -150,7 +155,7 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(AttnArgs p) {
       for (int j = 0; j < 4; ++j)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int key = kv0 + j * 16 + fg * 4 + r;
+          const int key = kv0 + (j >> 1) * 32 + fg * 8 + (j & 1) * 4 + r;
           float v = s[u][j][r] * p.scale_log2;
           v = key < limit[u] ? v : -1e30f;
           s[u][j][r] = v;
@@ -159,14 +164,14 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(AttnArgs p) {
       mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
       mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
       const float m_new = fmaxf(m_run[u], mx);
-      const float alpha = exp2f(m_run[u] - m_new);
+      const float alpha = __builtin_amdgcn_exp2f(m_run[u] - m_new);
       float rs = 0.f;
 #pragma unroll
       for (int j = 0; j < 4; ++j)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int key = kv0 + j * 16 + fg * 4 + r;
-          const float e = key < limit[u] ? exp2f(s[u][j][r] - m_new) : 0.f;
+          const int key = kv0 + (j >> 1) * 32 + fg * 8 + (j & 1) * 4 + r;
+          const float e = key < limit[u] ? __builtin_amdgcn_exp2f(s[u][j][r] - m_new) : 0.f;
           s[u][j][r] = e;
           rs += e;
         }
@@ -176,7 +181,7 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(AttnArgs p) {
       m_run[u] = m_new;
 #pragma unroll
       for (int n = 0; n < HD / 16; ++n) o[u][n] *= alpha;
-      // P^T as the B operand; k-slot (fg,e): e<4 -> key 32*tt + fg*4 + e ; e>=4 -> key 32*tt + 16 + fg*4 + (e-4)
+      // P^T as the B operand; k-slot (fg,e) <-> key 32*tt + fg*8 + e (standard contiguous slot)
 #pragma unroll
       for (int tt = 0; tt < 2; ++tt) {
         pb[u][tt].w[0] = pack2bf(s[u][2 * tt][0], s[u][2 * tt][1]);
@@ -191,15 +196,10 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(AttnArgs p) {
 #pragma unroll
       for (int n = 0; n < HD / 16; ++n) {
         const int row = n * 16 + fr;  // d index
-        const int off0 = (tt * 32 + fg * 4) * 2;
-        const int off1 = (tt * 32 + 16 + fg * 4) * 2;
-        const int sw = (row & 7) << 4;
-        const char* base = vsm + row * 128;
-        union { bf16x8 v; uint2 hh[2]; } vf;
-        vf.hh[0] = *(const uint2*)(base + (((off0 & ~15) ^ sw) | (off0 & 15)));
-        vf.hh[1] = *(const uint2*)(base + (((off1 & ~15) ^ sw) | (off1 & 15)));
+        const int c = tt * 4 + fg;    // keys 32*tt + fg*8 .. +7 = one 16-B chunk of the Vt row
+        const bf16x8 vfrag = *(const bf16x8*)(vsm + row * 128 + ((c ^ (row & 7)) << 4));
 #pragma unroll
-        for (int u = 0; u < QT; ++u) o[u][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf.v, pb[u][tt].v, o[u][n], 0, 0, 0);
+        for (int u = 0; u < QT; ++u) o[u][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vfrag, pb[u][tt].v, o[u][n], 0, 0, 0);
       }
     }
   }
