@@ -33,6 +33,18 @@
 enum { HT_A0 = 0, HT_B0 = 1, HT_B1 = 2, HT_A1 = 3 };
 
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0)
+#define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0)
+// G256_MFMA32 = 1 (experiment, measured SLOWER: 1.22 vs 1.42 PF at 8192^3): v_mfma_f32_32x32x16_bf16 instead of
+// v_mfma_f32_16x16x32_bf16 (16 per phase, ~17 clk each; 83 % ceiling).  Fragment rows are then 32 consecutive LDS
+// rows per ds_read_b128, which wants the chunk swizzle (row>>1)&7 instead of row&7 to stay conflict-free.
+#ifndef G256_MFMA32
+#define G256_MFMA32 0
+#endif
+#if G256_MFMA32
+#define LDS_SWZ(row) (((row) >> 1) & 7)
+#else
+#define LDS_SWZ(row) ((row) & 7)
+#endif
 
 __global__ __launch_bounds__(NT) void gemm_bf16_256_kernel(GemmArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -65,7 +77,7 @@ __global__ __launch_bounds__(NT) void gemm_bf16_256_kernel(GemmArgs p) {
 #pragma unroll
     for (int h = 0; h < 4; ++h) {
       const int r = rows[h] + lrow;
-      const int kc = lpos ^ (r & 7);
+      const int kc = lpos ^ LDS_SWZ(r);
       const bool isA = (h == HT_A0 || h == HT_A1);
       if (isA) {
         int m = m0 + r;
@@ -122,6 +134,19 @@ __global__ __launch_bounds__(NT) void gemm_bf16_256_kernel(GemmArgs p) {
     issue_at(h, tile, isA ? a_k_off(p, ks_begin + tile) : (long)(ks_begin + tile) * 64);
   };
 
+#if G256_MFMA32
+  f32x16 acc[4][2];  // [m-tile of 32][n-tile of 32]
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+  const int fr = lane & 31, fg = lane >> 5;  // fragment row, k-half of a 16-wide k-step
+  int koff[4];                               // byte offset of k-step s (chunk 2s+fg) in this lane's swizzled row
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) koff[ks] = ((2 * ks + fg) ^ LDS_SWZ(fr)) << 4;
+#else
   f32x4 acc[8][4];  // [mi][ni]
 #pragma unroll
   for (int i = 0; i < 8; ++i)
@@ -130,6 +155,7 @@ __global__ __launch_bounds__(NT) void gemm_bf16_256_kernel(GemmArgs p) {
 
   const int fr = lane & 15, fg = lane >> 4;
   const int off0 = (fg ^ (fr & 7)) << 4;  // chunk fg of a row with (row&7) == (fr&7); the kk=1 chunk is off0 ^ 64
+#endif
   const int a_lane = (wm * 128 + fr) * 128;
   const int b_lane = B_OFF + (wn * 64 + fr) * 128;
 
@@ -142,13 +168,65 @@ __global__ __launch_bounds__(NT) void gemm_bf16_256_kernel(GemmArgs p) {
   __builtin_amdgcn_s_barrier();
   if (wm == 1) __builtin_amdgcn_s_barrier();  // stagger the second wave group by one interval
 
-  bf16x8 af[4][2], b0f[2][2], b1f[2][2];
-
 #define WAIT_VM(N)                                                      \
   do {                                                                  \
     if (steady) asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory");   \
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               \
   } while (0)
+#if G256_MFMA32
+  bf16x8 af[2][4], b0f[4], b1f[4];  // [m-tile within the A half][k-step], [k-step]
+// barrier -> 8 MFMAs 32x32x16 (A half rows I0.., B n-tile J with fragment set BF) -> barrier
+#define COMPUTE_PHASE(I0, J, BF)                                                                          \
+  __builtin_amdgcn_sched_barrier(0);                                                                      \
+  __builtin_amdgcn_s_barrier();                                                                           \
+  __builtin_amdgcn_sched_barrier(0);                                                                      \
+  __builtin_amdgcn_s_setprio(1);                                                                          \
+  _Pragma("unroll") for (int ks = 0; ks < 4; ++ks)                                                        \
+    _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                         \
+      acc[I0 + i][J] = MFMA32(BF[ks], af[i][ks], acc[I0 + i][J]);                                         \
+  __builtin_amdgcn_s_setprio(0);                                                                          \
+  __builtin_amdgcn_sched_barrier(0);                                                                      \
+  __builtin_amdgcn_s_barrier();                                                                           \
+  __builtin_amdgcn_sched_barrier(0);
+#define READ_A(HALF)                                                                                      \
+  _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                           \
+    _Pragma("unroll") for (int ks = 0; ks < 4; ++ks)                                                      \
+      af[i][ks] = *(const bf16x8*)(st + a_lane + ((HALF) * 2 + i) * 4096 + koff[ks]);
+#define READ_B(DST, HALF)                                                                                 \
+  _Pragma("unroll") for (int ks = 0; ks < 4; ++ks)                                                        \
+    DST[ks] = *(const bf16x8*)(st + b_lane + (HALF) * 4096 + koff[ks]);
+
+  for (int t = 0; t < nt; ++t) {
+    const char* st = smem + (t & 1) * STAGE_BYTES;
+    const bool steady = t + 2 < nt;
+    // ===== phase 0 : reads A0,B0 ; A0 x B0 ; issues A1(t+1) ; retires B1(t)
+    READ_B(b0f, 0)
+    READ_A(0)
+    __builtin_amdgcn_sched_barrier(0);
+    WAIT_VM(4);
+    issue_at(HT_A1, t + 1, aoff1);
+    COMPUTE_PHASE(0, 0, b0f)
+    // ===== phase 1 : reads B1 ; A0 x B1 ; issues B1(t+1) ; retires A1(t)
+    READ_B(b1f, 1)
+    __builtin_amdgcn_sched_barrier(0);
+    WAIT_VM(8);
+    issue_at(HT_B1, t + 1, (long)(ks_begin + t + 1) * 64);
+    COMPUTE_PHASE(0, 1, b1f)
+    // ===== phase 2 : reads A1 ; A1 x B1 ; issues A0(t+2)
+    READ_A(1)
+    __builtin_amdgcn_sched_barrier(0);
+    if (!steady) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    issue_at(HT_A0, t + 2, aoff2);
+    COMPUTE_PHASE(2, 1, b1f)
+    // ===== phase 3 : no LDS reads ; A1 x B0 ; issues B0(t+2) ; retires A0(t+1), B0(t+1)
+    WAIT_VM(6);
+    issue_at(HT_B0, t + 2, (long)(ks_begin + t + 2) * 64);
+    advance();
+    COMPUTE_PHASE(2, 0, b0f)
+  }
+#else
+  bf16x8 af[4][2], b0f[2][2], b1f[2][2];
+
 // barrier -> 16 MFMAs (A sub-block rows I0.., B sub-block cols J0.. with fragment set BF) -> barrier
 #define COMPUTE_PHASE(I0, J0, BF)                                                                         \
   __builtin_amdgcn_sched_barrier(0);                                                                      \
@@ -209,6 +287,7 @@ __global__ __launch_bounds__(NT) void gemm_bf16_256_kernel(GemmArgs p) {
     advance();
     COMPUTE_PHASE(4, 0, b0f)
   }
+#endif
   if (wm == 0) __builtin_amdgcn_s_barrier();  // re-align the groups (same barrier count for every wave)
 
   // ---- epilogue through LDS in 4 passes of 64 rows (2 m-tiles per wave), double-buffered over the two stages ----
@@ -222,10 +301,21 @@ __global__ __launch_bounds__(NT) void gemm_bf16_256_kernel(GemmArgs p) {
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     char* buf = smem + (q & 1) * STAGE_BYTES;
+#if G256_MFMA32
+    // C layout of 32x32: col = lane&31 (-> m), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (-> n): 4 float4 groups per tile
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const f32x4 v = {acc[q][j][4 * g], acc[q][j][4 * g + 1], acc[q][j][4 * g + 2], acc[q][j][4 * g + 3]};
+        stage_write4<T256>(buf, wm * 32 + fr, wn * 16 + j * 8 + 2 * g + fg, v);
+      }
+#else
 #pragma unroll
     for (int e = 0; e < 2; ++e)
 #pragma unroll
       for (int j = 0; j < 4; ++j) stage_write4<T256>(buf, wm * 32 + e * 16 + fr, wn * 16 + j * 4 + fg, acc[2 * q + e][j]);
+#endif
     __syncthreads();
     // staged row sr -> tile row (sr>>5)*128 + q*32 + (sr&31)
     if (p.act == 3) {
