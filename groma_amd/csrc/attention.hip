@@ -15,6 +15,8 @@
 // a lane owns ONE query column: the row max/sum are in-lane + 2 shuffles, and P^T feeds
 // the second MFMA (O^T = Vt.P^T) straight from registers -- no LDS round trip for P.
 // K / Vt tiles are staged with global_load_lds into an XOR-swizzled, conflict-free image.
+#include <type_traits>
+
 #include "gr_common.h"
 #include "../../include/groma_hip.h"
 
@@ -81,6 +83,8 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(AttnArgs p) {
   const int blk_limit = p.causal ? min(kvmax, p.q_pos0 + blk_last + 1) : kvmax;
   const int wav_limit = p.causal ? min(kvmax, p.q_pos0 + wav_last + 1) : kvmax;
   const int ntiles = (blk_limit + KV - 1) / KV;
+  const int wav_first = min(q0 + wave * (16 * QT), p.Lq - 1);
+  const int wav_min_limit = p.causal ? min(kvmax, p.q_pos0 + wav_first + 1) : kvmax;  // min over the wave's rows
 
   f32x4 o[QT][HD / 16];
   float m_run[QT], l_run[QT];
@@ -145,51 +149,62 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(AttnArgs p) {
         for (int u = 0; u < QT; ++u) s[u][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[u][kk], s[u][j], 0, 0, 0);
       }
     }
-    // ---- online softmax; lane holds keys kv0 + (j>>1)*32 + fg*8 + (j&1)*4 + r of query fr (per q-tile)
+    // ---- online softmax; lane holds keys kv0 + (j>>1)*32 + fg*8 + (j&1)*4 + r of query fr (per q-tile).
+    // The running max is kept in RAW score units and the softmax scale is folded into one fma per element
+    // (e = exp2(s*c - m*c)); masking (2 cmp + 2 select per element) is compiled only into boundary tiles.
     union PB { bf16x8 v; uint32_t w[4]; };
     PB pb[QT][2];
+    const float cs = p.scale_log2;
+    auto softmax_tile = [&](auto masked_tag) {
+      constexpr bool MASKED = decltype(masked_tag)::value;
 #pragma unroll
-    for (int u = 0; u < QT; ++u) {
-      float mx = -1e30f;
+      for (int u = 0; u < QT; ++u) {
+        float mx = -1e30f;
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int key = kv0 + (j >> 1) * 32 + fg * 8 + (j & 1) * 4 + r;
-          float v = s[u][j][r] * p.scale_log2;
-          v = key < limit[u] ? v : -1e30f;
-          s[u][j][r] = v;
-          mx = fmaxf(mx, v);
+          for (int r = 0; r < 4; ++r) {
+            if (MASKED) {
+              const int key = kv0 + (j >> 1) * 32 + fg * 8 + (j & 1) * 4 + r;
+              if (key >= limit[u]) s[u][j][r] = -1e30f;
+            }
+            mx = fmaxf(mx, s[u][j][r]);
+          }
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m_run[u], mx);
+        const float alpha = __builtin_amdgcn_exp2f((m_run[u] - m_new) * cs);
+        const float mc = -m_new * cs;
+        float rs = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            // masked entries: s = -1e30 -> exp2(-huge) = 0 exactly, unless the whole row is masked so far (m_new = -1e30,
+            // argument 0): select 0 there
+            float e = __builtin_amdgcn_exp2f(__builtin_fmaf(s[u][j][r], cs, mc));
+            if (MASKED) e = s[u][j][r] <= -1e30f ? 0.f : e;
+            s[u][j][r] = e;
+            rs += e;
+          }
+        rs += __shfl_xor(rs, 16, 64);
+        rs += __shfl_xor(rs, 32, 64);
+        l_run[u] = l_run[u] * alpha + rs;
+        m_run[u] = m_new;
+#pragma unroll
+        for (int n = 0; n < HD / 16; ++n) o[u][n] *= alpha;
+        // P^T as the B operand; k-slot (fg,e) <-> key 32*tt + fg*8 + e (standard contiguous slot)
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+          pb[u][tt].w[0] = pack2bf(s[u][2 * tt][0], s[u][2 * tt][1]);
+          pb[u][tt].w[1] = pack2bf(s[u][2 * tt][2], s[u][2 * tt][3]);
+          pb[u][tt].w[2] = pack2bf(s[u][2 * tt + 1][0], s[u][2 * tt + 1][1]);
+          pb[u][tt].w[3] = pack2bf(s[u][2 * tt + 1][2], s[u][2 * tt + 1][3]);
         }
-      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-      const float m_new = fmaxf(m_run[u], mx);
-      const float alpha = __builtin_amdgcn_exp2f(m_run[u] - m_new);
-      float rs = 0.f;
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int key = kv0 + (j >> 1) * 32 + fg * 8 + (j & 1) * 4 + r;
-          const float e = key < limit[u] ? __builtin_amdgcn_exp2f(s[u][j][r] - m_new) : 0.f;
-          s[u][j][r] = e;
-          rs += e;
-        }
-      rs += __shfl_xor(rs, 16, 64);
-      rs += __shfl_xor(rs, 32, 64);
-      l_run[u] = l_run[u] * alpha + rs;
-      m_run[u] = m_new;
-#pragma unroll
-      for (int n = 0; n < HD / 16; ++n) o[u][n] *= alpha;
-      // P^T as the B operand; k-slot (fg,e) <-> key 32*tt + fg*8 + e (standard contiguous slot)
-#pragma unroll
-      for (int tt = 0; tt < 2; ++tt) {
-        pb[u][tt].w[0] = pack2bf(s[u][2 * tt][0], s[u][2 * tt][1]);
-        pb[u][tt].w[1] = pack2bf(s[u][2 * tt][2], s[u][2 * tt][3]);
-        pb[u][tt].w[2] = pack2bf(s[u][2 * tt + 1][0], s[u][2 * tt + 1][1]);
-        pb[u][tt].w[3] = pack2bf(s[u][2 * tt + 1][2], s[u][2 * tt + 1][3]);
       }
-    }
+    };
+    if (kv0 + KV <= wav_min_limit) softmax_tile(std::false_type{});  // every key of the tile visible to every row
+    else softmax_tile(std::true_type{});
     // ---- O^T += Vt . P^T ; Vt fragments shared by the q-tiles
 #pragma unroll
     for (int tt = 0; tt < 2; ++tt) {

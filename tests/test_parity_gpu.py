@@ -135,4 +135,9 @@ def test_generate_matches_oracle_greedy(setup):
     # token ids: exact unless the oracle's own top-2 margin at that step is inside the bf16 error band
     same = (g.sequences.cpu() == ref["sequences"])
     print("generated", g.sequences[:, -3:].tolist(), "oracle", ref["sequences"][:, -3:].tolist())
-    assert same[:, : ids.shape[1] + 1].all(), "first generated token differs from the oracle"
+    assert same[:, : ids.shape[1]].all()
+    # first generated token: must equal the oracle's wherever the oracle's own top-2 margin at the last prefill position
+    # is resolvable under bf16 compute (abs logit error is ~1e-2 on these weights; see test_full_forward_chained)
+    top2 = ref["prefill"]["logits"][:, -1].topk(2, dim=-1).values
+    clear = (top2[:, 0] - top2[:, 1]) > 0.05
+    assert same[:, ids.shape[1]][clear].all(), "first generated token differs from the oracle on a clear-margin row"
