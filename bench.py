@@ -173,31 +173,32 @@ def main():
         step(args.warmup + i)
     torch.cuda.synchronize()
     ops.prof_enable(False)
+    recs = ops.prof_read_launches()
     if args.gemm_breakdown and rank == 0:
-        recs = ops.prof_read_launches()
         agg = {}
         for M_, N_, K_, tag, ms in recs:
             a = agg.setdefault((M_, N_, K_, tag), [0, 0.0])
             a[0] += 1
             a[1] += ms
         with open(args.gemm_breakdown, "w") as f:
-            f.write("M N K tag(1=conv,2=splitK) calls_per_step avg_us TFLOPs share_of_gemm_time\n")
+            f.write("M N K tag(1=conv,2=splitK,4=256x256 kernel,8=decode kernel) calls_per_step avg_us TFLOPs share_of_gemm_time\n")
             tot = sum(v[1] for v in agg.values())
             for (M_, N_, K_, tag), (c, ms) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
                 f.write(f"{M_} {N_} {K_} {tag} {c / args.steps:.1f} {ms / c * 1e3:.1f} "
                         f"{2.0 * M_ * N_ * K_ * c / (ms * 1e-3) / 1e12:.0f} {ms / tot:.3f}\n")
-        gemm_ms = sum(r[4] for r in recs)
-        gemm_launches = len(recs)
-        gemm_flops = sum(2.0 * r[0] * r[1] * r[2] for r in recs)
-    else:
-        gemm_ms, gemm_launches, gemm_flops = ops.prof_read()
+    all_ms = sum(r[4] for r in recs)
+    all_flops = sum(2.0 * r[0] * r[1] * r[2] for r in recs)
+    dom = [r for r in recs if r[3] & 4]  # the dominant kernel: gemm_bf16_256_kernel
+    gemm_ms = sum(r[4] for r in dom)
+    gemm_launches = len(dom)
+    gemm_flops = sum(2.0 * r[0] * r[1] * r[2] for r in dom)
     # HBM-side traffic of the dominant kernel: rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE, separate runs, gfx950
     # correction applied) of THIS command, summarised under profiles/ -- bench.py cannot drive the profiler itself
     traffic = None
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic_b7.json")) as f:
+        with open(os.path.join(ROOT, "profiles", f"r01_pmc_traffic_b{args.batch}.json")) as f:
             pm = json.load(f)["kernels"]
-        if args.config == "7b" and args.batch == 7:
+        if args.config == "7b":
             traffic = pm["gemm_bf16_256_kernel(GemmArgs)"]["traffic_bytes_per_launch"]
     except Exception:
         traffic = None
@@ -215,14 +216,17 @@ def main():
                    "images_per_gpu": args.batch, "global_batch": world * args.batch, "prompt_tokens": P,
                    "llm_seq_len": fl["L"], "regions_per_image": sum(n_reg) / len(n_reg),
                    "parallelism": f"dp{world} (image batch sharded, full replica per GPU)"},
-        "roofline": {"bound": "mfma", "kernel": "gemm_bf16_kernel (all dense contractions incl. implicit-GEMM 3x3 convs)",
+        "roofline": {"bound": "mfma", "kernel": "gemm_bf16_256_kernel(GemmArgs) -- 256x256 ping-pong MFMA GEMM incl. implicit-GEMM 3x3 convs",
                      "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
                      "traffic_note": "bytes/launch of gemm_bf16_256_kernel at the L2<->fabric boundary (Infinity-Cache hits "
-                                     "included), rocprofv3 PMC, profiles/r01_pmc_traffic_b7.json" if traffic else None,
+                                     "included), rocprofv3 PMC, profiles/r01_pmc_traffic_b%d.json" % args.batch if traffic else None,
                      "launches_per_step": gemm_launches / max(args.steps, 1),
                      "avg_launch_us": gemm_ms * 1e3 / max(gemm_launches, 1),
                      "flops_per_launch": gemm_flops / max(gemm_launches, 1),
-                     "gemm_time_share_of_step": (gemm_ms / args.steps) / (elapsed / args.steps * 1e3),
+                     "kernel_time_share_of_step": (gemm_ms / args.steps) / (elapsed / args.steps * 1e3),
+                     "all_gemm_kernels": {"achieved": all_flops / (all_ms * 1e-3) / 1e12 if all_ms > 0 else 0.0,
+                                          "launches_per_step": len(recs) / max(args.steps, 1),
+                                          "time_share_of_step": (all_ms / args.steps) / (elapsed / args.steps * 1e3)},
                      "e2e_algorithmic_tflops_per_gpu": fl["total"] * args.batch * args.steps / elapsed / 1e12,
                      "e2e_frac_of_peak": fl["total"] * args.batch * args.steps / elapsed / 1e12 / peak},
     }
