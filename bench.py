@@ -109,6 +109,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=14, help="images per GPU per step (14*582 = 8148 rows ~ 32 GEMM row-tiles of 256)")
     ap.add_argument("--config", default="7b", choices=["7b", "tiny"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp8"],
+                    help="GEMM operand type of the DINOv2/LLaMA linears.  bf16 is the headline (the reference's precision); "
+                         "fp8 = OCP e4m3 operands + f32 accumulate (BASELINE configs[4] extension, reported as dtype fp8)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--gemm-breakdown", default=None, help="write a per-shape GEMM table (from the HIP-event hook) here")
     args = ap.parse_args()
@@ -130,7 +133,8 @@ def main():
     from groma_amd.groma import GromaModel
 
     cfg = gconfig.groma_7b(box_score_thres=0.0) if args.config == "7b" else gconfig.groma_tiny(box_score_thres=0.0)
-    model = GromaModel.from_synthetic(cfg, seed=0, device=dev)
+    fp8 = args.dtype == "fp8"
+    model = GromaModel.from_synthetic(cfg, seed=0, device=dev, fp8=fp8)
     model.init_special_token_id(constants.SyntheticTokenizer())
     P = 128
     images, ids = synth.make_inputs(cfg, model, args.batch, seed=1234 + rank, prompt_len=P)
@@ -188,7 +192,7 @@ def main():
                         f"{2.0 * M_ * N_ * K_ * c / (ms * 1e-3) / 1e12:.0f} {ms / tot:.3f}\n")
     all_ms = sum(r[4] for r in recs)
     all_flops = sum(2.0 * r[0] * r[1] * r[2] for r in recs)
-    dom = [r for r in recs if r[3] & 4]  # the dominant kernel: gemm_bf16_256_kernel
+    dom = [r for r in recs if (r[3] & 16 if fp8 else (r[3] & 4 and not r[3] & 16))]  # the dominant kernel
     gemm_ms = sum(r[4] for r in dom)
     gemm_launches = len(dom)
     gemm_flops = sum(2.0 * r[0] * r[1] * r[2] for r in dom)
@@ -198,25 +202,27 @@ def main():
     try:
         with open(os.path.join(ROOT, "profiles", f"r01_pmc_traffic_b{args.batch}.json")) as f:
             pm = json.load(f)["kernels"]
-        if args.config == "7b":
+        if args.config == "7b" and not fp8:
             traffic = pm["gemm_bf16_256_kernel(GemmArgs)"]["traffic_bytes_per_launch"]
     except Exception:
         traffic = None
     ips = world * args.batch * args.steps / elapsed
-    peak = 2500.0
+    peak = 5000.0 if fp8 else 2500.0  # dense MFMA peak of the operand type (MI355X_MICROARCH.md)
+    kname = "gemm_fp8_256_kernel(GemmArgs) -- 256x256 ping-pong e4m3 MFMA GEMM" if fp8 else \
+        "gemm_bf16_256_kernel(GemmArgs) -- 256x256 ping-pong MFMA GEMM incl. implicit-GEMM 3x3 convs"
     achieved = gemm_flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
     out = {
         "metric": "images/sec end-to-end forward (448px, 300 proposals, 128 tok)",
         "value": ips, "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "bf16", "data": "synthetic",
+        "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": "configs[2]: full Groma-7B forward (DINOv2-L + DDETR 300 proposals -> NMS 100 regions + "
                                "region encoder + Vicuna-7B prefill, logits for all positions), random-init weights"
                                if args.config == "7b" else "tiny parity architecture (NOT the headline workload)",
                    "images_per_gpu": args.batch, "global_batch": world * args.batch, "prompt_tokens": P,
                    "llm_seq_len": fl["L"], "regions_per_image": sum(n_reg) / len(n_reg),
                    "parallelism": f"dp{world} (image batch sharded, full replica per GPU)"},
-        "roofline": {"bound": "mfma", "kernel": "gemm_bf16_256_kernel(GemmArgs) -- 256x256 ping-pong MFMA GEMM incl. implicit-GEMM 3x3 convs",
+        "roofline": {"bound": "mfma", "kernel": kname,
                      "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
                      "traffic_note": "bytes/launch of gemm_bf16_256_kernel at the L2<->fabric boundary (Infinity-Cache hits "
                                      "included), rocprofv3 PMC, profiles/r01_pmc_traffic_b%d.json" % args.batch if traffic else None,

@@ -28,6 +28,7 @@ class GemmDesc(ctypes.Structure):
         ("resid_mod", c_int),
         ("c_group", c_int), ("c_group_stride", c_int), ("c_row_off", c_int),
         ("tile", c_int),
+        ("fp8", c_int), ("a_scale", c_void_p), ("w_scale", c_void_p),
     ]
 
 
@@ -40,6 +41,8 @@ SIGNATURES = {
     "gr_prof_read_launches": [_L, _P, _P, _P],
     "gr_gemm_bf16": [ctypes.POINTER(GemmDesc), _P],
     "gr_gemm_f32": [_P, _P, _P, _P, _P, _I, _I, _I, _L, _L, _L, _I, _P],
+    "gr_quant_rows_fp8": [_P, _I, _P, _P, _I, _I, _L, _P],
+    "gr_norm_fp8": [_P, _P, _P, _P, _P, _I, _I, _F, _I, _P],
     "gr_layernorm": [_P, _P, _P, _P, _P, _I, _I, _L, _L, _F, _I, _I, _P],
     "gr_rmsnorm": [_P, _P, _P, _I, _I, _L, _L, _F, _I, _P],
     "gr_attention_bf16": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _F, _P],
@@ -85,7 +88,7 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
         fn.argtypes = argtypes
         fn.restype = c_int
-    if lib.gr_abi_version() != 1:
+    if lib.gr_abi_version() != 2:
         raise RuntimeError("libgroma_hip.so ABI version mismatch")
     _lib = lib
     return lib

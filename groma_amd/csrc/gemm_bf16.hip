@@ -234,6 +234,7 @@ extern "C" int gr_gemm_bf16(const gr_gemm_desc* d, hipStream_t stream) {
   if (!d || !d->A || !d->W || !d->C) return GR_EINVAL;
   if (d->M <= 0 || d->N <= 0 || d->K <= 0) return GR_EINVAL;
   if (d->K % BK != 0 || d->N % 4 != 0) return GR_EINVAL;
+  if (d->fp8 && (d->K % 128 != 0 || d->conv_C > 0 || !d->w_scale || d->tile == 1)) return GR_EINVAL;
   if (d->conv_C > 0 && (d->conv_C % BK != 0 || d->K % (9 * d->conv_C) != 0)) return GR_EINVAL;
   const int splits = d->splits > 1 ? d->splits : 1;
   if (splits > 1 && !d->ws) return GR_EINVAL;
@@ -245,6 +246,8 @@ extern "C" int gr_gemm_bf16(const gr_gemm_desc* d, hipStream_t stream) {
   p.bias = d->bias;
   p.scale = d->scale;
   p.resid = d->resid;
+  p.a_scale = d->fp8 ? d->a_scale : nullptr;
+  p.w_scale = d->fp8 ? d->w_scale : nullptr;
   p.ws = d->ws;
   p.M = d->M; p.N = d->N; p.K = d->K;
   p.lda = d->lda; p.ldw = d->ldw; p.ldc = d->ldc; p.ldr = d->ldr;
@@ -258,7 +261,7 @@ extern "C" int gr_gemm_bf16(const gr_gemm_desc* d, hipStream_t stream) {
   bool use256 = false;
   const bool gemv = d->tile == 1;  // decode-step shape: weights streamed once, no MFMA (gemv_bf16.hip)
   if (gemv && (p.M > 8 || p.conv_C > 0 || splits != gr_cdiv(p.K, 512) || !p.ws)) return GR_EINVAL;
-  if (d->tile == 256) use256 = true;
+  if (d->tile == 256 || d->fp8) use256 = true;  // the fp8 build exists for the 256x256 kernel only
   else if (d->tile == 0) {
     const long t128 = (long)gr_cdiv(p.M, 128) * gr_cdiv(p.N, 128), t256 = (long)gr_cdiv(p.M, 256) * gr_cdiv(p.N, 256);
     const double ksteps = (double)(p.K / 64) / splits;
@@ -279,15 +282,15 @@ extern "C" int gr_gemm_bf16(const gr_gemm_desc* d, hipStream_t stream) {
   if (g_prof_on) {
     (void)hipEventCreate(&rec.a);
     (void)hipEventCreate(&rec.b);
-    rec.flops = 2.0 * p.M * (double)p.N * p.K;
-    rec.M = p.M; rec.N = p.N; rec.K = p.K; rec.tag = (p.conv_C > 0 ? 1 : 0) | (splits > 1 ? 2 : 0) | (use256 ? 4 : 0) | (gemv ? 8 : 0);
+    rec.flops = 2.0 * p.M * (double)p.N * p.K;  // (fp8 launches are tagged 16)
+    rec.M = p.M; rec.N = p.N; rec.K = p.K; rec.tag = (p.conv_C > 0 ? 1 : 0) | (splits > 1 ? 2 : 0) | (use256 ? 4 : 0) | (gemv ? 8 : 0) | (d->fp8 ? 16 : 0);
     (void)hipEventRecord(rec.a, stream);
   }
   if (gemv) {
     const int rc = gr_launch_gemv(p, stream);
     if (rc != GR_OK) return rc;
   } else if (use256) {
-    const int rc = gr_launch_gemm256(p, stream);
+    const int rc = d->fp8 ? gr_launch_gemm256_fp8(p, stream) : gr_launch_gemm256(p, stream);
     if (rc != GR_OK) return rc;
   } else {
     hipLaunchKernelGGL(gemm_bf16_kernel, grid, dim3(NTHREADS), 65536, stream, p);

@@ -32,7 +32,32 @@
 
 enum { HT_A0 = 0, HT_B0 = 1, HT_B1 = 2, HT_A1 = 3 };
 
+// The same source builds the OCP-fp8 (e4m3) variant (gemm_fp8_256.hip defines G256_FP8=1): operands are 1-byte
+// elements, a 128-B LDS row then holds 128 k-values, and every 16-B fragment chunk feeds TWO
+// v_mfma_f32_16x16x32_fp8_fp8 (low / high 8 bytes; both operands use the same k-order so the product is unchanged):
+// twice the MFMA work per byte staged.  Per-row / per-column dequantisation scales are applied in the epilogue.
+#ifndef G256_FP8
+#define G256_FP8 0
+#endif
+#if G256_FP8
+#define G256_KERNEL gemm_fp8_256_kernel
+#define G256_LAUNCH gr_launch_gemm256_fp8
+#define ESZ 1
+typedef union { bf16x8 v; long h[2]; } frag_u;
+__device__ __forceinline__ f32x4 mfma_fp8x2(bf16x8 a, bf16x8 b, f32x4 c) {
+  frag_u ua, ub;
+  ua.v = a; ub.v = b;
+  c = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(ua.h[0], ub.h[0], c, 0, 0, 0);
+  return __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(ua.h[1], ub.h[1], c, 0, 0, 0);
+}
+#define MFMA16(a, b, c) mfma_fp8x2(a, b, c)
+#else
+#define G256_KERNEL gemm_bf16_256_kernel
+#define G256_LAUNCH gr_launch_gemm256
+#define ESZ 2
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0)
+#endif
+#define KT (128 / ESZ)  // K elements per K-tile (one 128-B LDS row)
 #define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0)
 // G256_MFMA32 = 1 (experiment, measured SLOWER: 1.22 vs 1.42 PF at 8192^3): v_mfma_f32_32x32x16_bf16 instead of
 // v_mfma_f32_16x16x32_bf16 (16 per phase, ~17 clk each; 83 % ceiling).  Fragment rows are then 32 consecutive LDS
@@ -46,7 +71,7 @@ enum { HT_A0 = 0, HT_B0 = 1, HT_B1 = 2, HT_A1 = 3 };
 #define LDS_SWZ(row) ((row) & 7)
 #endif
 
-__global__ __launch_bounds__(NT) void gemm_bf16_256_kernel(GemmArgs p) {
+__global__ __launch_bounds__(NT) void G256_KERNEL(GemmArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -57,7 +82,7 @@ __global__ __launch_bounds__(NT) void gemm_bf16_256_kernel(GemmArgs p) {
   tile_of_block(blockIdx.x, gridDim.x, p.tiles_m, p.tiles_n, tm, tn);
   const int m0 = tm * T256, n0 = tn * T256;
 
-  const int ksteps_total = p.K / 64;
+  const int ksteps_total = p.K / KT;
   const int z = blockIdx.y;
   const int ks_per = (ksteps_total + p.splits - 1) / p.splits;
   const int ks_begin = z * ks_per;
@@ -67,7 +92,7 @@ __global__ __launch_bounds__(NT) void gemm_bf16_256_kernel(GemmArgs p) {
   // physical row inside the 256-row region:  A0: (hrow>>6)*128 + (hrow&63)   A1: +64
   //                                          B0: (hrow>>5)*64  + (hrow&31)   B1: +32
   const int lrow = lane >> 3, lpos = lane & 7;
-  const bf16_t* src[4][2];  // [half-tile][i] : per-lane global source (row base + swizzled chunk), k-offset added later
+  const char* src[4][2];  // [half-tile][i] : per-lane global source (row base + swizzled 16-B chunk), k-offset added later
   int ldsoff[4][2];         // wave-uniform LDS byte offset inside a stage
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
@@ -82,11 +107,11 @@ __global__ __launch_bounds__(NT) void gemm_bf16_256_kernel(GemmArgs p) {
       if (isA) {
         int m = m0 + r;
         if (m > p.M - 1) m = p.M - 1;
-        src[h][i] = p.A + a_row_base(p, m) + kc * 8;
+        src[h][i] = (const char*)p.A + a_row_base(p, m) * ESZ + kc * 16;
       } else {
         int n = n0 + r;
         if (n > p.N - 1) n = p.N - 1;
-        src[h][i] = p.W + (long)n * p.ldw + kc * 8;
+        src[h][i] = (const char*)p.W + (long)n * p.ldw * ESZ + kc * 16;
       }
       ldsoff[h][i] = (isA ? 0 : B_OFF) + rows[h] * 128;
     }
@@ -94,7 +119,11 @@ __global__ __launch_bounds__(NT) void gemm_bf16_256_kernel(GemmArgs p) {
 
   // A-operand k offsets of K-tiles t+1 and t+2 are carried incrementally (the conv gather's (segment, tap, channel)
   // decomposition needs integer divisions otherwise -- too slow for the 16-MFMA shadow of a phase)
+#if G256_FP8
+  long aoff1 = (long)(ks_begin + 1) * KT, aoff2 = (long)(ks_begin + 2) * KT;  // fp8: plain GEMM only (no conv gather)
+#else
   long aoff1 = a_k_off(p, ks_begin + 1), aoff2 = a_k_off(p, ks_begin + 2);
+#endif
   int cv_c = 0, cv_kx = 0, cv_ky = 0;
   long cv_base = 0;  // state of tile t+2
   if (p.conv_C > 0) {
@@ -119,19 +148,19 @@ __global__ __launch_bounds__(NT) void gemm_bf16_256_kernel(GemmArgs p) {
       }
       aoff2 = cv_base + (long)(cv_ky * (p.conv_W + 2) + cv_kx) * p.conv_C + cv_c;
     } else {
-      aoff2 += 64;
+      aoff2 += KT;
     }
   };
 
   auto issue_at = [&](int h, int tile, long koff) {  // one half-tile of K-tile `tile` into stage tile&1
     if (tile >= nt) return;
     char* st = smem + (tile & 1) * STAGE_BYTES;
-    glds16(src[h][0] + koff, st + ldsoff[h][0]);
-    glds16(src[h][1] + koff, st + ldsoff[h][1]);
+    glds16(src[h][0] + koff * ESZ, st + ldsoff[h][0]);
+    glds16(src[h][1] + koff * ESZ, st + ldsoff[h][1]);
   };
   auto issue = [&](int h, int tile) {  // prologue form (offset from the tile index)
     const bool isA = (h == HT_A0 || h == HT_A1);
-    issue_at(h, tile, isA ? a_k_off(p, ks_begin + tile) : (long)(ks_begin + tile) * 64);
+    issue_at(h, tile, (isA && !G256_FP8) ? a_k_off(p, ks_begin + tile) : (long)(ks_begin + tile) * KT);
   };
 
 #if G256_MFMA32
@@ -210,7 +239,7 @@ __global__ __launch_bounds__(NT) void gemm_bf16_256_kernel(GemmArgs p) {
     READ_B(b1f, 1)
     __builtin_amdgcn_sched_barrier(0);
     WAIT_VM(8);
-    issue_at(HT_B1, t + 1, (long)(ks_begin + t + 1) * 64);
+    issue_at(HT_B1, t + 1, (long)(ks_begin + t + 1) * KT);
     COMPUTE_PHASE(0, 1, b1f)
     // ===== phase 2 : reads A1 ; A1 x B1 ; issues A0(t+2)
     READ_A(1)
@@ -220,7 +249,7 @@ __global__ __launch_bounds__(NT) void gemm_bf16_256_kernel(GemmArgs p) {
     COMPUTE_PHASE(2, 1, b1f)
     // ===== phase 3 : no LDS reads ; A1 x B0 ; issues B0(t+2) ; retires A0(t+1), B0(t+1)
     WAIT_VM(6);
-    issue_at(HT_B0, t + 2, (long)(ks_begin + t + 2) * 64);
+    issue_at(HT_B0, t + 2, (long)(ks_begin + t + 2) * KT);
     advance();
     COMPUTE_PHASE(2, 0, b0f)
   }
@@ -269,7 +298,7 @@ __global__ __launch_bounds__(NT) void gemm_bf16_256_kernel(GemmArgs p) {
     }
     __builtin_amdgcn_sched_barrier(0);
     WAIT_VM(8);
-    issue_at(HT_B1, t + 1, (long)(ks_begin + t + 1) * 64);
+    issue_at(HT_B1, t + 1, (long)(ks_begin + t + 1) * KT);
     COMPUTE_PHASE(0, 2, b1f)
     // ===== phase 2 : reads A1 ; computes A1 x B1 ; issues A0(t+2) ; nothing to retire (phase 3 reads nothing)
 #pragma unroll
@@ -283,7 +312,7 @@ __global__ __launch_bounds__(NT) void gemm_bf16_256_kernel(GemmArgs p) {
     COMPUTE_PHASE(4, 2, b1f)
     // ===== phase 3 : no LDS reads ; computes A1 x B0 ; issues B0(t+2) ; retires A0(t+1), B0(t+1) (next phase 0)
     WAIT_VM(6);
-    issue_at(HT_B0, t + 2, (long)(ks_begin + t + 2) * 64);
+    issue_at(HT_B0, t + 2, (long)(ks_begin + t + 2) * KT);
     advance();
     COMPUTE_PHASE(4, 0, b0f)
   }
@@ -340,16 +369,16 @@ __global__ __launch_bounds__(NT) void gemm_bf16_256_kernel(GemmArgs p) {
   }
 }
 
-int gr_launch_gemm256(const GemmArgs& p, hipStream_t stream) {
+int G256_LAUNCH(const GemmArgs& p, hipStream_t stream) {
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+    hipError_t e = hipFuncSetAttribute((const void*)G256_KERNEL, hipFuncAttributeMaxDynamicSharedMemorySize,
                                        2 * STAGE_BYTES);
     if (e != hipSuccess) return (int)e;
     attr_set = true;
   }
   dim3 grid(p.tiles_m * p.tiles_n, p.splits);
-  hipLaunchKernelGGL(gemm_bf16_256_kernel, grid, dim3(NT), 2 * STAGE_BYTES, stream, p);
+  hipLaunchKernelGGL(G256_KERNEL, grid, dim3(NT), 2 * STAGE_BYTES, stream, p);
   GR_CHECK_LAUNCH();
   return GR_OK;
 }

@@ -17,6 +17,8 @@ struct GemmArgs {
   const float* bias;
   const float* scale;
   const float* resid;
+  const float* a_scale;  // fp8 path: per-row dequantisation scale of A [M] (or null)
+  const float* w_scale;  // fp8 path: per-output-channel scale of W [N] (or null)
   float* ws;
   int M, N, K;
   long lda, ldw, ldc, ldr;
@@ -141,11 +143,12 @@ __device__ __forceinline__ f32x4 epi_math4(const GemmArgs& p, f32x4 v, int m, lo
 // are loaded ONCE per thread (zero / one when absent).
 template <int W4>
 struct EpiCols {
-  f32x4 bias[W4], scale[W4];
+  f32x4 bias[W4], scale[W4], wsc[W4];
   __device__ __forceinline__ void load(const GemmArgs& p, int n) {
 #pragma unroll
     for (int w = 0; w < W4; ++w) {
       const bool in = n + 4 * w < p.N;
+      wsc[w] = (p.w_scale && in) ? *(const f32x4*)(p.w_scale + n + 4 * w) : (f32x4){1.f, 1.f, 1.f, 1.f};
       bias[w] = (p.bias && in) ? *(const f32x4*)(p.bias + n + 4 * w) : (f32x4){0.f, 0.f, 0.f, 0.f};
       scale[w] = (p.scale && in) ? *(const f32x4*)(p.scale + n + 4 * w) : (f32x4){1.f, 1.f, 1.f, 1.f};
     }
@@ -159,6 +162,11 @@ __device__ __forceinline__ void epi_from_stage(const GemmArgs& p, const char* ba
   f32x4 v[W4];
 #pragma unroll
   for (int w = 0; w < W4; ++w) v[w] = stage_read4<COLS>(base, srow, c4 + w);
+  if (p.w_scale) {  // fp8: dequantise  acc * a_scale[m] * w_scale[n]
+    const float as = p.a_scale ? p.a_scale[m] : 1.f;
+#pragma unroll
+    for (int w = 0; w < W4; ++w) v[w] = v[w] * ec.wsc[w] * as;
+  }
   const int n = n0 + c4 * 4;
   if (p.splits > 1) {
 #pragma unroll
@@ -213,3 +221,5 @@ __device__ __forceinline__ void epi_from_stage(const GemmArgs& p, const char* ba
 int gr_launch_gemv(const GemmArgs& p, hipStream_t stream);
 // 256x256x64 ping-pong kernel (gemm_bf16_256.hip)
 int gr_launch_gemm256(const GemmArgs& p, hipStream_t stream);
+// OCP-fp8 build of the same kernel (gemm_fp8_256.hip); A/W are e4m3 bytes, K % 128 == 0
+int gr_launch_gemm256_fp8(const GemmArgs& p, hipStream_t stream);

@@ -70,16 +70,31 @@ class VitEngine:
         q = ws.get("vit_q", (bs, H, T, hd), BF16)
         k = ws.get("vit_k", (bs, H, Tp, hd), BF16)
         vt = ws.get("vit_vt", (bs, H, hd, Tp), BF16)
+        fp8 = w["fp8"]
+
+        def lin(x_f32, ln_g, ln_b, wt, **kw):
+            """LayerNorm -> GEMM (bf16 operands, or e4m3 operands with dynamic per-row activation scales)"""
+            if fp8:
+                x8, sx = ops.norm_fp8(x_f32, ln_g, ln_b, self.eps, False)
+                return ops.gemm(x8, wt[0], a_scale=sx, w_scale=wt[1], **kw)
+            x = ops.layernorm(x_f32, ln_g, ln_b, self.eps, out_bf16=True, out=ws.get("vit_x", (M, D), BF16))
+            return ops.gemm(x, wt[0], **kw)
+
+        def lin_bf16(x_bf16, wt, **kw):
+            if fp8:
+                x8, sx = ops.quant_rows_fp8(x_bf16)
+                return ops.gemm(x8, wt[0], a_scale=sx, w_scale=wt[1], **kw)
+            return ops.gemm(x_bf16, wt[0], **kw)
+
         for i, L in enumerate(w["layers"]):
-            x = ops.layernorm(h, L["ln1_g"], L["ln1_b"], self.eps, out_bf16=True, out=ws.get("vit_x", (M, D), BF16))
-            qkv = ops.gemm(x, L["wqkv"], bias=L["bqkv"], out=ws.get("vit_qkv", (M, 3 * D), BF16))
+            qkv = lin(h, L["ln1_g"], L["ln1_b"], L["wqkv"], bias=L["bqkv"], out=ws.get("vit_qkv", (M, 3 * D), BF16))
             ops.qkv_split(qkv, q, k, vt, B=bs, H=H, L=T, hd=hd)
             ctx = ops.attention(q, k, vt, Skv=T, causal=False, out=ws.get("vit_ctx", (M, D), BF16))
-            ops.gemm(ctx, L["wo"], bias=L["bo"], scale=L["ls1"], resid=h, out=mid, out_f32=True)
-            x = ops.layernorm(mid, L["ln2_g"], L["ln2_b"], self.eps, out_bf16=True, out=ws.get("vit_x", (M, D), BF16))
-            y = ops.gemm(x, L["w1"], bias=L["b1"], act=1, out=ws.get("vit_y", (M, L["w1"].shape[0]), BF16))
+            lin_bf16(ctx, L["wo"], bias=L["bo"], scale=L["ls1"], resid=h, out=mid, out_f32=True)
+            y = lin(mid, L["ln2_g"], L["ln2_b"], L["w1"], bias=L["b1"], act=1,
+                    out=ws.get("vit_y", (M, L["w1"][0].shape[0]), BF16))
             hn = out_buf(i + 1)
-            ops.gemm(y, L["w2"], bias=L["b2"], scale=L["ls2"], resid=mid, out=hn, out_f32=True)
+            lin_bf16(y, L["w2"], bias=L["b2"], scale=L["ls2"], resid=mid, out=hn, out_f32=True)
             h = hn
         first = nl + 1 - self.keep
         return [out_buf(j) for j in range(max(first, 0), nl + 1)]
@@ -292,16 +307,30 @@ class LlamaEngine:
         if past + L > cache.smax:
             cache.grow(_ru(past + L + 64, 64))
         q = ws.get("llm_q", (bs, H, L, hd), BF16)
+        fp8 = w["fp8"]
+
+        def lin(x_f32, gain, wt, **kw):
+            """RMSNorm -> GEMM (bf16 operands, or e4m3 operands with dynamic per-row activation scales)"""
+            if fp8:
+                x8, sx = ops.norm_fp8(x_f32, gain, None, self.eps, True)
+                return ops.gemm(x8, wt[0], a_scale=sx, w_scale=wt[1], **kw)
+            x = ops.rmsnorm(x_f32, gain, self.eps, out=ws.get("llm_x", (M, T), BF16))
+            return ops.gemm(x, wt[0], **kw)
+
+        def lin_bf16(x_bf16, wt, **kw):
+            if fp8:
+                x8, sx = ops.quant_rows_fp8(x_bf16)
+                return ops.gemm(x8, wt[0], a_scale=sx, w_scale=wt[1], **kw)
+            return ops.gemm(x_bf16, wt[0], **kw)
+
         for i, Lw in enumerate(w["layers"]):
-            x = ops.rmsnorm(h, Lw["n1"], self.eps, out=ws.get("llm_x", (M, T), BF16))
-            qkv = ops.gemm(x, Lw["wqkv"], out=ws.get("llm_qkv", (M, 3 * T), BF16))
+            qkv = lin(h, Lw["n1"], Lw["wqkv"], out=ws.get("llm_qkv", (M, 3 * T), BF16))
             ops.qkv_split(qkv, q, cache.k[i], cache.vt[i], B=bs, H=H, L=L, hd=hd, pos0=past, cos=w["cos"], sin=w["sin"])
             ctx = ops.attention(q, cache.k[i], cache.vt[i], Skv=past + L, causal=True, q_pos0=past, kv_len=kv_len,
                                 out=ws.get("llm_ctx", (M, T), BF16))
-            ops.gemm(ctx, Lw["wo"], resid=h, out=h, out_f32=True)
-            x = ops.rmsnorm(h, Lw["n2"], self.eps, out=ws.get("llm_x", (M, T), BF16))
-            y = ops.gemm(x, Lw["wgu"], act=3, out=ws.get("llm_y", (M, self.I), BF16))
-            ops.gemm(y, Lw["wd"], resid=h, out=h, out_f32=True)
+            lin_bf16(ctx, Lw["wo"], resid=h, out=h, out_f32=True)
+            y = lin(h, Lw["n2"], Lw["wgu"], act=3, out=ws.get("llm_y", (M, self.I), BF16))
+            lin_bf16(y, Lw["wd"], resid=h, out=h, out_f32=True)
         cache.seq_len = past + L
         hn = ops.rmsnorm(h, w["norm"], self.eps, out=ws.get("llm_x", (M, T), BF16))
         if not all_logits and L > 1:

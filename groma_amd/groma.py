@@ -63,8 +63,9 @@ def _box_iou(b1, b2):  # torchvision.ops.box_iou on a handful of host-side boxes
 class GromaModel:
     config_class = GromaConfig
 
-    def __init__(self, config: GromaConfig, source=None, device="cuda"):
+    def __init__(self, config: GromaConfig, source=None, device="cuda", fp8=False):
         self.config = config
+        self.fp8 = bool(fp8)  # BASELINE configs[4]: OCP e4m3 operands for the DINOv2 and LLaMA GEMMs (extension)
         self.device = torch.device(device)
         self.training = False
         self.pad_token_id = None
@@ -87,11 +88,11 @@ class GromaModel:
         ops._lib.load()  # fail loudly if the HIP library is missing
         cfg = self.config
         self._ws = engine.Workspace(self.device)
-        self.vit = engine.VitEngine(weights.pack_vit(source, cfg), cfg, self._ws)
+        self.vit = engine.VitEngine(weights.pack_vit(source, cfg, self.fp8), cfg, self._ws)
         self.proposer = engine.ProposerEngine(weights.pack_ddetr(source, cfg), cfg, self._ws)
         self.region = engine.RegionEngine(weights.pack_region(source, cfg), cfg, self._ws)
         self.bridge = weights.pack_bridge(source, cfg)
-        self.llm = engine.LlamaEngine(weights.pack_llm(source, cfg), cfg, self._ws)
+        self.llm = engine.LlamaEngine(weights.pack_llm(source, cfg, self.fp8), cfg, self._ws)
         self._loaded = True
 
     def _side_stream(self):
@@ -108,13 +109,13 @@ class GromaModel:
         return c
 
     @classmethod
-    def from_state_dict(cls, config, state_dict, device="cuda"):
-        return cls(config, weights.Source.from_state_dict(state_dict, torch.device(device)), device)
+    def from_state_dict(cls, config, state_dict, device="cuda", fp8=False):
+        return cls(config, weights.Source.from_state_dict(state_dict, torch.device(device)), device, fp8=fp8)
 
     @classmethod
-    def from_synthetic(cls, config, seed=0, device="cuda"):
+    def from_synthetic(cls, config, seed=0, device="cuda", fp8=False):
         """Random-init weights of the configured architecture, generated on the device (benchmark path)."""
-        return cls(config, weights.Source.synthetic(config, seed, torch.device(device)), device)
+        return cls(config, weights.Source.synthetic(config, seed, torch.device(device)), device, fp8=fp8)
 
     @classmethod
     def from_pretrained(cls, path, torch_dtype=None, device="cuda", **kw):

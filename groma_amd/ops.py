@@ -11,6 +11,7 @@ from . import _lib
 from ._lib import GemmDesc
 
 BF16, F32, I32, I64 = torch.bfloat16, torch.float32, torch.int32, torch.int64
+FP8 = torch.float8_e4m3fn  # OCP e4m3 (gfx950 native)
 
 
 def _stream():
@@ -44,13 +45,23 @@ def _gemv_ws(splits, M, N, device):
 
 
 def gemm(a, w, *, out=None, bias=None, scale=None, resid=None, act=0, out_f32=False, splits=1, ws=None,
-         M=None, lda=None, conv=None, resid_mod=0, row_map=None, ldc=None, ldr=None, tile=0):
+         M=None, lda=None, conv=None, resid_mod=0, row_map=None, ldc=None, ldr=None, tile=0,
+         a_scale=None, w_scale=None):
     """out[M,N] = epilogue(a[M,K] @ w[N,K]^T).  `conv=(imgs,H,W,C,seg_stride)` switches A to the implicit
     3x3 gather over zero-bordered NHWC maps (then M = imgs*H*W, K = w.shape[1])."""
     lib = _lib.load()
-    _chk(a, BF16, "a"); _chk(w, BF16, "w")
+    fp8 = w.dtype == FP8
+    if fp8:
+        _chk(a, FP8, "a"); _chk(w, FP8, "w")
+        if w_scale is None:
+            raise ValueError("fp8 gemm needs w_scale")
+    else:
+        _chk(a, BF16, "a"); _chk(w, BF16, "w")
     N, K = w.shape
     d = GemmDesc()
+    d.fp8 = int(fp8)
+    d.a_scale = _chk(a_scale, F32, "a_scale").data_ptr() if a_scale is not None else None
+    d.w_scale = _chk(w_scale, F32, "w_scale").data_ptr() if w_scale is not None else None
     if conv is not None:
         imgs, H, W_, C, seg = conv
         M = imgs * H * W_
@@ -62,7 +73,7 @@ def gemm(a, w, *, out=None, bias=None, scale=None, resid=None, act=0, out_f32=Fa
         d.lda = lda if lda is not None else a.shape[-1]
         if a.shape[-1] != K and lda is None:
             raise ValueError(f"gemm: K mismatch {a.shape[-1]} vs {K}")
-    if tile == 0 and conv is None and M <= 8 and splits == 1 and N * K >= (1 << 20):
+    if tile == 0 and conv is None and not fp8 and M <= 8 and splits == 1 and N * K >= (1 << 20):
         tile, splits = 1, (K + 511) // 512  # decode step: weight-streaming kernel + deterministic split-K reduce
         ws = _gemv_ws(splits, M, N, a.device)
     n_out = N // 2 if act == 3 else N
@@ -344,3 +355,26 @@ def prof_read_launches(cap=65536):
                "gr_prof_read_launches")
     k = min(n.value, cap)
     return [(int(mnk[i, 0]), int(mnk[i, 1]), int(mnk[i, 2]), int(mnk[i, 3]), float(ms[i])) for i in range(k)]
+
+
+def quant_rows_fp8(x):
+    """x bf16|f32 [rows, K] -> (q e4m3 [rows, K], scale f32 [rows]) with x ~= q * scale[:, None]"""
+    lib = _lib.load()
+    K = x.shape[-1]
+    rows = x.numel() // K
+    q = torch.empty((rows, K), dtype=FP8, device=x.device)
+    s = torch.empty((rows,), dtype=F32, device=x.device)
+    _lib.check(lib.gr_quant_rows_fp8(_p(x), int(x.dtype == F32), _p(q), _p(s), rows, K, K, _stream()), "gr_quant_rows_fp8")
+    return q, s
+
+
+def norm_fp8(x, gamma, beta, eps, rms):
+    """RMSNorm / LayerNorm of f32 rows, emitted as e4m3 + per-row scale"""
+    lib = _lib.load()
+    _chk(x, F32, "x")
+    C = x.shape[-1]
+    rows = x.numel() // C
+    q = torch.empty((rows, C), dtype=FP8, device=x.device)
+    s = torch.empty((rows,), dtype=F32, device=x.device)
+    _lib.check(lib.gr_norm_fp8(_p(x), _p(gamma), _p(beta), _p(q), _p(s), rows, C, eps, int(rms), _stream()), "gr_norm_fp8")
+    return q, s

@@ -54,6 +54,21 @@ def bf(t):
     return t.to(BF16).contiguous()
 
 
+FP8 = torch.float8_e4m3fn
+
+
+def q8(t):
+    """per-output-channel OCP e4m3 quantisation of a [N,K] weight: (w8, scale[N]) with w ~= w8 * scale[:, None]"""
+    t = t.float()
+    s = (t.abs().amax(dim=1).clamp_min(1e-20) / 448.0).contiguous()
+    return (t / s[:, None]).to(FP8).contiguous(), s
+
+
+def wq(t, fp8):
+    """GEMM weight in the compute format of the engine: bf16, or (e4m3, per-row scale)"""
+    return q8(t) if fp8 else (bf(t), None)
+
+
 def pad_k(w, K):
     out = torch.zeros((w.shape[0], K), dtype=w.dtype, device=w.device)
     out[:, : w.shape[1]] = w
@@ -78,7 +93,7 @@ def vit_pos_embed_4_32(pos, grid):
     return torch.cat((pos[0, :1], patch), dim=0)
 
 
-def pack_vit(W, cfg):
+def pack_vit(W, cfg, fp8=False):
     vc = cfg.perceiver_cfg.vis_encoder_cfg
     D, P = vc.hidden_size, vc.patch_size
     grid = cfg.image_size // P
@@ -88,20 +103,20 @@ def pack_vit(W, cfg):
     pw = W(v + "embeddings.patch_embeddings.projection.weight").reshape(D, -1)
     pos = vit_pos_embed_4_32(W(v + "embeddings.position_embeddings"), grid).to(dev)
     cls = W(v + "embeddings.cls_token").reshape(D)
-    out = dict(grid=grid, Kpad=Kp, patch_w=bf(pad_k(pw, Kp)), patch_b=W(v + "embeddings.patch_embeddings.projection.bias"),
+    out = dict(fp8=fp8, grid=grid, Kpad=Kp, patch_w=bf(pad_k(pw, Kp)), patch_b=W(v + "embeddings.patch_embeddings.projection.bias"),
                cls_pos0=(cls + pos[0]).contiguous(), pos_patch=pos[1:].contiguous(), layers=[])
     for i in range(vc.num_hidden_layers):
         p = f"{v}encoder.layer.{i}."
         a = p + "attention.attention."
         out["layers"].append(dict(
             ln1_g=W(p + "norm1.weight"), ln1_b=W(p + "norm1.bias"),
-            wqkv=bf(torch.cat([W(a + "query.weight"), W(a + "key.weight"), W(a + "value.weight")], 0)),
+            wqkv=wq(torch.cat([W(a + "query.weight"), W(a + "key.weight"), W(a + "value.weight")], 0), fp8),
             bqkv=torch.cat([W(a + "query.bias"), W(a + "key.bias"), W(a + "value.bias")], 0).contiguous(),
-            wo=bf(W(p + "attention.output.dense.weight")), bo=W(p + "attention.output.dense.bias"),
+            wo=wq(W(p + "attention.output.dense.weight"), fp8), bo=W(p + "attention.output.dense.bias"),
             ls1=W(p + "layer_scale1.lambda1"),
             ln2_g=W(p + "norm2.weight"), ln2_b=W(p + "norm2.bias"),
-            w1=bf(W(p + "mlp.fc1.weight")), b1=W(p + "mlp.fc1.bias"),
-            w2=bf(W(p + "mlp.fc2.weight")), b2=W(p + "mlp.fc2.bias"),
+            w1=wq(W(p + "mlp.fc1.weight"), fp8), b1=W(p + "mlp.fc1.bias"),
+            w2=wq(W(p + "mlp.fc2.weight"), fp8), b2=W(p + "mlp.fc2.bias"),
             ls2=W(p + "layer_scale2.lambda1")))
     return out
 
@@ -219,10 +234,10 @@ def pack_region(W, cfg):
     return out
 
 
-def pack_llm(W, cfg):
+def pack_llm(W, cfg, fp8=False):
     lc = cfg.llm_cfg
     T, I = lc.hidden_size, lc.intermediate_size
-    out = dict(layers=[])
+    out = dict(layers=[], fp8=fp8)
     out["embed"] = bf(W("llm.model.embed_tokens.weight"))
     out["new_embed"] = bf(W("new_input_embs.weight"))
     for i in range(lc.num_hidden_layers):
@@ -230,12 +245,12 @@ def pack_llm(W, cfg):
         gate, up = W(p + "mlp.gate_proj.weight"), W(p + "mlp.up_proj.weight")
         out["layers"].append(dict(
             n1=W(p + "input_layernorm.weight"),
-            wqkv=bf(torch.cat([W(p + "self_attn.q_proj.weight"), W(p + "self_attn.k_proj.weight"),
-                               W(p + "self_attn.v_proj.weight")], 0)),
-            wo=bf(W(p + "self_attn.o_proj.weight")),
+            wqkv=wq(torch.cat([W(p + "self_attn.q_proj.weight"), W(p + "self_attn.k_proj.weight"),
+                               W(p + "self_attn.v_proj.weight")], 0), fp8),
+            wo=wq(W(p + "self_attn.o_proj.weight"), fp8),
             n2=W(p + "post_attention_layernorm.weight"),
-            wgu=bf(torch.stack([gate, up], 1).reshape(2 * I, T)),  # interleaved rows: gate_0, up_0, gate_1, ...
-            wd=bf(W(p + "mlp.down_proj.weight"))))
+            wgu=wq(torch.stack([gate, up], 1).reshape(2 * I, T), fp8),  # interleaved rows: gate_0, up_0, gate_1, ...
+            wd=wq(W(p + "mlp.down_proj.weight"), fp8)))
     out["norm"] = W("llm.model.norm.weight")
     V = lc.vocab_size + cfg.num_new_token
     Vp = _ru(V, 128)

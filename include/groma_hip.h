@@ -26,7 +26,7 @@ extern "C" {
 typedef struct ihipStream_t* hipStream_t;
 #endif
 
-#define GROMA_HIP_ABI_VERSION 1
+#define GROMA_HIP_ABI_VERSION 2
 int gr_abi_version(void);
 /* kernel timing hook used by bench.py: when enabled, every gr_gemm_bf16 launch is bracketed by HIP
  * events on its own stream; gr_prof_read drains them (sync) and returns total ms + launch count. */
@@ -62,6 +62,11 @@ typedef struct gr_gemm_desc {
   int c_group, c_group_stride, c_row_off;
   int tile;           /* 0 = choose per shape; 128 / 256 force the 128x128 / 256x256 kernel; 1 = skinny decode
                          kernel (M <= 8; requires splits == ceil(K/512) and ws)                        */
+  /* OCP fp8 (e4m3) operands (BASELINE configs[4]): A, W are 1-byte elements, K % 128 == 0, no conv gather;
+   * the result is dequantised as acc * a_scale[m] * w_scale[n] before the rest of the epilogue */
+  int fp8;
+  const float* a_scale; /* [M] per-row scale of A, or NULL (= 1)                                     */
+  const float* w_scale; /* [N] per-output-channel scale of W (required when fp8)                     */
 } gr_gemm_desc;
 int gr_gemm_bf16(const gr_gemm_desc* d, hipStream_t stream);
 
@@ -74,6 +79,10 @@ int gr_gemm_f32(const float* A, const float* W, float* C, const float* bias, con
 /* out = LN(x (+ add)) * gamma + beta over C (C % 256 == 0, C <= 4096); out bf16 or f32. */
 int gr_layernorm(const float* x, const float* add, const float* gamma, const float* beta, void* out, int rows, int C,
                  long ldx, long ldo, float eps, int out_bf16, int relu_in, hipStream_t stream);
+/* fp8 row quantisation: q = e4m3(x / s), s[m] = max|x[m,:]| / 448 ; and the fused norm -> fp8 variant */
+int gr_quant_rows_fp8(const void* x, int x_is_f32, void* q, float* scale, int rows, int K, long ldx, hipStream_t stream);
+int gr_norm_fp8(const float* x, const float* gamma, const float* beta, void* q, float* scale, int rows, int C, float eps,
+                int rms, hipStream_t stream);
 /* HF LlamaRMSNorm */
 int gr_rmsnorm(const float* x, const float* gamma, void* out, int rows, int C, long ldx, long ldo, float eps,
                int out_bf16, hipStream_t stream);

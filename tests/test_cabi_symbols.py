@@ -22,7 +22,7 @@ def test_header_symbols_are_exported_and_typed():
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/groma_hip.h but not exported"
     assert set(names) == set(_lib.SIGNATURES), "ctypes signature table out of sync with the header"
-    assert _lib.load().gr_abi_version() == 1
+    assert _lib.load().gr_abi_version() == 2
 
 
 def test_bad_arguments_are_rejected_without_a_gpu():

@@ -38,8 +38,8 @@ def test_from_pretrained_safetensors_and_bin(tmp_path):
     for m in (m1, m2):
         assert m.config.to_dict() == cfg.to_dict()
         assert torch.equal(m.llm.w["head"], ref.llm.w["head"])
-        assert torch.equal(m.llm.w["layers"][1]["wgu"], ref.llm.w["layers"][1]["wgu"])
-        assert torch.equal(m.vit.w["layers"][0]["wqkv"], ref.vit.w["layers"][0]["wqkv"])
+        assert torch.equal(m.llm.w["layers"][1]["wgu"][0], ref.llm.w["layers"][1]["wgu"][0])
+        assert torch.equal(m.vit.w["layers"][0]["wqkv"][0], ref.vit.w["layers"][0]["wqkv"][0])
         assert torch.equal(m.region.w["flat_w"], ref.region.w["flat_w"])
         assert torch.equal(m.proposer.w["dec"][0]["qk_w"], ref.proposer.w["dec"][0]["qk_w"])
 
@@ -49,7 +49,7 @@ def test_packed_layouts_match_their_definitions():
     m = GromaModel.from_state_dict(cfg, sd, device="cpu")
     lc = cfg.llm_cfg
     # gate/up interleave: row 2i = gate_i, row 2i+1 = up_i
-    wgu = m.llm.w["layers"][0]["wgu"].float()
+    wgu = m.llm.w["layers"][0]["wgu"][0].float()
     assert torch.equal(wgu[0::2], sd["llm.model.layers.0.mlp.gate_proj.weight"].bfloat16().float())
     assert torch.equal(wgu[1::2], sd["llm.model.layers.0.mlp.up_proj.weight"].bfloat16().float())
     # head = lm_head (+) extra_lm_head, zero padded to a multiple of 128 rows

@@ -361,3 +361,46 @@ def test_ddetr_small(dev):
     assert relerr(ops.box_refine(tmp, r0), (tmp + inv).sigmoid()) < 1e-6
     a, b = rnd((600,), dev, seed=6), rnd((600,), dev, seed=7)
     assert relerr(ops.score_fuse(a, b, 600), a.sigmoid() ** 0.4 * b.sigmoid() ** 0.6) < 1e-6
+
+
+def _q_ref(x):
+    s = x.float().abs().amax(-1).clamp_min(1e-20) / 448.0
+    return (x.float() / s[:, None]).to(torch.float8_e4m3fn), s
+
+
+@pytest.mark.parametrize("M,N,K", [(300, 512, 256), (2328, 4096, 4096), (100, 260, 1408), (4074, 1024, 11008)])
+def test_gemm_fp8(dev, M, N, K):
+    """fp8 (OCP e4m3) GEMM = exact products of the quantised operands, fp32 accumulation, scales in the epilogue"""
+    ops = _ops()
+    if K % 128:
+        K = (K // 128) * 128
+    a = rnd((M, K), dev, seed=1)
+    w = rnd((N, K), dev, 0.05, seed=2)
+    a8, sa = ops.quant_rows_fp8(a.bfloat16())
+    r8, rs = _q_ref(a.bfloat16())
+    # x*(1/s) (kernel) vs x/s (reference) may differ by one fp32 ulp before the e4m3 rounding: allow rare 1-step flips
+    assert torch.allclose(sa, rs, rtol=1e-6)
+    assert (a8.view(torch.uint8) == r8.view(torch.uint8)).float().mean().item() > 0.995
+    assert relerr(a8.float() * sa[:, None], r8.float() * rs[:, None]) < 6e-3  # <=0.5% of bytes one e4m3 step off (x*rcp vs x/s ties)
+    w8, sw = _q_ref(w)
+    ref = ((a8.double() * sa[:, None].double()) @ (w8.double() * sw[:, None].double()).t()).float()
+    out = ops.gemm(a8, w8, a_scale=sa, w_scale=sw, out_f32=True)
+    assert relerr(out, ref) < 5e-5  # exact e4m3 products, f32 accumulation over K vs f64
+    bias, resid = rnd((N,), dev, seed=3), rnd((M, N), dev, seed=4)
+    out = ops.gemm(a8, w8, a_scale=sa, w_scale=sw, bias=bias, resid=resid, out_f32=True)
+    assert relerr(out, ref + bias + resid) < 5e-5
+    assert relerr(ops.gemm(a8, w8, a_scale=sa, w_scale=sw), ref) < 4e-3
+    # and the fp8 result tracks the unquantised product at the e4m3 noise level
+    assert relerr(out - bias - resid, a.bfloat16().float() @ w.float().t()) < 6e-2
+
+
+def test_norm_fp8(dev):
+    ops = _ops()
+    x = rnd((37, 1024), dev, 2.0, seed=1) + 0.3
+    g, b = rnd((1024,), dev, seed=2), rnd((1024,), dev, seed=3)
+    q, s = ops.norm_fp8(x, g, None, 1e-5, True)
+    ref = g * (x * torch.rsqrt(x.pow(2).mean(-1, keepdim=True) + 1e-5))
+    assert relerr(q.float() * s[:, None], ref) < 4e-2
+    assert (q.float().abs().amax(-1) == 448).all()
+    q, s = ops.norm_fp8(x, g, b, 1e-6, False)
+    assert relerr(q.float() * s[:, None], F.layer_norm(x, (1024,), g, b, 1e-6)) < 4e-2
