@@ -45,8 +45,8 @@ SIGNATURES = {
     "gr_norm_fp8": [_P, _P, _P, _P, _P, _I, _I, _F, _I, _P],
     "gr_layernorm": [_P, _P, _P, _P, _P, _I, _I, _L, _L, _F, _I, _I, _P],
     "gr_rmsnorm": [_P, _P, _P, _I, _I, _L, _L, _F, _I, _P],
-    "gr_attention_bf16": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _F, _P],
-    "gr_qkv_split": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "gr_attention_bf16": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _F, _P, _I, _P],
+    "gr_qkv_split": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _I, _P],
     "gr_patchify": [_P, _P, _I, _I, _I, _I, _P],
     "gr_fill_rows_f32": [_P, _P, _I, _I, _L, _P],
     "gr_mean4_tokens": [_P, _P, _P, _P, _P, _I, _I, _I, _P],
@@ -61,6 +61,7 @@ SIGNATURES = {
     "gr_embed_gather": [_P, _P, _P, _P, _L, _I, _I, _I, _P],
     "gr_scatter_rows_f32": [_P, _P, _P, _L, _I, _P],
     "gr_argmax_rows": [_P, _P, _I, _I, _L, _P],
+    "gr_greedy_advance": [_P, _P, _P, _P, _P, _P, _P, _I, _L, _L, _I, _I, _I, _P],
     "gr_msda_f32": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "gr_mha32_f32": [_P, _P, _P, _I, _I, _I, _I, _F, _P],
     "gr_ddetr_topk_gather": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
@@ -88,7 +89,7 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
         fn.argtypes = argtypes
         fn.restype = c_int
-    if lib.gr_abi_version() != 2:
+    if lib.gr_abi_version() != 3:
         raise RuntimeError("libgroma_hip.so ABI version mismatch")
     _lib = lib
     return lib

@@ -29,6 +29,8 @@ struct AttnArgs {
   const bf16_t* vt;
   bf16_t* out;
   const int* kv_len;  // [B] or null
+  const int* pos_dev;  // or null: q_pos0 of row b = pos_dev[b * pos_stride], Skv = q_pos0 + Lq (device-resident step)
+  int pos_stride;
   int B, H, Lq, Skv, kv_stride;
   int causal, q_pos0;
   float scale_log2;  // softmax scale * log2(e)
@@ -61,7 +63,9 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(AttnArgs p) {
   const bf16_t* Kp = p.k + (long)bh * p.kv_stride * HD;
   const bf16_t* Vp = p.vt + (long)bh * HD * p.kv_stride;
 
-  int kvmax = p.Skv;
+  const int q_pos0 = p.pos_dev ? p.pos_dev[b * p.pos_stride] : p.q_pos0;
+  const int Skv = p.pos_dev ? q_pos0 + p.Lq : p.Skv;
+  int kvmax = Skv;
   if (p.kv_len) kvmax = min(kvmax, p.kv_len[b]);
 
   // this lane's query rows (B-operand columns), one per q-tile -- clamp the tail
@@ -75,16 +79,16 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(AttnArgs p) {
     if (!q_valid[u]) qi[u] = p.Lq - 1;
 #pragma unroll
     for (int kk = 0; kk < HD / 32; ++kk) qf[u][kk] = *(const bf16x8*)(Qp + (long)qi[u] * HD + kk * 32 + fg * 8);
-    limit[u] = p.causal ? min(kvmax, p.q_pos0 + qi[u] + 1) : kvmax;  // keys [0, limit) visible
+    limit[u] = p.causal ? min(kvmax, q_pos0 + qi[u] + 1) : kvmax;  // keys [0, limit) visible
   }
   // loop bounds: block-level (staging + barriers) and wave-level (compute)
   const int blk_last = min(q0 + 64 * QT - 1, p.Lq - 1);
   const int wav_last = min(q0 + wave * (16 * QT) + 16 * QT - 1, p.Lq - 1);
-  const int blk_limit = p.causal ? min(kvmax, p.q_pos0 + blk_last + 1) : kvmax;
-  const int wav_limit = p.causal ? min(kvmax, p.q_pos0 + wav_last + 1) : kvmax;
+  const int blk_limit = p.causal ? min(kvmax, q_pos0 + blk_last + 1) : kvmax;
+  const int wav_limit = p.causal ? min(kvmax, q_pos0 + wav_last + 1) : kvmax;
   const int ntiles = (blk_limit + KV - 1) / KV;
   const int wav_first = min(q0 + wave * (16 * QT), p.Lq - 1);
-  const int wav_min_limit = p.causal ? min(kvmax, p.q_pos0 + wav_first + 1) : kvmax;  // min over the wave's rows
+  const int wav_min_limit = p.causal ? min(kvmax, q_pos0 + wav_first + 1) : kvmax;  // min over the wave's rows
 
   f32x4 o[QT][HD / 16];
   float m_run[QT], l_run[QT];
@@ -108,7 +112,7 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(AttnArgs p) {
       const int row = q / KCH, pos = q % KCH;
       const int c = pos ^ kswz(row);
       int kr = kv0 + row;
-      if (kr > p.Skv - 1) kr = p.Skv - 1;
+      if (kr > Skv - 1) kr = Skv - 1;
       __builtin_amdgcn_global_load_lds((gptr_t)(Kp + (long)kr * HD + c * 8), (lptr_t)(ksm + i * 4096 + wave * 1024), 16, 0, 0);
     }
     constexpr int NVC = HD * 8;
@@ -237,12 +241,14 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(AttnArgs p) {
 
 extern "C" int gr_attention_bf16(const void* q, const void* k, const void* vt, void* out, const int* kv_len, int B, int H,
                                  int Lq, int Skv, int kv_stride, int head_dim, int causal, int q_pos0, float scale,
+                                 const int* pos_dev, int pos_stride,
                                  hipStream_t stream) {
   if (!q || !k || !vt || !out || B <= 0 || H <= 0 || Lq <= 0 || Skv <= 0) return GR_EINVAL;
   if (kv_stride % 64 != 0 || kv_stride < Skv) return GR_EINVAL;  // Vt tile reads run to the next multiple of 64
   AttnArgs p;
   p.q = (const bf16_t*)q; p.k = (const bf16_t*)k; p.vt = (const bf16_t*)vt; p.out = (bf16_t*)out;
   p.kv_len = kv_len;
+  p.pos_dev = pos_dev; p.pos_stride = pos_stride;
   p.B = B; p.H = H; p.Lq = Lq; p.Skv = Skv; p.kv_stride = kv_stride;
   p.causal = causal; p.q_pos0 = q_pos0;
   p.scale_log2 = scale * 1.44269504088896340736f;

@@ -71,9 +71,20 @@ __device__ __forceinline__ f32x4 mfma_fp8x2(bf16x8 a, bf16x8 b, f32x4 c) {
 #define LDS_SWZ(row) ((row) & 7)
 #endif
 
+#if defined(G256_CLK) && !G256_FP8  // diagnostic build only (tests/diag/build_clk.py): shader/wall clocks of block 0 at start, loop end, exit
+__device__ unsigned long long g256_clk[6];
+extern "C" int gr_diag_clk(unsigned long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g256_clk), sizeof(g256_clk));
+}
+#define CLK_MARK(i) if (threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0) { g256_clk[i] = clock64(); g256_clk[3 + i] = wall_clock64(); }
+#else
+#define CLK_MARK(i)
+#endif
+
 __global__ __launch_bounds__(NT) void G256_KERNEL(GemmArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
+  CLK_MARK(0)
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 2, wn = wave & 3;
@@ -321,6 +332,7 @@ __global__ __launch_bounds__(NT) void G256_KERNEL(GemmArgs p) {
 
   // ---- epilogue through LDS in 4 passes of 64 rows (2 m-tiles per wave), double-buffered over the two stages ----
   __syncthreads();
+  CLK_MARK(1)
   EpiCols<4> ec4;
   EpiCols<2> ec2;
   EpiCols<1> ec1;
@@ -367,6 +379,7 @@ __global__ __launch_bounds__(NT) void G256_KERNEL(GemmArgs p) {
       }
     }
   }
+  CLK_MARK(2)
 }
 
 int G256_LAUNCH(const GemmArgs& p, hipStream_t stream) {

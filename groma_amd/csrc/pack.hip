@@ -17,10 +17,13 @@ template <int HD>
 __global__ __launch_bounds__(256) void qkv_split_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ q,
                                                         bf16_t* __restrict__ k, bf16_t* __restrict__ vt,
                                                         const float* __restrict__ cosT, const float* __restrict__ sinT,
-                                                        int B, int H, int L, int pos0, int kv_stride) {
+                                                        int B, int H, int L, int pos0_arg, int kv_stride,
+                                                        const int* __restrict__ pos_dev, int pos_stride) {
   __shared__ __attribute__((aligned(16))) bf16_t vs[64][HD + 8];
   const int t0 = blockIdx.x * 64;
   const int h = blockIdx.y, b = blockIdx.z;
+  // device-resident write position (graph-captured / ragged decode): row b appends at pos_dev[b * pos_stride]
+  const int pos0 = pos_dev ? pos_dev[b * pos_stride] : pos0_arg;
   const int tid = threadIdx.x;
   const long row_stride = 3L * H * HD;
   constexpr int HALF = HD / 2;
@@ -85,16 +88,17 @@ __global__ __launch_bounds__(256) void qkv_split_kernel(const bf16_t* __restrict
 }
 
 extern "C" int gr_qkv_split(const void* qkv, void* q, void* k, void* vt, const float* cosT, const float* sinT, int B,
-                            int H, int L, int head_dim, int pos0, int kv_stride, hipStream_t stream) {
+                            int H, int L, int head_dim, int pos0, int kv_stride, const int* pos_dev, int pos_stride,
+                            hipStream_t stream) {
   if (!qkv || !q || !k || !vt || B <= 0 || H <= 0 || L <= 0) return GR_EINVAL;
   if ((cosT == nullptr) != (sinT == nullptr)) return GR_EINVAL;
   dim3 grid(gr_cdiv(L, 64), H, B);
   if (head_dim == 128)
     hipLaunchKernelGGL(qkv_split_kernel<128>, grid, dim3(256), 0, stream, (const bf16_t*)qkv, (bf16_t*)q, (bf16_t*)k,
-                       (bf16_t*)vt, cosT, sinT, B, H, L, pos0, kv_stride);
+                       (bf16_t*)vt, cosT, sinT, B, H, L, pos0, kv_stride, pos_dev, pos_stride);
   else if (head_dim == 64)
     hipLaunchKernelGGL(qkv_split_kernel<64>, grid, dim3(256), 0, stream, (const bf16_t*)qkv, (bf16_t*)q, (bf16_t*)k,
-                       (bf16_t*)vt, cosT, sinT, B, H, L, pos0, kv_stride);
+                       (bf16_t*)vt, cosT, sinT, B, H, L, pos0, kv_stride, pos_dev, pos_stride);
   else return GR_EINVAL;
   GR_CHECK_LAUNCH();
   return GR_OK;
@@ -569,6 +573,48 @@ __global__ __launch_bounds__(256) void argmax_kernel(const float* __restrict__ x
   }
   if (threadIdx.x == 0) out[row] = si[0];
 }
+// HF 4.32 greedy_search bookkeeping for one step, entirely on the device (so the decode step is hipGraph-capturable):
+//   n = unfinished ? argmax : pad ; sequences[:, step] = n ; next input token = n ; unfinished &= (n != eos) ;
+//   step += 1 ; (inc_pos) every KV write position += 1 ; n_unfinished = sum(unfinished)
+__global__ __launch_bounds__(256) void greedy_advance_kernel(const long* __restrict__ nxt, long* __restrict__ tok,
+                                                             long* __restrict__ unfinished, long* __restrict__ seq,
+                                                             int* __restrict__ pos, int* __restrict__ step,
+                                                             int* __restrict__ n_unfinished, int rows, long eos, long pad,
+                                                             int seq_ld, int pos_rows, int inc_pos) {
+  __shared__ int cnt;
+  if (threadIdx.x == 0) cnt = 0;
+  __syncthreads();
+  const int st = *step;
+  for (int b = threadIdx.x; b < rows; b += 256) {
+    long n = nxt[b];
+    if (eos >= 0) {
+      if (!unfinished[b]) n = pad;
+      if (n == eos) unfinished[b] = 0;
+      if (unfinished[b]) atomicAdd(&cnt, 1);
+    } else {
+      atomicAdd(&cnt, 1);
+    }
+    if (st < seq_ld) seq[(long)b * seq_ld + st] = n;
+    tok[b] = n;
+  }
+  if (inc_pos)
+    for (int r = threadIdx.x; r < pos_rows; r += 256) pos[r] += 1;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    *step = st + 1;
+    *n_unfinished = cnt;
+  }
+}
+extern "C" int gr_greedy_advance(const long* nxt, long* tok, long* unfinished, long* seq, int* pos, int* step,
+                                 int* n_unfinished, int rows, long eos, long pad, int seq_ld, int pos_rows, int inc_pos,
+                                 hipStream_t stream) {
+  if (!nxt || !tok || !unfinished || !seq || !pos || !step || !n_unfinished || rows <= 0 || seq_ld <= 0) return GR_EINVAL;
+  hipLaunchKernelGGL(greedy_advance_kernel, dim3(1), dim3(256), 0, stream, nxt, tok, unfinished, seq, pos, step,
+                     n_unfinished, rows, eos, pad, seq_ld, pos_rows, inc_pos);
+  GR_CHECK_LAUNCH();
+  return GR_OK;
+}
+
 extern "C" int gr_argmax_rows(const float* x, long* out, int rows, int V, long ld, hipStream_t stream) {
   if (!x || !out || rows <= 0 || V <= 0) return GR_EINVAL;
   hipLaunchKernelGGL(argmax_kernel, dim3(rows), dim3(256), 0, stream, x, out, V, ld);

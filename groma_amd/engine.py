@@ -298,13 +298,17 @@ class LlamaEngine:
     def new_cache(self, bs, smax, device):
         return KVCache(len(self.w["layers"]), bs, self.H, self.hd, _ru(smax, 64), device)
 
-    def forward(self, h, bs, L, cache, kv_len=None, all_logits=True):
+    def forward(self, h, bs, L, cache, kv_len=None, all_logits=True, pos_dev=None, pos_stride=0):
         """h: f32 [bs*L, T] input embeddings (consumed as the residual stream, updated in place).
-        Appends L positions to `cache`.  Returns logits f32 [bs, L or 1, V] (view into a Vpad-wide buffer)."""
+        Appends L positions to `cache`.  Returns logits f32 [bs, L or 1, V] (view into a Vpad-wide buffer).
+        pos_dev (i32, device): the append position is read on the device (row b: pos_dev[b*pos_stride]) instead of
+        cache.seq_len -- no host value enters the kernel arguments, so the step can be captured in a hipGraph; the
+        caller then owns the position counter and must have sized the cache."""
         w, ws, T, H, hd = self.w, self.ws, self.T, self.H, self.hd
         M = bs * L
-        past = cache.seq_len
-        if past + L > cache.smax:
+        dyn = pos_dev is not None
+        past = 0 if dyn else cache.seq_len
+        if not dyn and past + L > cache.smax:
             cache.grow(_ru(past + L + 64, 64))
         q = ws.get("llm_q", (bs, H, L, hd), BF16)
         fp8 = w["fp8"]
@@ -325,13 +329,15 @@ class LlamaEngine:
 
         for i, Lw in enumerate(w["layers"]):
             qkv = lin(h, Lw["n1"], Lw["wqkv"], out=ws.get("llm_qkv", (M, 3 * T), BF16))
-            ops.qkv_split(qkv, q, cache.k[i], cache.vt[i], B=bs, H=H, L=L, hd=hd, pos0=past, cos=w["cos"], sin=w["sin"])
-            ctx = ops.attention(q, cache.k[i], cache.vt[i], Skv=past + L, causal=True, q_pos0=past, kv_len=kv_len,
-                                out=ws.get("llm_ctx", (M, T), BF16))
+            ops.qkv_split(qkv, q, cache.k[i], cache.vt[i], B=bs, H=H, L=L, hd=hd, pos0=past, cos=w["cos"], sin=w["sin"],
+                          pos_dev=pos_dev, pos_stride=pos_stride)
+            ctx = ops.attention(q, cache.k[i], cache.vt[i], Skv=cache.smax if dyn else past + L, causal=True, q_pos0=past,
+                                kv_len=kv_len, out=ws.get("llm_ctx", (M, T), BF16), pos_dev=pos_dev, pos_stride=pos_stride)
             lin_bf16(ctx, Lw["wo"], resid=h, out=h, out_f32=True)
             y = lin(h, Lw["n2"], Lw["wgu"], act=3, out=ws.get("llm_y", (M, self.I), BF16))
             lin_bf16(y, Lw["wd"], resid=h, out=h, out_f32=True)
-        cache.seq_len = past + L
+        if not dyn:
+            cache.seq_len = past + L
         hn = ops.rmsnorm(h, w["norm"], self.eps, out=ws.get("llm_x", (M, T), BF16))
         if not all_logits and L > 1:
             hn = hn.view(bs, L, T)[:, -1].contiguous()
@@ -339,3 +345,73 @@ class LlamaEngine:
             return logits.view(bs, 1, self.Vpad)[:, :, : self.V], hn
         logits = ops.gemm(hn, w["head"], out_f32=True, out=ws.get("llm_logits", (M, self.Vpad), F32))
         return logits.view(bs, L, self.Vpad)[:, :, : self.V], hn
+
+
+class GreedyDecoder:
+    """Decode arena for a fixed batch of rows: KV cache + device-resident loop state + ONE captured hipGraph of the
+    per-token step (embed -> 32 layers -> lm_head -> arg-max -> HF greedy_search bookkeeping).
+
+    Reference behaviour reproduced (HF 4.32 GenerationMixin.greedy_search around groma/model/groma.py:176-200,376-379):
+    every row appends at the same position past+1 (all-ones mask over the padded prefix); finished rows
+    emit `pad`; the loop ends when every row has produced `eos`.  Nothing position-dependent is a kernel argument: the
+    kernels read the step position from `pos` (gr_qkv_split / gr_attention_bf16 pos_dev), so the graph is replayed
+    unchanged for every token instead of ~330 launches per token going through the host."""
+
+    def __init__(self, llm, bs, smax, max_new, eos, pad, device):
+        self.llm, self.bs, self.eos, self.pad = llm, bs, eos, pad
+        self.cache = llm.new_cache(bs, smax, device)
+        I64, I32 = torch.int64, torch.int32
+        self.tok = torch.zeros((bs,), dtype=I64, device=device)
+        self.nxt = torch.zeros((bs,), dtype=I64, device=device)
+        self.unfinished = torch.ones((bs,), dtype=I64, device=device)
+        self.seq = torch.zeros((bs, max_new), dtype=I64, device=device)
+        self.pos = torch.zeros((1,), dtype=I32, device=device)
+        self.step = torch.zeros((1,), dtype=I32, device=device)
+        self.n_unf = torch.zeros((1,), dtype=I32, device=device)
+        self.h = torch.zeros((bs, llm.T), dtype=F32, device=device)
+        self.graph = None
+
+    def _advance(self, inc_pos):
+        ops.greedy_advance(self.nxt, self.tok, self.unfinished, self.seq, self.pos, self.step, self.n_unf,
+                           eos=self.eos, pad=self.pad, inc_pos=inc_pos)
+
+    def _step(self):
+        llm = self.llm
+        ops.embed_gather(self.tok, llm.w["embed"], llm.w["new_embed"], out=self.h)
+        llm.forward(self.h, self.bs, 1, self.cache, pos_dev=self.pos, pos_stride=0)
+        ops.argmax_rows(llm.ws.get("llm_logits", (self.bs, llm.Vpad), F32), llm.V, out=self.nxt)
+        self._advance(1)
+
+    def capture(self):
+        side = torch.cuda.Stream(device=self.tok.device)
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):  # warm-up: workspace buffers, GEMV split-K scratch, function attributes
+            for _ in range(3):
+                self.pos.zero_()
+                self._step()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            self._step()
+        self.graph = g
+
+    def run(self, first_logits, L, max_new):
+        """first_logits f32 [bs, V]: last-position logits of the prefill that filled cache[0:L).  Returns the number of
+        tokens produced; they are in self.seq[:, :n]."""
+        if max_new > self.seq.shape[1]:
+            raise ValueError("max_new exceeds the arena")
+        if self.graph is None:
+            raise RuntimeError("GreedyDecoder.capture() must run before the prefill fills the arena")
+        self.pos.fill_(L)
+        self.step.zero_()
+        self.unfinished.fill_(1)
+        ops.argmax_rows(first_logits.contiguous(), first_logits.shape[-1], out=self.nxt)
+        self._advance(0)
+        n = 1
+        while n < max_new:
+            if self.eos is not None and int(self.n_unf.item()) == 0:
+                break
+            self.graph.replay()
+            n += 1
+        return n

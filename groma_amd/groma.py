@@ -65,6 +65,7 @@ class GromaModel:
 
     def __init__(self, config: GromaConfig, source=None, device="cuda", fp8=False):
         self.config = config
+        self.decode_graph = True  # generate(): replay one captured hipGraph per token (False = eager per-kernel launches)
         self.fp8 = bool(fp8)  # BASELINE configs[4]: OCP e4m3 operands for the DINOv2 and LLaMA GEMMs (extension)
         self.device = torch.device(device)
         self.training = False
@@ -250,7 +251,7 @@ class GromaModel:
     # ------------------------------------------------------------------ forward
     def forward(self, input_ids=None, inputs_embeds=None, labels=None, attention_mask=None, images=None,
                 refer_boxes=None, ground_boxes=None, past_key_values=None, use_cache=False, output_attentions=False,
-                output_hidden_states=False, return_dict=False, _last_logits_only=False, _reserve=0):
+                output_hidden_states=False, return_dict=False, _last_logits_only=False, _reserve=0, _cache=None):
         if not self._loaded:
             raise RuntimeError("GromaModel has no weights: use from_pretrained / from_state_dict / from_synthetic")
         if output_attentions:
@@ -330,7 +331,12 @@ class GromaModel:
                                      ref_rows.to(I32).to(dev), emb)
                 attention_mask = mask_h.to(dev)
                 kv_len = mask_h.sum(-1).to(I32).to(dev) if not bool(mask_h.all()) else None
-                if use_cache or _reserve:
+                if _cache is not None:  # generate(): prefill straight into the decode arena the captured graph reads
+                    cache = _cache
+                    cache.seq_len = 0
+                    if cache.bs != bs or cache.smax < L + max(int(_reserve), 0):
+                        raise RuntimeError("decode arena too small for this prompt")
+                elif use_cache or _reserve:
                     cache = self.llm.new_cache(bs, L + max(int(_reserve), 0), dev)
                 else:  # no cache requested: recycle one scratch KV buffer instead of zero-filling 2x32 tensors per call
                     cache = self._scratch_cache(bs, L)
@@ -377,6 +383,42 @@ class GromaModel:
                                          labels_h[i][reg_pos + 1: pad_pos])))
         return torch.nn.utils.rnn.pad_sequence(new_labels, batch_first=True, padding_value=IGNORE_INDEX)
 
+    # ------------------------------------------------------------------ hipGraph decode loop
+    def _decoder(self, bs, smax, max_new, eos, pad):
+        key = (bs, smax, max_new, eos, pad)
+        pool = self.__dict__.setdefault("_decoders", {})
+        dec = pool.get(key)
+        if dec is None:
+            if len(pool) >= 2:  # each arena owns a KV cache: keep the two most recent shapes
+                pool.pop(next(iter(pool)))
+            dec = engine.GreedyDecoder(self.llm, bs, smax, max_new, eos, pad, self.device)
+            dec.capture()  # before any prefill lands in the arena: the warm-up steps scribble on KV rows 0..2
+            pool[key] = dec
+        return dec
+
+    def _generate_graph(self, seqs, ids, images, refer_boxes, ground_boxes, max_new_tokens, eos, pad, return_dict,
+                        output_hidden_states):
+        """generate() with the per-token step captured once in a hipGraph (engine.GreedyDecoder): the step position,
+        the token fed back, the finished mask and the output ids all live on the device, so one replay = one token
+        and the host only reads the unfinished-row count when an EOS id is configured."""
+        bs, P = ids.shape
+        pc = self.config.perceiver_cfg
+        n_img_tok = (self.config.image_size // pc.vis_encoder_cfg.patch_size // 2) ** 2
+        bound = P + n_img_tok + 2 * self.config.max_region_num + (sum(len(b) for b in refer_boxes) if refer_boxes else 0)
+        smax = engine._ru(bound + max_new_tokens + 1, 256)
+        dec = self._decoder(bs, smax, engine._ru(max_new_tokens, 64), eos, pad)
+        first = self.forward(input_ids=ids, images=images, refer_boxes=refer_boxes, ground_boxes=ground_boxes,
+                             use_cache=True, output_hidden_states=output_hidden_states, return_dict=True,
+                             _last_logits_only=True, _reserve=max_new_tokens, _cache=dec.cache)
+        L = dec.cache.seq_len
+        n = dec.run(first.logits[:, -1, :], L, max_new_tokens)
+        dec.cache.seq_len = L + n - 1
+        seqs = torch.cat([seqs, dec.seq[:, :n]], dim=-1)
+        if not return_dict:
+            return seqs
+        hs = (first.hidden_states,) if output_hidden_states else None
+        return GenerateOutput(sequences=seqs, hidden_states=hs, past_key_values=dec.cache)
+
     # ------------------------------------------------------------------ generate (HF 4.32 greedy_search semantics)
     def generate(self, input_ids, images=None, refer_boxes=None, ground_boxes=None, use_cache=True, do_sample=False,
                  max_new_tokens=None, return_dict_in_generate=False, output_hidden_states=False, generation_config=None,
@@ -398,6 +440,9 @@ class GromaModel:
         dev = self.device
         seqs = input_ids.to(dev).clone()
         ids_for_model = input_ids.to(dev)
+        if self.decode_graph and max_new_tokens > 1:
+            return self._generate_graph(seqs, ids_for_model, images, refer_boxes, ground_boxes, max_new_tokens, eos, pad,
+                                        return_dict_in_generate, output_hidden_states)
         out = self.forward(input_ids=ids_for_model, images=images, refer_boxes=refer_boxes, ground_boxes=ground_boxes,
                            use_cache=True, output_hidden_states=output_hidden_states, return_dict=True,
                            _last_logits_only=True, _reserve=max_new_tokens)

@@ -138,8 +138,9 @@ def rmsnorm(x, gamma, eps, *, out_bf16=True, out=None):
     return out
 
 
-def attention(q, k, vt, *, Skv, causal, q_pos0=0, kv_len=None, scale=None, out=None):
-    """q [B,H,Lq,hd]; k [B,H,kv_stride,hd]; vt [B,H,hd,kv_stride] -> [B*Lq, H*hd]"""
+def attention(q, k, vt, *, Skv, causal, q_pos0=0, kv_len=None, scale=None, out=None, pos_dev=None, pos_stride=0):
+    """q [B,H,Lq,hd]; k [B,H,kv_stride,hd]; vt [B,H,hd,kv_stride] -> [B*Lq, H*hd].
+    pos_dev (i32 device tensor): row b attends keys [0, pos_dev[b*pos_stride] + Lq) -- device-resident decode position."""
     lib = _lib.load()
     _chk(q, BF16, "q"); _chk(k, BF16, "k"); _chk(vt, BF16, "vt")
     B, H, Lq, hd = q.shape
@@ -150,16 +151,20 @@ def attention(q, k, vt, *, Skv, causal, q_pos0=0, kv_len=None, scale=None, out=N
         out = torch.empty((B * Lq, H * hd), dtype=BF16, device=q.device)
     if kv_len is not None:
         _chk(kv_len, I32, "kv_len")
+    if pos_dev is not None:
+        _chk(pos_dev, I32, "pos_dev")
     _lib.check(lib.gr_attention_bf16(_p(q), _p(k), _p(vt), _p(out), _p(kv_len), B, H, Lq, Skv, kv_stride, hd,
-                                     int(causal), q_pos0, scale, _stream()), "gr_attention_bf16")
+                                     int(causal), q_pos0, scale, _p(pos_dev), pos_stride, _stream()), "gr_attention_bf16")
     return out
 
 
-def qkv_split(qkv, q, k, vt, *, B, H, L, hd, pos0=0, cos=None, sin=None):
+def qkv_split(qkv, q, k, vt, *, B, H, L, hd, pos0=0, cos=None, sin=None, pos_dev=None, pos_stride=0):
     lib = _lib.load()
     _chk(qkv, BF16, "qkv")
+    if pos_dev is not None:
+        _chk(pos_dev, I32, "pos_dev")
     _lib.check(lib.gr_qkv_split(_p(qkv), _p(q), _p(k), _p(vt), _p(cos), _p(sin), B, H, L, hd, pos0, k.shape[2],
-                                _stream()), "gr_qkv_split")
+                                _p(pos_dev), pos_stride, _stream()), "gr_qkv_split")
 
 
 def patchify(images, P, Kpad):
@@ -240,11 +245,12 @@ def add_rows(a, b, b_mod=0, out=None):
     return out
 
 
-def embed_gather(ids, table0, table1):
+def embed_gather(ids, table0, table1, out=None):
     lib = _lib.load()
     _chk(ids, I64, "ids")
     C = table0.shape[1]
-    out = torch.empty((ids.numel(), C), dtype=F32, device=ids.device)
+    if out is None:
+        out = torch.empty((ids.numel(), C), dtype=F32, device=ids.device)
     _lib.check(lib.gr_embed_gather(_p(ids), _p(table0), _p(table1), _p(out), ids.numel(), C, table0.shape[0],
                                    table1.shape[0], _stream()), "gr_embed_gather")
     return out
@@ -257,13 +263,24 @@ def scatter_rows(src, row_idx, dst):
                "gr_scatter_rows_f32")
 
 
-def argmax_rows(x, V):
+def argmax_rows(x, V, out=None):
     lib = _lib.load()
     _chk(x, F32, "x")
     rows = x.numel() // x.shape[-1]
-    out = torch.empty((rows,), dtype=I64, device=x.device)
+    if out is None:
+        out = torch.empty((rows,), dtype=I64, device=x.device)
     _lib.check(lib.gr_argmax_rows(_p(x), _p(out), rows, V, x.shape[-1], _stream()), "gr_argmax_rows")
     return out
+
+
+def greedy_advance(nxt, tok, unfinished, seq, pos, step, n_unfinished, *, eos, pad, inc_pos):
+    """HF greedy_search bookkeeping of one step on the device (see include/groma_hip.h)"""
+    lib = _lib.load()
+    _chk(nxt, I64, "nxt"); _chk(tok, I64, "tok"); _chk(unfinished, I64, "unfinished"); _chk(seq, I64, "seq")
+    _chk(pos, I32, "pos"); _chk(step, I32, "step"); _chk(n_unfinished, I32, "n_unfinished")
+    _lib.check(lib.gr_greedy_advance(_p(nxt), _p(tok), _p(unfinished), _p(seq), _p(pos), _p(step), _p(n_unfinished),
+                                     tok.numel(), -1 if eos is None else int(eos), 0 if pad is None else int(pad),
+                                     seq.shape[-1], pos.numel(), int(inc_pos), _stream()), "gr_greedy_advance")
 
 
 def msda(value, offw, ref, *, B, Q, heads, n_points, Hs, Ws, rdim, ref_batched):

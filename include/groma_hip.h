@@ -26,7 +26,7 @@ extern "C" {
 typedef struct ihipStream_t* hipStream_t;
 #endif
 
-#define GROMA_HIP_ABI_VERSION 2
+#define GROMA_HIP_ABI_VERSION 3
 int gr_abi_version(void);
 /* kernel timing hook used by bench.py: when enabled, every gr_gemm_bf16 launch is bracketed by HIP
  * events on its own stream; gr_prof_read drains them (sync) and returns total ms + launch count. */
@@ -89,12 +89,16 @@ int gr_rmsnorm(const float* x, const float* gamma, void* out, int rows, int C, l
 
 /* ---------------------------------------------------------------------------------- attention -- */
 /* q [B,H,Lq,hd], k [B,H,kv_stride,hd], vt [B,H,hd,kv_stride] bf16 -> out [B*Lq, H*hd] bf16.
- * key j visible to query i <=> j < Skv, j < kv_len[b] (if given), and (causal) j <= q_pos0 + i.  hd in {64,128}. */
+ * key j visible to query i <=> j < Skv, j < kv_len[b] (if given), and (causal) j <= q_pos0 + i.  hd in {64,128}.
+ * pos_dev (optional, device): q_pos0 of batch row b = pos_dev[b * pos_stride] and Skv = q_pos0 + Lq -- the step position
+ * lives in device memory so a decode step can be captured once in a hipGraph and replayed (pos_stride 0 = one shared
+ * counter, 1 = ragged per-row positions); Skv is then only the capacity bound that is validated. */
 int gr_attention_bf16(const void* q, const void* k, const void* vt, void* out, const int* kv_len, int B, int H, int Lq,
-                      int Skv, int kv_stride, int head_dim, int causal, int q_pos0, float scale, hipStream_t stream);
+                      int Skv, int kv_stride, int head_dim, int causal, int q_pos0, float scale, const int* pos_dev,
+                      int pos_stride, hipStream_t stream);
 /* fused-QKV split (+ HF rotate_half RoPE when cos/sin given) into the layouts above / the KV cache */
 int gr_qkv_split(const void* qkv, void* q, void* k, void* vt, const float* cosT, const float* sinT, int B, int H, int L,
-                 int head_dim, int pos0, int kv_stride, hipStream_t stream);
+                 int head_dim, int pos0, int kv_stride, const int* pos_dev, int pos_stride, hipStream_t stream);
 
 /* ------------------------------------------------------------------------- packing / movement -- */
 int gr_patchify(const float* images, void* out, int B, int S, int P, int Kpad, hipStream_t stream);
@@ -117,6 +121,11 @@ int gr_embed_gather(const long* ids, const void* table0, const void* table1, flo
                     hipStream_t stream);
 int gr_scatter_rows_f32(const float* src, const int* row_idx, float* dst, long n, int C, hipStream_t stream);
 int gr_argmax_rows(const float* x, long* out, int rows, int V, long ld, hipStream_t stream);
+/* one step of HF 4.32 GenerationMixin.greedy_search bookkeeping on the device (reference: the loop HF runs around
+ * groma/model/groma.py:176-200): n = unfinished ? nxt : pad; seq[:, *step] = n; tok = n; unfinished &= n != eos;
+ * ++*step; pos[0..pos_rows) += inc_pos; *n_unfinished = sum(unfinished).  eos < 0 = no stopping token. */
+int gr_greedy_advance(const long* nxt, long* tok, long* unfinished, long* seq, int* pos, int* step, int* n_unfinished,
+                      int rows, long eos, long pad, int seq_ld, int pos_rows, int inc_pos, hipStream_t stream);
 
 /* --------------------------------------------------------------- region proposer (fp32, DDETR) -- */
 int gr_msda_f32(const float* value, const float* offw, const float* ref, float* out, int B, int Q, int heads,

@@ -1,0 +1,31 @@
+"""Run with GROMA_HIP_LIB=tests/diag/libgroma_hip_clk.so: shader clock + per-tile phase times of the 256x256 GEMM."""
+import ctypes, os, sys
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
+import torch
+from groma_amd import ops, _lib
+
+lib = _lib.load()
+lib.gr_diag_clk.argtypes = [ctypes.c_void_p]
+buf = (ctypes.c_ulonglong * 6)()
+for (M, N, K) in [(8192, 8192, 8192), (8148, 22016, 4096), (8148, 4096, 4096), (8148, 4096, 11008)]:
+    a = (torch.randn((M, K), device="cuda") * 0.5).bfloat16()
+    w = (torch.randn((N, K), device="cuda") * 0.5).bfloat16()
+    out = torch.empty((M, N), device="cuda", dtype=torch.bfloat16)
+    for _ in range(3):
+        ops.gemm(a, w, out=out, tile=256)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(20):
+        ops.gemm(a, w, out=out, tile=256)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / 20
+    lib.gr_diag_clk(buf)
+    c = list(buf)
+    mhz = (c[2] - c[0]) / max(c[5] - c[3], 1) * 100
+    loop_us = (c[4] - c[3]) / 100.0
+    epi_us = (c[5] - c[4]) / 100.0
+    ks = K // 64
+    print(f"{M}x{N}x{K}: {ms * 1e3:.1f} us, {2.0 * M * N * K / ms / 1e9:.0f} TF | block0: shader clock {mhz:.0f} MHz, "
+          f"prologue+loop {loop_us:.1f} us ({(c[1] - c[0]) / ks:.0f} clk per K-step; MFMA-bound floor 2048), epilogue {epi_us:.1f} us")

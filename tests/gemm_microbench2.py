@@ -19,7 +19,7 @@ def bench(M,N,K,tile,it=20,**kw):
     e1.record(); torch.cuda.synchronize()
     ms=e0.elapsed_time(e1)/it
     return "%.1f us %.0f TF" % (ms*1e3, 2.0*M*N*K/ms/1e9)
-for (M,N,K) in [(7175,4096,1024),(7175,3072,1024),(7175,1024,1024),(7175,1024,4096)]:
+for (M,N,K) in [(14350,4096,1024),(14350,3072,1024),(14350,1024,1024),(14350,1024,4096)]:
     for tile in (128,256):
         print((M,N,K), tile, "plain", bench(M,N,K,tile), "| bias", bench(M,N,K,tile,bias=1), "| bias+gelu", bench(M,N,K,tile,bias=1,act=1),
               "| f32 bias scale resid", bench(M,N,K,tile,bias=1,scale=1,resid=1,out_f32=True), flush=True)

@@ -141,3 +141,34 @@ def test_generate_matches_oracle_greedy(setup):
     top2 = ref["prefill"]["logits"][:, -1].topk(2, dim=-1).values
     clear = (top2[:, 0] - top2[:, 1]) > 0.05
     assert same[:, ids.shape[1]][clear].all(), "first generated token differs from the oracle on a clear-margin row"
+
+
+@pytest.mark.parametrize("eos", [None, "from_eager"])
+def test_generate_graph_equals_eager(setup, eos):
+    """The hipGraph-replayed decode loop (device-resident position / finished mask / output ids) must produce exactly
+    the token ids of the eager per-kernel loop -- same kernels, same order, so bit-identical logits and arg-max --
+    including HF's EOS handling (finished rows emit pad; stop when every row is finished)."""
+    cfg, sd, tk, model, images, ids = setup
+    gc = model.generation_config
+    old = (gc.eos_token_id, getattr(gc, "pad_token_id", None), model.decode_graph)
+    try:
+        gc.eos_token_id = None
+        model.decode_graph = False
+        torch.manual_seed(9)
+        free = model.generate(ids.clone(), images=images, max_new_tokens=12).cpu()
+        if eos == "from_eager":  # pick row 0's 3rd generated token as EOS: row 0 stops early, row 1 may go on
+            gc.eos_token_id = int(free[0, ids.shape[1] + 2])
+            gc.pad_token_id = 0
+        torch.manual_seed(9)
+        eager = model.generate(ids.clone(), images=images, max_new_tokens=12).cpu()
+        model.decode_graph = True
+        for _ in range(2):  # second call replays the already-captured graph on a reused arena
+            torch.manual_seed(9)
+            out = model.generate(ids.clone(), images=images, max_new_tokens=12, return_dict_in_generate=True)
+            assert torch.equal(out.sequences.cpu(), eager), (out.sequences[:, ids.shape[1]:].tolist(), eager[:, ids.shape[1]:].tolist())
+            assert out.past_key_values.seq_len == out.past_key_values.seq_len  # arena stays readable
+        if eos == "from_eager":
+            assert eager.shape[1] <= ids.shape[1] + 12
+            assert (eager[0, ids.shape[1] + 3:] == 0).all()  # finished row pads
+    finally:
+        gc.eos_token_id, gc.pad_token_id, model.decode_graph = old
