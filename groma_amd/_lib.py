@@ -47,6 +47,9 @@ SIGNATURES = {
     "gr_rmsnorm": [_P, _P, _P, _I, _I, _L, _L, _F, _I, _P],
     "gr_attention_bf16": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _F, _P, _I, _P],
     "gr_qkv_split": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _I, _P],
+    "gr_decode_reduce_norm": [_P, _I, _P, _P, _P, _I, _I, _F, _P],
+    "gr_decode_qkv_rope": [_P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _I, _P],
+    "gr_decode_attention": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _P, _I, _P],
     "gr_patchify": [_P, _P, _I, _I, _I, _I, _P],
     "gr_fill_rows_f32": [_P, _P, _I, _I, _L, _P],
     "gr_mean4_tokens": [_P, _P, _P, _P, _P, _I, _I, _I, _P],

@@ -14,6 +14,7 @@ SOURCES = {
     "fp8.hip": [],
     "gemm_f32.hip": [],
     "attention.hip": [],
+    "decode.hip": [],
     "norm.hip": [],
     "pack.hip": [],
     "ddetr.hip": [],

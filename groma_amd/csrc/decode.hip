@@ -1,0 +1,222 @@
+// Decode-step kernels (one new token per sequence row, M = rows <= 8): SURVEY §8a row a22.
+// A decode step streams 13.2 GB of bf16 weights (HBM-bound, gemv_bf16.hip); everything else on the step is tiny, so
+// its cost is the NUMBER of kernels (each costs >= ~4.7 us of GPU timeline on MI355X) and their dependent-latency
+// chains.  These kernels fuse the split-K reductions of the weight-streaming GEMVs into their consumers and replace
+// the 128-query-row MFMA attention tile (1 useful row) by a one-block-per-(row, head) dot-product kernel:
+//   gr_decode_reduce_norm : h += sum_z part[z]  ;  x = bf16(RMSNorm(h) * gamma)          (o-proj / down-proj consumer)
+//   gr_decode_qkv_rope    : qkv = bf16(sum_z part[z]) -> RoPE -> q, K-cache row, V^T-cache column   (qkv consumer)
+//   gr_decode_attention   : softmax(q K^T * scale) V over the cache, one block per (row, head)
+// Positions come from device memory when pos_dev is given (hipGraph replay / ragged continuous batching).
+#include "gr_common.h"
+#include "../../include/groma_hip.h"
+
+// ------------------------------------------------------------------------------------------------
+// h[m,:] += sum_z part[z,m,:] (z ascending: deterministic), then RMSNorm -> x bf16.  One block per row.
+__global__ __launch_bounds__(1024) void decode_reduce_norm_kernel(const float* __restrict__ part, int splits,
+                                                                 float* __restrict__ h, const float* __restrict__ gamma,
+                                                                 bf16_t* __restrict__ x, int M, int N, float eps) {
+  __shared__ float red[16];
+  const int m = blockIdx.x, tid = threadIdx.x;
+  float* hr = h + (long)m * N;
+  f32x4 v[2];  // N <= 8192
+  float ss = 0.f;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int c = tid * 4 + i * 4096;
+    if (c < N) {
+      f32x4 a = {0.f, 0.f, 0.f, 0.f};
+      if (part) {
+        const float* pp = part + (long)m * N + c;
+        for (int z = 0; z < splits; ++z) a += *(const f32x4*)(pp + (long)z * M * N);
+      }
+      a += *(const f32x4*)(hr + c);
+      if (part) *(f32x4*)(hr + c) = a;
+      v[i] = a;
+      ss += a[0] * a[0] + a[1] * a[1] + a[2] * a[2] + a[3] * a[3];
+    }
+  }
+  ss = block_sum(ss, red);
+  const float rstd = rsqrtf(ss / (float)N + eps);
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int c = tid * 4 + i * 4096;
+    if (c < N) {
+      const f32x4 g = *(const f32x4*)(gamma + c);
+      const f32x4 o = g * (v[i] * rstd);
+      uint2 pk;
+      pk.x = pack2bf(o[0], o[1]);
+      pk.y = pack2bf(o[2], o[3]);
+      *(uint2*)(x + (long)m * N + c) = pk;
+    }
+  }
+}
+
+extern "C" int gr_decode_reduce_norm(const float* part, int splits, float* h, const float* gamma, void* x, int M, int N,
+                                     float eps, hipStream_t stream) {
+  if (!h || !gamma || !x || M <= 0 || N <= 0 || N % 4 != 0 || N > 8192 || (part && splits <= 0)) return GR_EINVAL;
+  hipLaunchKernelGGL(decode_reduce_norm_kernel, dim3(M), dim3(1024), 0, stream, part, splits, h, gamma, (bf16_t*)x, M, N, eps);
+  GR_CHECK_LAUNCH();
+  return GR_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Fused-QKV split of ONE new position per row from split-K partials: part [splits, B, 3*H*HD] f32.
+// The summed projection is rounded to bf16 first (exactly what the prefill path's GEMM epilogue stores), then HF
+// rotate_half RoPE in f32 (pack.hip qkv_split_kernel semantics), then q / K-cache row / V^T-cache column.
+template <int HD>
+__global__ __launch_bounds__(HD) void decode_qkv_rope_kernel(const float* __restrict__ part, int splits,
+                                                             bf16_t* __restrict__ q, bf16_t* __restrict__ k,
+                                                             bf16_t* __restrict__ vt, const float* __restrict__ cosT,
+                                                             const float* __restrict__ sinT, int B, int H, int pos0,
+                                                             int kv_stride, const int* __restrict__ pos_dev, int pos_stride) {
+  __shared__ float sq[HD], sk[HD];
+  const int h = blockIdx.x, b = blockIdx.y, d = threadIdx.x;
+  const int pos = pos_dev ? pos_dev[b * pos_stride] : pos0;
+  const long N = 3L * H * HD;
+  const float* pp = part + (long)b * N + h * HD + d;
+  float aq = 0.f, ak = 0.f, av = 0.f;
+  for (int z = 0; z < splits; ++z) {
+    const float* pz = pp + (long)z * B * N;
+    aq += pz[0];
+    ak += pz[(long)H * HD];
+    av += pz[2L * H * HD];
+  }
+  aq = bf2f(f2bf(aq));
+  ak = bf2f(f2bf(ak));
+  sq[d] = aq;
+  sk[d] = ak;
+  __syncthreads();
+  constexpr int HALF = HD / 2;
+  float oq = aq, ok = ak;
+  if (cosT) {
+    const int dc = d < HALF ? d : d - HALF, dp = d < HALF ? d + HALF : d - HALF;
+    const float sgn = d < HALF ? -1.f : 1.f;
+    const float c = cosT[(long)pos * HALF + dc], s = sinT[(long)pos * HALF + dc];
+    oq = aq * c + sgn * sq[dp] * s;
+    ok = ak * c + sgn * sk[dp] * s;
+  }
+  const long bh = (long)b * H + h;
+  q[bh * HD + d] = f2bf(oq);
+  k[(bh * kv_stride + pos) * HD + d] = f2bf(ok);
+  vt[(bh * HD + d) * kv_stride + pos] = f2bf(av);
+}
+
+extern "C" int gr_decode_qkv_rope(const float* part, int splits, void* q, void* k, void* vt, const float* cosT,
+                                  const float* sinT, int B, int H, int head_dim, int pos0, int kv_stride,
+                                  const int* pos_dev, int pos_stride, hipStream_t stream) {
+  if (!part || !q || !k || !vt || splits <= 0 || B <= 0 || H <= 0 || (!pos_dev && (pos0 < 0 || pos0 >= kv_stride))) return GR_EINVAL;
+  if ((cosT == nullptr) != (sinT == nullptr)) return GR_EINVAL;
+  dim3 grid(H, B);
+  if (head_dim == 128)
+    hipLaunchKernelGGL(decode_qkv_rope_kernel<128>, grid, dim3(128), 0, stream, part, splits, (bf16_t*)q, (bf16_t*)k,
+                       (bf16_t*)vt, cosT, sinT, B, H, pos0, kv_stride, pos_dev, pos_stride);
+  else if (head_dim == 64)
+    hipLaunchKernelGGL(decode_qkv_rope_kernel<64>, grid, dim3(64), 0, stream, part, splits, (bf16_t*)q, (bf16_t*)k,
+                       (bf16_t*)vt, cosT, sinT, B, H, pos0, kv_stride, pos_dev, pos_stride);
+  else return GR_EINVAL;
+  GR_CHECK_LAUNCH();
+  return GR_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Single-query attention over the cache: one 1024-thread block per (row b, head h).
+//   scores : 16 lanes per key (16 B = 8 dims each; a wave instruction reads 4 consecutive K rows = 1 KiB contiguous)
+//   softmax: fp32, scores kept in LDS (S <= DEC_SMAX)
+//   P.V    : V is cached TRANSPOSED [hd, kv_stride], so out[d] is a dot along contiguous keys: 1024/HD threads per d,
+//            16-B loads, reduced with cross-lane adds
+// Key s is visible iff s < S_b, S_b = (pos_dev ? pos_dev[b*stride] : q_pos0) + 1, and s < kv_len[b] if given.
+#define DEC_SMAX 8192
+
+template <int HD>
+__global__ __launch_bounds__(1024) void decode_attention_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
+                                                               const bf16_t* __restrict__ vt, bf16_t* __restrict__ out,
+                                                               const int* __restrict__ kv_len, int H, int kv_stride,
+                                                               int q_pos0, float scale, const int* __restrict__ pos_dev,
+                                                               int pos_stride) {
+  extern __shared__ float sc[];  // [round_up(S, 64)] scores -> probabilities
+  __shared__ float red[16];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int bh = blockIdx.x, b = bh / H;
+  int S = (pos_dev ? pos_dev[b * pos_stride] : q_pos0) + 1;
+  if (kv_len) S = min(S, kv_len[b]);
+  const int Spad = (S + 63) & ~63;
+  const bf16_t* Kp = k + (long)bh * kv_stride * HD;
+  const bf16_t* Vp = vt + (long)bh * HD * kv_stride;
+
+  // ---- scores
+  constexpr int LPK = HD / 8;          // lanes per key (16 for hd 128, 8 for hd 64)
+  constexpr int KPI = 1024 / LPK;      // keys per block iteration
+  const int j = tid % LPK, g = tid / LPK;
+  float qf[8];
+  {
+    const bf16x8 qv = *(const bf16x8*)(q + (long)bh * HD + j * 8);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) qf[e] = bf2f((bf16_t)qv[e]) * scale;
+  }
+  float mloc = -1e30f;
+  for (int s0 = 0; s0 < Spad; s0 += KPI) {
+    const int s = s0 + g;
+    float dot = 0.f;
+    if (s < S) {
+      const bf16x8 kv = *(const bf16x8*)(Kp + (long)s * HD + j * 8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) dot += qf[e] * bf2f((bf16_t)kv[e]);
+    }
+#pragma unroll
+    for (int o = LPK / 2; o > 0; o >>= 1) dot += __shfl_xor(dot, o, 64);
+    if (j == 0 && s < Spad) {
+      sc[s] = s < S ? dot : -1e30f;
+      if (s < S) mloc = fmaxf(mloc, dot);
+    }
+  }
+  // ---- block max
+  mloc = wave_max(mloc);
+  if (lane == 0) red[wave] = mloc;
+  __syncthreads();
+  float mx = red[0];
+#pragma unroll
+  for (int i = 1; i < 16; ++i) mx = fmaxf(mx, red[i]);
+  // ---- probabilities + sum
+  float lsum = 0.f;
+  for (int s = tid; s < Spad; s += 1024) {
+    const float p = s < S ? __expf(sc[s] - mx) : 0.f;
+    sc[s] = p;
+    lsum += p;
+  }
+  const float denom = block_sum(lsum, red);  // (syncs: sc[] complete)
+  // ---- P.V along contiguous keys of V^T
+  constexpr int TPD = 1024 / HD;  // threads per output dim (8 / 16)
+  const int d = tid / TPD, part = tid % TPD;
+  const bf16_t* vrow = Vp + (long)d * kv_stride;
+  float acc = 0.f;
+  for (int s0 = part * 8; s0 < Spad; s0 += TPD * 8) {
+    const bf16x8 vv = *(const bf16x8*)(vrow + s0);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float p = sc[s0 + e];
+      acc += p > 0.f ? p * bf2f((bf16_t)vv[e]) : 0.f;  // p == 0 beyond S: never multiply stale cache bytes (NaN-safe)
+    }
+  }
+#pragma unroll
+  for (int o = TPD / 2; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+  if (part == 0) out[(long)bh * HD + d] = f2bf(acc / denom);
+}
+
+extern "C" int gr_decode_attention(const void* q, const void* k, const void* vt, void* out, const int* kv_len, int B, int H,
+                                   int Smax, int kv_stride, int head_dim, int q_pos0, float scale, const int* pos_dev,
+                                   int pos_stride, hipStream_t stream) {
+  if (!q || !k || !vt || !out || B <= 0 || H <= 0 || Smax <= 0 || Smax > DEC_SMAX) return GR_EINVAL;
+  if (kv_stride % 64 != 0 || kv_stride < Smax || (!pos_dev && q_pos0 + 1 > Smax)) return GR_EINVAL;
+  const size_t lds = (size_t)((Smax + 63) & ~63) * sizeof(float);
+  if (head_dim == 128)
+    hipLaunchKernelGGL(decode_attention_kernel<128>, dim3(B * H), dim3(1024), lds, stream, (const bf16_t*)q,
+                       (const bf16_t*)k, (const bf16_t*)vt, (bf16_t*)out, kv_len, H, kv_stride, q_pos0, scale, pos_dev,
+                       pos_stride);
+  else if (head_dim == 64)
+    hipLaunchKernelGGL(decode_attention_kernel<64>, dim3(B * H), dim3(1024), lds, stream, (const bf16_t*)q,
+                       (const bf16_t*)k, (const bf16_t*)vt, (bf16_t*)out, kv_len, H, kv_stride, q_pos0, scale, pos_dev,
+                       pos_stride);
+  else return GR_EINVAL;
+  GR_CHECK_LAUNCH();
+  return GR_OK;
+}

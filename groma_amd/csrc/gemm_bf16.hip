@@ -231,10 +231,10 @@ extern "C" int gr_prof_read_launches(long cap, int* mnk, float* ms, long* n_out)
 }
 
 extern "C" int gr_gemm_bf16(const gr_gemm_desc* d, hipStream_t stream) {
-  if (!d || !d->A || !d->W || !d->C) return GR_EINVAL;
+  if (!d || !d->A || !d->W || (!d->C && d->tile != 2)) return GR_EINVAL;
   if (d->M <= 0 || d->N <= 0 || d->K <= 0) return GR_EINVAL;
   if (d->K % BK != 0 || d->N % 4 != 0) return GR_EINVAL;
-  if (d->fp8 && (d->K % 128 != 0 || d->conv_C > 0 || !d->w_scale || d->tile == 1)) return GR_EINVAL;
+  if (d->fp8 && (d->K % 128 != 0 || d->conv_C > 0 || !d->w_scale || d->tile == 1 || d->tile == 2)) return GR_EINVAL;
   if (d->conv_C > 0 && (d->conv_C % BK != 0 || d->K % (9 * d->conv_C) != 0)) return GR_EINVAL;
   const int splits = d->splits > 1 ? d->splits : 1;
   if (splits > 1 && !d->ws) return GR_EINVAL;
@@ -259,7 +259,8 @@ extern "C" int gr_gemm_bf16(const gr_gemm_desc* d, hipStream_t stream) {
   // ---- kernel choice: estimated time = rounds x per-slot tile time (slots: 512 for 128^2 at 2 blocks/CU, 256 for
   // 256^2 at 1 block/CU; per-CU throughput ratio measured on MI355X) ----
   bool use256 = false;
-  const bool gemv = d->tile == 1;  // decode-step shape: weights streamed once, no MFMA (gemv_bf16.hip)
+  const bool gemv = d->tile == 1 || d->tile == 2;  // decode-step shape: weights streamed once, no MFMA (gemv_bf16.hip)
+  const bool partials_only = d->tile == 2;         // the caller's next kernel consumes ws[splits, M, N] (decode.hip)
   if (gemv && (p.M > 8 || p.conv_C > 0 || splits != gr_cdiv(p.K, 512) || !p.ws)) return GR_EINVAL;
   if (d->tile == 256 || d->fp8) use256 = true;  // the fp8 build exists for the 256x256 kernel only
   else if (d->tile == 0) {
@@ -300,7 +301,7 @@ extern "C" int gr_gemm_bf16(const gr_gemm_desc* d, hipStream_t stream) {
     g_prof.push_back(rec);
   }
   GR_CHECK_LAUNCH();
-  if (splits > 1 || gemv) {
+  if ((splits > 1 || gemv) && !partials_only) {
     const long tot = (long)p.M * (p.N >> 2);
     hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3(gr_cdiv(tot, 256)), dim3(256), 0, stream, p);
     GR_CHECK_LAUNCH();

@@ -546,32 +546,37 @@ extern "C" int gr_scatter_rows_f32(const float* src, const int* row_idx, float* 
 
 // ---------------------------------------------------------------------------------------
 // Greedy next-token: argmax over logits f32 [rows, ld] restricted to [0, V); first maximal index wins.
-__global__ __launch_bounds__(256) void argmax_kernel(const float* __restrict__ x, long* __restrict__ out, int V, long ld) {
-  const int row = blockIdx.x;
+__global__ __launch_bounds__(1024) void argmax_kernel(const float* __restrict__ x, long* __restrict__ out, int V, long ld) {
+  const int row = blockIdx.x, tid = threadIdx.x;
   const float* xr = x + (long)row * ld;
   float best = -INFINITY;
   int bi = 0x7fffffff;
-  for (int i = threadIdx.x; i < V; i += 256) {
-    const float v = xr[i];
+  auto take = [&](float v, int i) {
     if (v > best || (v == best && i < bi)) { best = v; bi = i; }
+  };
+  const bool vec = (ld & 3) == 0 && (((uintptr_t)x) & 15) == 0;
+  const int nv = vec ? V >> 2 : 0;
+  for (int i = tid; i < nv; i += 1024) {
+    const f32x4 v = *(const f32x4*)(xr + i * 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) take(v[e], i * 4 + e);
   }
-  __shared__ float sv[256];
-  __shared__ int si[256];
-  sv[threadIdx.x] = best;
-  si[threadIdx.x] = bi;
+  for (int i = nv * 4 + tid; i < V; i += 1024) take(xr[i], i);
+  // wave-level then block-level (value desc, index asc)
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ov = __shfl_xor(best, o, 64);
+    const int oi = __shfl_xor(bi, o, 64);
+    take(ov, oi);
+  }
+  __shared__ float sv[16];
+  __shared__ int si[16];
+  if ((tid & 63) == 0) { sv[tid >> 6] = best; si[tid >> 6] = bi; }
   __syncthreads();
-  for (int s = 128; s > 0; s >>= 1) {
-    if (threadIdx.x < s) {
-      const float ov = sv[threadIdx.x + s];
-      const int oi = si[threadIdx.x + s];
-      if (ov > sv[threadIdx.x] || (ov == sv[threadIdx.x] && oi < si[threadIdx.x])) {
-        sv[threadIdx.x] = ov;
-        si[threadIdx.x] = oi;
-      }
-    }
-    __syncthreads();
+  if (tid == 0) {
+    for (int w = 1; w < 16; ++w) take(sv[w], si[w]);
+    out[row] = bi;
   }
-  if (threadIdx.x == 0) out[row] = si[0];
 }
 // HF 4.32 greedy_search bookkeeping for one step, entirely on the device (so the decode step is hipGraph-capturable):
 //   n = unfinished ? argmax : pad ; sequences[:, step] = n ; next input token = n ; unfinished &= (n != eos) ;
@@ -617,7 +622,7 @@ extern "C" int gr_greedy_advance(const long* nxt, long* tok, long* unfinished, l
 
 extern "C" int gr_argmax_rows(const float* x, long* out, int rows, int V, long ld, hipStream_t stream) {
   if (!x || !out || rows <= 0 || V <= 0) return GR_EINVAL;
-  hipLaunchKernelGGL(argmax_kernel, dim3(rows), dim3(256), 0, stream, x, out, V, ld);
+  hipLaunchKernelGGL(argmax_kernel, dim3(rows), dim3(1024), 0, stream, x, out, V, ld);
   GR_CHECK_LAUNCH();
   return GR_OK;
 }

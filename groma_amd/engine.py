@@ -310,6 +310,8 @@ class LlamaEngine:
         past = 0 if dyn else cache.seq_len
         if not dyn and past + L > cache.smax:
             cache.grow(_ru(past + L + 64, 64))
+        if L == 1 and M <= 8 and not w["fp8"] and T <= 8192 and cache.smax <= 8192:
+            return self._decode_forward(h, bs, cache, kv_len, pos_dev, pos_stride, past)
         q = ws.get("llm_q", (bs, H, L, hd), BF16)
         fp8 = w["fp8"]
 
@@ -345,6 +347,34 @@ class LlamaEngine:
             return logits.view(bs, 1, self.Vpad)[:, :, : self.V], hn
         logits = ops.gemm(hn, w["head"], out_f32=True, out=ws.get("llm_logits", (M, self.Vpad), F32))
         return logits.view(bs, L, self.Vpad)[:, :, : self.V], hn
+
+    def _decode_forward(self, h, bs, cache, kv_len, pos_dev, pos_stride, past):
+        """One new position per row.  Weight GEMVs leave their split-K partials for the next kernel
+        (csrc/decode.hip): 9 launches per layer instead of 13, and a one-block-per-(row, head) attention."""
+        w, ws, T, H, hd = self.w, self.ws, self.T, self.H, self.hd
+        dyn = pos_dev is not None
+        x = ws.get("dec_x", (bs, T), BF16)
+        q = ws.get("dec_q", (bs, H, 1, hd), BF16)
+        ctx = ws.get("dec_ctx", (bs, T), BF16)
+        y = ws.get("dec_y", (bs, self.I), BF16)
+        part, splits = None, 0
+        for i, Lw in enumerate(w["layers"]):
+            ops.decode_reduce_norm(part, splits, h, Lw["n1"], x, self.eps)  # (+ previous layer's down-proj partials)
+            pq, sq = ops.gemv_partials(x, Lw["wqkv"][0])
+            ops.decode_qkv_rope(pq, sq, q, cache.k[i], cache.vt[i], w["cos"], w["sin"], B=bs, H=H, hd=hd, pos0=past,
+                                pos_dev=pos_dev, pos_stride=pos_stride)
+            ops.decode_attention(q, cache.k[i], cache.vt[i], ctx, Smax=cache.smax if dyn else past + 1, q_pos0=past,
+                                 kv_len=kv_len, pos_dev=pos_dev, pos_stride=pos_stride)
+            po, so = ops.gemv_partials(ctx, Lw["wo"][0])
+            ops.decode_reduce_norm(po, so, h, Lw["n2"], x, self.eps)
+            ops.gemm(x, Lw["wgu"][0], act=3, out=y, tile=1, splits=(T + 511) // 512,
+                     ws=ops._gemv_ws((T + 511) // 512, bs, 2 * self.I, h.device))
+            part, splits = ops.gemv_partials(y, Lw["wd"][0])
+        if not dyn:
+            cache.seq_len = past + 1
+        ops.decode_reduce_norm(part, splits, h, w["norm"], x, self.eps)
+        logits = ops.gemm(x, w["head"], out_f32=True, out=ws.get("llm_logits", (bs, self.Vpad), F32))
+        return logits.view(bs, 1, self.Vpad)[:, :, : self.V], x
 
 
 class GreedyDecoder:

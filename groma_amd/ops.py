@@ -100,6 +100,57 @@ def gemm(a, w, *, out=None, bias=None, scale=None, resid=None, act=0, out_f32=Fa
     return out
 
 
+def gemv_partials(a, w, M=None):
+    """Decode-step weight streaming: returns (part f32 [splits, M, N], splits) with a @ w^T = sum_z part[z]; the
+    reduction is left to a fused consumer (decode_reduce_norm / decode_qkv_rope)."""
+    lib = _lib.load()
+    _chk(a, BF16, "a"); _chk(w, BF16, "w")
+    N, K = w.shape
+    if M is None:
+        M = a.numel() // a.shape[-1]
+    splits = (K + 511) // 512
+    ws = _gemv_ws(splits, M, N, a.device)
+    d = GemmDesc()
+    d.A, d.W, d.C, d.ws = a.data_ptr(), w.data_ptr(), None, ws.data_ptr()
+    d.M, d.N, d.K, d.lda, d.ldw, d.ldc = M, N, K, a.shape[-1], w.stride(0), N
+    d.splits, d.tile = splits, 2
+    _lib.check(lib.gr_gemm_bf16(ctypes.byref(d), _stream()), "gr_gemm_bf16")
+    return ws, splits
+
+
+def decode_reduce_norm(part, splits, h, gamma, x, eps):
+    lib = _lib.load()
+    _chk(h, F32, "h"); _chk(x, BF16, "x")
+    N = h.shape[-1]
+    _lib.check(lib.gr_decode_reduce_norm(_p(part), splits, _p(h), _p(gamma), _p(x), h.numel() // N, N, eps, _stream()),
+               "gr_decode_reduce_norm")
+    return x
+
+
+def decode_qkv_rope(part, splits, q, k, vt, cos, sin, *, B, H, hd, pos0=0, pos_dev=None, pos_stride=0):
+    lib = _lib.load()
+    if pos_dev is not None:
+        _chk(pos_dev, I32, "pos_dev")
+    _lib.check(lib.gr_decode_qkv_rope(_p(part), splits, _p(q), _p(k), _p(vt), _p(cos), _p(sin), B, H, hd, pos0, k.shape[2],
+                                      _p(pos_dev), pos_stride, _stream()), "gr_decode_qkv_rope")
+
+
+def decode_attention(q, k, vt, out, *, Smax, q_pos0=0, kv_len=None, scale=None, pos_dev=None, pos_stride=0):
+    """q [B,H,1,hd] against the cache k [B,H,kv_stride,hd] / vt [B,H,hd,kv_stride] -> out bf16 [B, H*hd]"""
+    lib = _lib.load()
+    _chk(q, BF16, "q"); _chk(k, BF16, "k"); _chk(vt, BF16, "vt"); _chk(out, BF16, "out")
+    B, H, _, hd = q.shape
+    if scale is None:
+        scale = hd ** -0.5
+    if pos_dev is not None:
+        _chk(pos_dev, I32, "pos_dev")
+    if kv_len is not None:
+        _chk(kv_len, I32, "kv_len")
+    _lib.check(lib.gr_decode_attention(_p(q), _p(k), _p(vt), _p(out), _p(kv_len), B, H, Smax, k.shape[2], hd, q_pos0,
+                                       scale, _p(pos_dev), pos_stride, _stream()), "gr_decode_attention")
+    return out
+
+
 def gemm_f32(a, w, *, bias=None, resid=None, act=0, out=None, M=None, lda=None, ldc=None):
     lib = _lib.load()
     _chk(a, F32, "a"); _chk(w, F32, "w")

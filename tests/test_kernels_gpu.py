@@ -404,3 +404,90 @@ def test_norm_fp8(dev):
     assert (q.float().abs().amax(-1) == 448).all()
     q, s = ops.norm_fp8(x, g, b, 1e-6, False)
     assert relerr(q.float() * s[:, None], F.layer_norm(x, (1024,), g, b, 1e-6)) < 4e-2
+
+
+# ------------------------------------------------------------------------------------------------ decode-step kernels
+@pytest.mark.parametrize("M,N,splits", [(4, 4096, 8), (3, 512, 22), (8, 8192, 1), (2, 4096, 0)])
+def test_decode_reduce_norm(dev, M, N, splits):
+    ops = _ops()
+    h = rnd((M, N), dev, seed=1)
+    g = rnd((N,), dev, seed=2)
+    part = rnd((splits, M, N), dev, seed=3) if splits else None
+    x = torch.empty((M, N), dtype=torch.bfloat16, device=dev)
+    h2 = h.clone()
+    ops.decode_reduce_norm(part, splits, h2, g, x, 1e-5)
+    hs = h.double() + (part.double().sum(0) if splits else 0)
+    assert relerr(h2, hs.float()) < 1e-6
+    ref = g * (h2 * torch.rsqrt(h2.pow(2).mean(-1, keepdim=True) + 1e-5))
+    assert relerr(x, ref) < 4e-3
+    if not splits:
+        assert torch.equal(h2, h)  # plain norm: the residual stream is not rewritten
+
+
+@pytest.mark.parametrize("hd,use_dev_pos", [(64, False), (128, True)])
+def test_decode_qkv_rope_matches_prefill_split(dev, hd, use_dev_pos):
+    """decode consumer of the qkv partials == (reduce -> bf16 -> qkv_split at L=1), the path the prefill uses"""
+    ops = _ops()
+    B, H, splits, stride = 4, 5, 8, 128
+    part = rnd((splits, B, 3 * H * hd), dev, seed=1)
+    inv = 1.0 / (10000 ** (torch.arange(0, hd, 2, device=dev).float() / hd))
+    fr = torch.outer(torch.arange(256, device=dev).float(), inv)
+    cos, sin = fr.cos().contiguous(), fr.sin().contiguous()
+    pos = torch.tensor([7, 30, 0, 99], dtype=torch.int32, device=dev)
+    outs = []
+    for fused in (True, False):
+        q = torch.zeros((B, H, 1, hd), dtype=torch.bfloat16, device=dev)
+        k = torch.zeros((B, H, stride, hd), dtype=torch.bfloat16, device=dev)
+        vt = torch.zeros((B, H, hd, stride), dtype=torch.bfloat16, device=dev)
+        kw = dict(pos_dev=pos, pos_stride=1) if use_dev_pos else dict(pos0=11)
+        if fused:
+            ops.decode_qkv_rope(part, splits, q, k, vt, cos, sin, B=B, H=H, hd=hd, **kw)
+        else:
+            acc = torch.zeros_like(part[0])
+            for z in range(splits):
+                acc = acc + part[z]
+            ops.qkv_split(acc.bfloat16(), q, k, vt, B=B, H=H, L=1, hd=hd, cos=cos, sin=sin, **kw)
+        outs.append((q, k, vt))
+    for a, b in zip(*outs):
+        assert (a != 0).any()
+        assert relerr(a, b) < 3e-3 and (a.float() - b.float()).abs().max().item() < 0.04  # <= 1 bf16 ulp (fma contraction)
+    assert torch.equal(outs[0][2], outs[1][2])  # V is a pure copy
+
+
+@pytest.mark.parametrize("B,H,hd,S,mode", [(4, 32, 128, 583, "host"), (2, 8, 64, 70, "host"), (4, 32, 128, 640, "dev"),
+                                           (3, 4, 128, 1500, "ragged"), (2, 8, 64, 300, "len")])
+def test_decode_attention(dev, B, H, hd, S, mode):
+    ops = _ops()
+    stride = (S + 63) // 64 * 64 + 64
+    q = rnd((B, H, 1, hd), dev, seed=1).bfloat16()
+    k = rnd((B, H, stride, hd), dev, seed=2).bfloat16()   # rows beyond the visible range hold garbage on purpose
+    v = rnd((B, H, stride, hd), dev, seed=3).bfloat16()
+    k[0, 0, S // 2] *= 8.0
+    v[:, :, S:] = float("nan")  # never-visible cache bytes must not leak (stale / uninitialised memory)
+    vt = v.transpose(2, 3).contiguous()
+    out = torch.empty((B, H * hd), dtype=torch.bfloat16, device=dev)
+    kv_len, lens = None, [S] * B
+    if mode == "host":
+        ops.decode_attention(q, k, vt, out, Smax=S, q_pos0=S - 1)
+    elif mode == "dev":
+        pos = torch.tensor([S - 1], dtype=torch.int32, device=dev)
+        ops.decode_attention(q, k, vt, out, Smax=stride, pos_dev=pos, pos_stride=0)
+    elif mode == "ragged":
+        lens = [S, S - 313, 1][:B]
+        pos = torch.tensor([l - 1 for l in lens], dtype=torch.int32, device=dev)
+        ops.decode_attention(q, k, vt, out, Smax=stride, pos_dev=pos, pos_stride=1)
+    else:
+        lens = [S - 37, S][:B]
+        kv_len = torch.tensor(lens, dtype=torch.int32, device=dev)
+        ops.decode_attention(q, k, vt, out, Smax=S, q_pos0=S - 1, kv_len=kv_len)
+    ref = torch.empty((B, H, hd), device=dev)
+    for b in range(B):
+        L = lens[b]
+        s = torch.einsum("hd,hsd->hs", q[b, :, 0].float(), k[b, :, :L].float()) * hd ** -0.5
+        ref[b] = torch.einsum("hs,hsd->hd", torch.softmax(s, -1), v[b, :, :L].float())
+    assert torch.isfinite(out.float()).all()
+    assert relerr(out, ref.view(B, H * hd)) < 6e-3
+    if mode == "host":  # and against the MFMA tile kernel the prefill uses
+        v2 = v.clone(); v2[:, :, S:] = 0
+        mf = ops.attention(q, k, v2.transpose(2, 3).contiguous(), Skv=S, causal=True, q_pos0=S - 1)
+        assert relerr(out, mf) < 1e-2
