@@ -112,6 +112,10 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp8"],
                     help="GEMM operand type of the DINOv2/LLaMA linears.  bf16 is the headline (the reference's precision); "
                          "fp8 = OCP e4m3 operands + f32 accumulate (BASELINE configs[4] extension, reported as dtype fp8)")
+    ap.add_argument("--mode", default="forward", choices=["forward", "generate"],
+                    help="forward = the headline prefill metric (BASELINE configs[2]); generate = configs[3]: greedy decoding "
+                         "of --new-tokens tokens per image at --batch images per GPU (use --batch 4), HBM-bound decode steps")
+    ap.add_argument("--new-tokens", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--gemm-breakdown", default=None, help="write a per-shape GEMM table (from the HIP-event hook) here")
     args = ap.parse_args()
@@ -142,8 +146,18 @@ def main():
     r0 = model.box_idx_token_ids[0]
     gathered = torch.empty((world * args.batch, 100), dtype=torch.float32, device=dev) if world > 1 else None
 
+    gen = args.mode == "generate"
+    if gen:
+        model.generation_config.eos_token_id = None  # random-init weights: fixed-length decode, never an early stop
+        gathered_ids = torch.empty((world * args.batch, P + args.new_tokens), dtype=torch.int64, device=dev) if world > 1 else None
+
     def step(i):
         torch.manual_seed(1000 + i)  # the path draws torch.randperm (T4)
+        if gen:
+            seq = model.generate(ids, images=images, max_new_tokens=args.new_tokens)
+            if world > 1:
+                dist.all_gather_into_tensor(gathered_ids, seq.contiguous())
+            return seq
         logits, _ = model.forward(input_ids=ids, images=images, use_cache=False)
         region_logits = logits[:, -1, r0:r0 + 100].contiguous()
         if world > 1:
@@ -172,6 +186,7 @@ def main():
     # ---- roofline leg: the same steps again with HIP events around every GEMM launch (on the launch stream) ----
     n_reg = [b.shape[0] for b in model._last_aux["sel_idx"]]
     fl = flops_per_image(cfg, sum(n_reg) / len(n_reg), P)
+    model.decode_graph = False  # HIP events cannot bracket launches inside a replayed graph: time the same kernels eagerly
     ops.prof_enable(True)
     for i in range(args.steps):
         step(args.warmup + i)
@@ -236,8 +251,23 @@ def main():
                      "e2e_algorithmic_tflops_per_gpu": fl["total"] * args.batch * args.steps / elapsed / 1e12,
                      "e2e_frac_of_peak": fl["total"] * args.batch * args.steps / elapsed / 1e12 / peak},
     }
+    if gen:  # configs[3]: the decode steps stream the bf16 weights once per token -> HBM roofline of the GEMV kernel
+        gv = [r for r in recs if r[3] & 8]
+        gv_ms = sum(r[4] for r in gv)
+        gv_bytes = sum(2.0 * r[1] * r[2] for r in gv)  # algorithmic bytes per launch: the N x K bf16 weight, read once
+        out["metric"] = "images/sec greedy generate (448px, 300 proposals, 128-token prompt, %d new tokens)" % args.new_tokens
+        out["config"]["workload"] = ("configs[3]: generate() = full Groma-7B prefill + %d greedy decode steps (hipGraph replay), "
+                                     "random-init weights, no EOS" % args.new_tokens)
+        out["config"]["new_tokens"] = args.new_tokens
+        ach = gv_bytes / (gv_ms * 1e-3) / 1e9 if gv_ms > 0 else 0.0
+        out["roofline"] = {"bound": "hbm", "kernel": "gemv_bf16_kernel<M>(GemmArgs) -- decode-step weight streaming",
+                           "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0, "traffic": None,
+                           "launches_per_step": len(gv) / max(args.steps, 1),
+                           "avg_launch_us": gv_ms * 1e3 / max(len(gv), 1),
+                           "bytes_per_launch": gv_bytes / max(len(gv), 1),
+                           "kernel_time_share_of_step": (gv_ms / args.steps) / (elapsed / args.steps * 1e3)}
     if rank == 0:
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not gen:
             try:
                 out["cpu_baseline"] = cpu_baseline(args.config)
             except Exception as e:  # never lose the GPU measurement to a host-side failure

@@ -29,6 +29,7 @@ class GemmDesc(ctypes.Structure):
         ("c_group", c_int), ("c_group_stride", c_int), ("c_row_off", c_int),
         ("tile", c_int),
         ("fp8", c_int), ("a_scale", c_void_p), ("w_scale", c_void_p),
+        ("a_parts", c_void_p), ("a_nsplit", c_int), ("a_hd", c_int),
     ]
 
 
@@ -49,7 +50,7 @@ SIGNATURES = {
     "gr_qkv_split": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _I, _P],
     "gr_decode_reduce_norm": [_P, _I, _P, _P, _P, _I, _I, _F, _P],
     "gr_decode_qkv_rope": [_P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _I, _P],
-    "gr_decode_attention": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _P, _I, _P],
+    "gr_decode_attention": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _P, _I, _I, _P, _P],
     "gr_patchify": [_P, _P, _I, _I, _I, _I, _P],
     "gr_fill_rows_f32": [_P, _P, _I, _I, _L, _P],
     "gr_mean4_tokens": [_P, _P, _P, _P, _P, _I, _I, _I, _P],

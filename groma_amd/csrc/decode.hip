@@ -126,47 +126,70 @@ extern "C" int gr_decode_qkv_rope(const float* part, int splits, void* q, void* 
 //            16-B loads, reduced with cross-lane adds
 // Key s is visible iff s < S_b, S_b = (pos_dev ? pos_dev[b*stride] : q_pos0) + 1, and s < kv_len[b] if given.
 #define DEC_SMAX 8192
+#define DEC_U 11  // chunks in flight per thread and round (K and V^T): 11 x 64 = 704 keys per round at hd 128; 12 spills
 
 template <int HD>
 __global__ __launch_bounds__(1024) void decode_attention_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
                                                                const bf16_t* __restrict__ vt, bf16_t* __restrict__ out,
                                                                const int* __restrict__ kv_len, int H, int kv_stride,
                                                                int q_pos0, float scale, const int* __restrict__ pos_dev,
-                                                               int pos_stride) {
+                                                               int pos_stride, float* __restrict__ ws) {
   extern __shared__ float sc[];  // [round_up(S, 64)] scores -> probabilities
   __shared__ float red[16];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int bh = blockIdx.x, b = bh / H;
-  int S = (pos_dev ? pos_dev[b * pos_stride] : q_pos0) + 1;
-  if (kv_len) S = min(S, kv_len[b]);
+  const int nsplit = gridDim.y, z = blockIdx.y;
+  int Sall = (pos_dev ? pos_dev[b * pos_stride] : q_pos0) + 1;
+  if (kv_len) Sall = min(Sall, kv_len[b]);
+  // this block's slice of the keys (64-aligned start so the 16-B V^T loads stay aligned)
+  const int chunk = (((Sall + nsplit - 1) / nsplit) + 63) & ~63;
+  const int sb = z * chunk;
+  const int S = max(0, min(Sall, sb + chunk) - sb);
   const int Spad = (S + 63) & ~63;
-  const bf16_t* Kp = k + (long)bh * kv_stride * HD;
-  const bf16_t* Vp = vt + (long)bh * HD * kv_stride;
+  const bf16_t* Kp = k + ((long)bh * kv_stride + sb) * HD;
+  const bf16_t* Vp = vt + (long)bh * HD * kv_stride + sb;
 
-  // ---- scores
+  // All global loads of a round are issued before anything consumes them (one exposed memory latency per round of
+  // DEC_U x 64 keys, for K and for V^T together): a decode block is a pure latency chain otherwise.
   constexpr int LPK = HD / 8;          // lanes per key (16 for hd 128, 8 for hd 64)
-  constexpr int KPI = 1024 / LPK;      // keys per block iteration
+  constexpr int KPI = 1024 / LPK;      // keys per pass of the block
+  constexpr int TPD = 1024 / HD;       // threads per output dim (8 / 16)
   const int j = tid % LPK, g = tid / LPK;
+  const int d = tid / TPD, part = tid % TPD;
+  const bf16_t* vrow = Vp + (long)d * kv_stride;
+  const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
   float qf[8];
   {
     const bf16x8 qv = *(const bf16x8*)(q + (long)bh * HD + j * 8);
 #pragma unroll
     for (int e = 0; e < 8; ++e) qf[e] = bf2f((bf16_t)qv[e]) * scale;
   }
-  float mloc = -1e30f;
-  for (int s0 = 0; s0 < Spad; s0 += KPI) {
-    const int s = s0 + g;
-    float dot = 0.f;
-    if (s < S) {
-      const bf16x8 kv = *(const bf16x8*)(Kp + (long)s * HD + j * 8);
+  bf16x8 vv[DEC_U];  // V^T chunks of round 0 (keys part*8 + u*TPD*8 ..+8), loaded alongside the K rows
 #pragma unroll
-      for (int e = 0; e < 8; ++e) dot += qf[e] * bf2f((bf16_t)kv[e]);
+  for (int u = 0; u < DEC_U; ++u) {
+    const int s0 = part * 8 + u * TPD * 8;
+    vv[u] = s0 < Spad ? *(const bf16x8*)(vrow + s0) : zero8;
+  }
+  float mloc = -1e30f;
+  for (int r0 = 0; r0 < Spad; r0 += KPI * DEC_U) {
+    bf16x8 kv[DEC_U];
+#pragma unroll
+    for (int u = 0; u < DEC_U; ++u) {
+      const int s = r0 + u * KPI + g;
+      kv[u] = s < S ? *(const bf16x8*)(Kp + (long)s * HD + j * 8) : zero8;
     }
 #pragma unroll
-    for (int o = LPK / 2; o > 0; o >>= 1) dot += __shfl_xor(dot, o, 64);
-    if (j == 0 && s < Spad) {
-      sc[s] = s < S ? dot : -1e30f;
-      if (s < S) mloc = fmaxf(mloc, dot);
+    for (int u = 0; u < DEC_U; ++u) {
+      const int s = r0 + u * KPI + g;
+      float dot = 0.f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) dot += qf[e] * bf2f((bf16_t)kv[u][e]);
+#pragma unroll
+      for (int o = LPK / 2; o > 0; o >>= 1) dot += __shfl_xor(dot, o, 64);
+      if (j == 0 && s < Spad) {
+        sc[s] = s < S ? dot : -1e30f;
+        if (s < S) mloc = fmaxf(mloc, dot);
+      }
     }
   }
   // ---- block max
@@ -185,37 +208,59 @@ __global__ __launch_bounds__(1024) void decode_attention_kernel(const bf16_t* __
   }
   const float denom = block_sum(lsum, red);  // (syncs: sc[] complete)
   // ---- P.V along contiguous keys of V^T
-  constexpr int TPD = 1024 / HD;  // threads per output dim (8 / 16)
-  const int d = tid / TPD, part = tid % TPD;
-  const bf16_t* vrow = Vp + (long)d * kv_stride;
   float acc = 0.f;
-  for (int s0 = part * 8; s0 < Spad; s0 += TPD * 8) {
-    const bf16x8 vv = *(const bf16x8*)(vrow + s0);
+  auto pv = [&](const bf16x8 v8, int s0) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       const float p = sc[s0 + e];
-      acc += p > 0.f ? p * bf2f((bf16_t)vv[e]) : 0.f;  // p == 0 beyond S: never multiply stale cache bytes (NaN-safe)
+      acc += p > 0.f ? p * bf2f((bf16_t)v8[e]) : 0.f;  // p == 0 beyond S: never multiply stale cache bytes (NaN-safe)
+    }
+  };
+#pragma unroll
+  for (int u = 0; u < DEC_U; ++u) {
+    const int s0 = part * 8 + u * TPD * 8;
+    if (s0 < Spad) pv(vv[u], s0);
+  }
+  for (int r0 = DEC_U * TPD * 8; r0 < Spad; r0 += DEC_U * TPD * 8) {  // long caches: further rounds
+#pragma unroll
+    for (int u = 0; u < DEC_U; ++u) {
+      const int s0 = r0 + part * 8 + u * TPD * 8;
+      vv[u] = s0 < Spad ? *(const bf16x8*)(vrow + s0) : zero8;
+    }
+#pragma unroll
+    for (int u = 0; u < DEC_U; ++u) {
+      const int s0 = r0 + part * 8 + u * TPD * 8;
+      if (s0 < Spad) pv(vv[u], s0);
     }
   }
 #pragma unroll
   for (int o = TPD / 2; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
-  if (part == 0) out[(long)bh * HD + d] = f2bf(acc / denom);
+  if (nsplit == 1) {
+    if (part == 0) out[(long)bh * HD + d] = f2bf(acc / denom);
+    return;
+  }
+  // ---- split keys: publish (un-normalised o, max, sum) of this slice; the o-proj GEMV merges the slices in slice
+  // order while loading its operand (gemv_bf16.hip) -- kernel boundaries provide the visibility, no fences here
+  float* wo = ws + ((long)bh * nsplit + z) * (HD + 2);
+  if (part == 0) wo[d] = acc;
+  if (tid == 0) { wo[HD] = mx; wo[HD + 1] = denom; }
 }
 
 extern "C" int gr_decode_attention(const void* q, const void* k, const void* vt, void* out, const int* kv_len, int B, int H,
                                    int Smax, int kv_stride, int head_dim, int q_pos0, float scale, const int* pos_dev,
-                                   int pos_stride, hipStream_t stream) {
+                                   int pos_stride, int nsplit, float* parts, hipStream_t stream) {
   if (!q || !k || !vt || !out || B <= 0 || H <= 0 || Smax <= 0 || Smax > DEC_SMAX) return GR_EINVAL;
+  if (nsplit < 1 || nsplit > 16 || (nsplit > 1 && !parts)) return GR_EINVAL;
   if (kv_stride % 64 != 0 || kv_stride < Smax || (!pos_dev && q_pos0 + 1 > Smax)) return GR_EINVAL;
   const size_t lds = (size_t)((Smax + 63) & ~63) * sizeof(float);
   if (head_dim == 128)
-    hipLaunchKernelGGL(decode_attention_kernel<128>, dim3(B * H), dim3(1024), lds, stream, (const bf16_t*)q,
+    hipLaunchKernelGGL(decode_attention_kernel<128>, dim3(B * H, nsplit), dim3(1024), lds, stream, (const bf16_t*)q,
                        (const bf16_t*)k, (const bf16_t*)vt, (bf16_t*)out, kv_len, H, kv_stride, q_pos0, scale, pos_dev,
-                       pos_stride);
+                       pos_stride, parts);
   else if (head_dim == 64)
-    hipLaunchKernelGGL(decode_attention_kernel<64>, dim3(B * H), dim3(1024), lds, stream, (const bf16_t*)q,
+    hipLaunchKernelGGL(decode_attention_kernel<64>, dim3(B * H, nsplit), dim3(1024), lds, stream, (const bf16_t*)q,
                        (const bf16_t*)k, (const bf16_t*)vt, (bf16_t*)out, kv_len, H, kv_stride, q_pos0, scale, pos_dev,
-                       pos_stride);
+                       pos_stride, parts);
   else return GR_EINVAL;
   GR_CHECK_LAUNCH();
   return GR_OK;

@@ -231,7 +231,9 @@ extern "C" int gr_prof_read_launches(long cap, int* mnk, float* ms, long* n_out)
 }
 
 extern "C" int gr_gemm_bf16(const gr_gemm_desc* d, hipStream_t stream) {
-  if (!d || !d->A || !d->W || (!d->C && d->tile != 2)) return GR_EINVAL;
+  if (!d || (!d->A && !d->a_parts) || !d->W || (!d->C && d->tile != 2)) return GR_EINVAL;
+  if (d->a_parts && ((d->tile != 1 && d->tile != 2) || d->a_nsplit < 1 || d->a_hd < 8 || d->a_hd % 8 != 0 || d->K % d->a_hd != 0))
+    return GR_EINVAL;
   if (d->M <= 0 || d->N <= 0 || d->K <= 0) return GR_EINVAL;
   if (d->K % BK != 0 || d->N % 4 != 0) return GR_EINVAL;
   if (d->fp8 && (d->K % 128 != 0 || d->conv_C > 0 || !d->w_scale || d->tile == 1 || d->tile == 2)) return GR_EINVAL;
@@ -249,6 +251,7 @@ extern "C" int gr_gemm_bf16(const gr_gemm_desc* d, hipStream_t stream) {
   p.a_scale = d->fp8 ? d->a_scale : nullptr;
   p.w_scale = d->fp8 ? d->w_scale : nullptr;
   p.ws = d->ws;
+  p.a_parts = d->a_parts; p.a_nsplit = d->a_nsplit; p.a_hd = d->a_hd;
   p.M = d->M; p.N = d->N; p.K = d->K;
   p.lda = d->lda; p.ldw = d->ldw; p.ldc = d->ldc; p.ldr = d->ldr;
   p.act = d->act; p.out_f32 = d->out_f32; p.splits = splits;

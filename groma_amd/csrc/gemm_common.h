@@ -20,6 +20,8 @@ struct GemmArgs {
   const float* a_scale;  // fp8 path: per-row dequantisation scale of A [M] (or null)
   const float* w_scale;  // fp8 path: per-output-channel scale of W [N] (or null)
   float* ws;
+  const float* a_parts;  // decode GEMV only: A given as un-merged single-query attention slices (decode.hip), or null
+  int a_nsplit, a_hd;
   int M, N, K;
   long lda, ldw, ldc, ldr;
   int act, out_f32, splits;

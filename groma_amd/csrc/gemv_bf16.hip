@@ -27,6 +27,29 @@ __global__ __launch_bounds__(256) void gemv_bf16_kernel(GemmArgs p) {
 #pragma unroll
   for (int m = 0; m < MB; ++m) {
     bf16x8 t = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (p.a_parts) {  // x = merged single-query attention slices (decode.hip), rounded to bf16 like the unsplit kernel
+      if (kin && m < p.M) {
+        const int hd = p.a_hd, hh = k0 / hd, dd = k0 - hh * hd;
+        const float* base = p.a_parts + ((long)(m * (p.K / hd) + hh) * p.a_nsplit) * (hd + 2);
+        float mx = -1e30f;
+        for (int i = 0; i < p.a_nsplit; ++i) mx = fmaxf(mx, base[i * (hd + 2) + hd]);
+        float o[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, l = 0.f;
+        for (int i = 0; i < p.a_nsplit; ++i) {
+          const float* bi = base + i * (hd + 2);
+          const float f = __expf(bi[hd] - mx);
+          l += f * bi[hd + 1];
+          const f32x4 o0 = *(const f32x4*)(bi + dd), o1 = *(const f32x4*)(bi + dd + 4);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { o[e] += f * o0[e]; o[4 + e] += f * o1[e]; }
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) xv[m][e] = bf2f(f2bf(o[e] / l));
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) xv[m][e] = 0.f;
+      }
+      continue;
+    }
     if (kin && m < p.M) t = *(const bf16x8*)(p.A + (long)m * p.lda + k0);
 #pragma unroll
     for (int e = 0; e < 8; ++e) xv[m][e] = bf2f((bf16_t)t[e]);
@@ -36,7 +59,8 @@ __global__ __launch_bounds__(256) void gemv_bf16_kernel(GemmArgs p) {
   for (int r = 0; r < GV_ROWS; ++r) {
     int n = n_base + r;
     if (n > p.N - 1) n = p.N - 1;
-    w[r] = kin ? *(const bf16x8*)(p.W + (long)n * p.ldw + k0) : (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+    // weights are read exactly once per step by exactly one wave: non-temporal, do not displace x / KV in L2/MALL
+    w[r] = kin ? __builtin_nontemporal_load((const bf16x8*)(p.W + (long)n * p.ldw + k0)) : (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
   }
   if constexpr (MB >= 4) {
     // 64 per-lane partials (4 rows x... = 64/MB rows x MB) are summed across the wave with a reduce-scatter butterfly:

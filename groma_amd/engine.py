@@ -363,9 +363,12 @@ class LlamaEngine:
             pq, sq = ops.gemv_partials(x, Lw["wqkv"][0])
             ops.decode_qkv_rope(pq, sq, q, cache.k[i], cache.vt[i], w["cos"], w["sin"], B=bs, H=H, hd=hd, pos0=past,
                                 pos_dev=pos_dev, pos_stride=pos_stride)
-            ops.decode_attention(q, cache.k[i], cache.vt[i], ctx, Smax=cache.smax if dyn else past + 1, q_pos0=past,
-                                 kv_len=kv_len, pos_dev=pos_dev, pos_stride=pos_stride)
-            po, so = ops.gemv_partials(ctx, Lw["wo"][0])
+            att = ops.decode_attention(q, cache.k[i], cache.vt[i], ctx, Smax=cache.smax if dyn else past + 1, q_pos0=past,
+                                       kv_len=kv_len, pos_dev=pos_dev, pos_stride=pos_stride)
+            if isinstance(att, tuple):  # key slices on separate blocks: the o-proj merges them while loading x
+                po, so = ops.gemv_partials(None, Lw["wo"][0], a_parts=att)
+            else:
+                po, so = ops.gemv_partials(ctx, Lw["wo"][0])
             ops.decode_reduce_norm(po, so, h, Lw["n2"], x, self.eps)
             ops.gemm(x, Lw["wgu"][0], act=3, out=y, tile=1, splits=(T + 511) // 512,
                      ws=ops._gemv_ws((T + 511) // 512, bs, 2 * self.I, h.device))

@@ -100,19 +100,27 @@ def gemm(a, w, *, out=None, bias=None, scale=None, resid=None, act=0, out_f32=Fa
     return out
 
 
-def gemv_partials(a, w, M=None):
+def gemv_partials(a, w, M=None, a_parts=None):
     """Decode-step weight streaming: returns (part f32 [splits, M, N], splits) with a @ w^T = sum_z part[z]; the
-    reduction is left to a fused consumer (decode_reduce_norm / decode_qkv_rope)."""
+    reduction is left to a fused consumer (decode_reduce_norm / decode_qkv_rope).
+    a_parts = (parts, nsplit, hd, M): the operand is the un-merged output of decode_attention(nsplit > 1)."""
     lib = _lib.load()
-    _chk(a, BF16, "a"); _chk(w, BF16, "w")
+    _chk(w, BF16, "w")
     N, K = w.shape
+    if a_parts is not None:
+        parts, nsplit, hd, M = a_parts
+        _chk(parts, F32, "a_parts")
+    else:
+        _chk(a, BF16, "a")
     if M is None:
         M = a.numel() // a.shape[-1]
     splits = (K + 511) // 512
-    ws = _gemv_ws(splits, M, N, a.device)
+    ws = _gemv_ws(splits, M, N, w.device)
     d = GemmDesc()
-    d.A, d.W, d.C, d.ws = a.data_ptr(), w.data_ptr(), None, ws.data_ptr()
-    d.M, d.N, d.K, d.lda, d.ldw, d.ldc = M, N, K, a.shape[-1], w.stride(0), N
+    d.A, d.W, d.C, d.ws = (a.data_ptr() if a is not None else None), w.data_ptr(), None, ws.data_ptr()
+    d.M, d.N, d.K, d.lda, d.ldw, d.ldc = M, N, K, K, w.stride(0), N
+    if a_parts is not None:
+        d.a_parts, d.a_nsplit, d.a_hd = parts.data_ptr(), nsplit, hd
     d.splits, d.tile = splits, 2
     _lib.check(lib.gr_gemm_bf16(ctypes.byref(d), _stream()), "gr_gemm_bf16")
     return ws, splits
@@ -135,8 +143,13 @@ def decode_qkv_rope(part, splits, q, k, vt, cos, sin, *, B, H, hd, pos0=0, pos_d
                                       _p(pos_dev), pos_stride, _stream()), "gr_decode_qkv_rope")
 
 
-def decode_attention(q, k, vt, out, *, Smax, q_pos0=0, kv_len=None, scale=None, pos_dev=None, pos_stride=0):
-    """q [B,H,1,hd] against the cache k [B,H,kv_stride,hd] / vt [B,H,hd,kv_stride] -> out bf16 [B, H*hd]"""
+_DEC_ATT_WS = {}
+
+
+def decode_attention(q, k, vt, out, *, Smax, q_pos0=0, kv_len=None, scale=None, pos_dev=None, pos_stride=0, nsplit=None):
+    """q [B,H,1,hd] against the cache k [B,H,kv_stride,hd] / vt [B,H,hd,kv_stride] -> out bf16 [B, H*hd].
+    nsplit None = enough key slices per (row, head) to put a block on every CU.  With nsplit > 1 `out` is NOT written:
+    the return value is (parts, nsplit, hd, B) for gemv_partials(..., a_parts=...) (the o-proj merges the slices)."""
     lib = _lib.load()
     _chk(q, BF16, "q"); _chk(k, BF16, "k"); _chk(vt, BF16, "vt"); _chk(out, BF16, "out")
     B, H, _, hd = q.shape
@@ -146,8 +159,22 @@ def decode_attention(q, k, vt, out, *, Smax, q_pos0=0, kv_len=None, scale=None, 
         _chk(pos_dev, I32, "pos_dev")
     if kv_len is not None:
         _chk(kv_len, I32, "kv_len")
+    if nsplit is None:
+        # measured on MI355X (tests/diag/dec_attn_bench.py): one block per (row, head) streams the cache at ~4.2 TB/s
+        # marginal once B*H >= 128; slicing only pays when fewer blocks than that exist (the consumer-side merge costs
+        # ~5 us in the o-proj GEMV).  Independent of S, so eager and graph-replayed steps slice identically.
+        nsplit = 1 if B * H >= 128 else max(1, min(4, 128 // (B * H)))
+    parts = None
+    if nsplit > 1:
+        key = (B * H, nsplit, hd, str(q.device))
+        if key not in _DEC_ATT_WS:
+            _DEC_ATT_WS[key] = torch.empty((B * H * nsplit * (hd + 2),), dtype=F32, device=q.device)
+        parts = _DEC_ATT_WS[key]
     _lib.check(lib.gr_decode_attention(_p(q), _p(k), _p(vt), _p(out), _p(kv_len), B, H, Smax, k.shape[2], hd, q_pos0,
-                                       scale, _p(pos_dev), pos_stride, _stream()), "gr_decode_attention")
+                                       scale, _p(pos_dev), pos_stride, nsplit, _p(parts), _stream()),
+               "gr_decode_attention")
+    if nsplit > 1:
+        return parts, nsplit, hd, B
     return out
 
 

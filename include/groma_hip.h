@@ -69,6 +69,11 @@ typedef struct gr_gemm_desc {
   int fp8;
   const float* a_scale; /* [M] per-row scale of A, or NULL (= 1)                                     */
   const float* w_scale; /* [N] per-output-channel scale of W (required when fp8)                     */
+  /* tile 1/2 only: A is the not-yet-merged output of gr_decode_attention(nsplit > 1): f32
+   * [M * K/a_hd heads][a_nsplit][a_hd + 2] = (un-normalised o, running max, running sum) per key slice; the kernel
+   * merges the slices (in slice order) while loading its x operand and rounds to bf16 exactly as the nsplit = 1 path */
+  const float* a_parts;
+  int a_nsplit, a_hd;
 } gr_gemm_desc;
 int gr_gemm_bf16(const gr_gemm_desc* d, hipStream_t stream);
 
@@ -109,6 +114,10 @@ int gr_qkv_split(const void* qkv, void* q, void* k, void* vt, const float* cosT,
  *   gr_decode_qkv_rope   : qkv = bf16(sum_z part) with N = 3*H*hd; rotate_half RoPE at the row's position; writes
  *                          q [B,H,1,hd], K-cache row k[b,h,pos,:], V^T-cache column vt[b,h,:,pos]
  *   gr_decode_attention  : out[b, h*hd + d] = softmax(q.K^T * scale)[0 .. pos] . V   (Smax <= 8192 = LDS score buffer)
+ *                          nsplit > 1 cuts every row's keys into nsplit slices (one block each, so B*H*nsplit blocks
+ *                          fill the chip at small B) and writes parts f32 [B*H][nsplit][hd+2] instead of out; the
+ *                          o-proj GEMV merges them while loading its operand (gr_gemm_desc.a_parts) -- no cross-block
+ *                          hand-off inside the launch, hence no device-scope fence (an L2 write-back on a multi-XCD part)
  * Position of row b = pos_dev ? pos_dev[b * pos_stride] : pos0 / q_pos0 (see gr_attention_bf16). */
 int gr_decode_reduce_norm(const float* part, int splits, float* h, const float* gamma, void* x, int M, int N, float eps,
                           hipStream_t stream);
@@ -117,7 +126,7 @@ int gr_decode_qkv_rope(const float* part, int splits, void* q, void* k, void* vt
                        hipStream_t stream);
 int gr_decode_attention(const void* q, const void* k, const void* vt, void* out, const int* kv_len, int B, int H, int Smax,
                         int kv_stride, int head_dim, int q_pos0, float scale, const int* pos_dev, int pos_stride,
-                        hipStream_t stream);
+                        int nsplit, float* parts, hipStream_t stream);
 
 /* ------------------------------------------------------------------------- packing / movement -- */
 int gr_patchify(const float* images, void* out, int B, int S, int P, int Kpad, hipStream_t stream);

@@ -37,6 +37,7 @@ def test_bad_arguments_are_rejected_without_a_gpu():
     assert lib.gr_roi_align_pack(None, None, None, 0, 8, 4, 4, 14, 14, 1.0, 2, 1, 1, 0, None) == 0  # empty ROI set is fine
     assert lib.gr_roi_align_pack(None, None, None, 3, 8, 4, 4, 14, 14, 1.0, 2, 1, 1, 0, None) == 22
     assert lib.gr_attention_bf16(None, None, None, None, None, 1, 1, 1, 1, 64, 64, 0, 0, 1.0, None, 0, None) == 22
+    assert lib.gr_decode_attention(None, None, None, None, None, 1, 1, 1, 64, 64, 0, 1.0, None, 0, 1, None, None) == 22
     assert lib.gr_greedy_advance(None, None, None, None, None, None, None, 4, -1, 0, 8, 1, 1, None) == 22
 
 

@@ -454,9 +454,10 @@ def test_decode_qkv_rope_matches_prefill_split(dev, hd, use_dev_pos):
     assert torch.equal(outs[0][2], outs[1][2])  # V is a pure copy
 
 
+@pytest.mark.parametrize("nsplit", [1, None, 3])
 @pytest.mark.parametrize("B,H,hd,S,mode", [(4, 32, 128, 583, "host"), (2, 8, 64, 70, "host"), (4, 32, 128, 640, "dev"),
                                            (3, 4, 128, 1500, "ragged"), (2, 8, 64, 300, "len")])
-def test_decode_attention(dev, B, H, hd, S, mode):
+def test_decode_attention(dev, B, H, hd, S, mode, nsplit):
     ops = _ops()
     stride = (S + 63) // 64 * 64 + 64
     q = rnd((B, H, 1, hd), dev, seed=1).bfloat16()
@@ -468,23 +469,27 @@ def test_decode_attention(dev, B, H, hd, S, mode):
     out = torch.empty((B, H * hd), dtype=torch.bfloat16, device=dev)
     kv_len, lens = None, [S] * B
     if mode == "host":
-        ops.decode_attention(q, k, vt, out, Smax=S, q_pos0=S - 1)
+        r = ops.decode_attention(q, k, vt, out, Smax=S, q_pos0=S - 1, nsplit=nsplit)
     elif mode == "dev":
         pos = torch.tensor([S - 1], dtype=torch.int32, device=dev)
-        ops.decode_attention(q, k, vt, out, Smax=stride, pos_dev=pos, pos_stride=0)
+        r = ops.decode_attention(q, k, vt, out, Smax=stride, pos_dev=pos, pos_stride=0, nsplit=nsplit)
     elif mode == "ragged":
         lens = [S, S - 313, 1][:B]
         pos = torch.tensor([l - 1 for l in lens], dtype=torch.int32, device=dev)
-        ops.decode_attention(q, k, vt, out, Smax=stride, pos_dev=pos, pos_stride=1)
+        r = ops.decode_attention(q, k, vt, out, Smax=stride, pos_dev=pos, pos_stride=1, nsplit=nsplit)
     else:
         lens = [S - 37, S][:B]
         kv_len = torch.tensor(lens, dtype=torch.int32, device=dev)
-        ops.decode_attention(q, k, vt, out, Smax=S, q_pos0=S - 1, kv_len=kv_len)
+        r = ops.decode_attention(q, k, vt, out, Smax=S, q_pos0=S - 1, kv_len=kv_len, nsplit=nsplit)
     ref = torch.empty((B, H, hd), device=dev)
     for b in range(B):
         L = lens[b]
         s = torch.einsum("hd,hsd->hs", q[b, :, 0].float(), k[b, :, :L].float()) * hd ** -0.5
         ref[b] = torch.einsum("hs,hsd->hd", torch.softmax(s, -1), v[b, :, :L].float())
+    if isinstance(r, tuple):  # key slices: merged by the consumer GEMV's operand load -- use an identity weight
+        eye = torch.eye(H * hd, device=dev).bfloat16()
+        part, sp = ops.gemv_partials(None, eye, a_parts=r)
+        out = part[:sp].sum(0)
     assert torch.isfinite(out.float()).all()
     assert relerr(out, ref.view(B, H * hd)) < 6e-3
     if mode == "host":  # and against the MFMA tile kernel the prefill uses
