@@ -590,19 +590,22 @@ __global__ __launch_bounds__(256) void greedy_advance_kernel(const long* __restr
   if (threadIdx.x == 0) cnt = 0;
   __syncthreads();
   const int st = *step;
+  const bool per_row = inc_pos == 2;  // ragged batch: every row owns its KV write position (pos_rows == rows)
   for (int b = threadIdx.x; b < rows; b += 256) {
     long n = nxt[b];
-    if (eos >= 0) {
-      if (!unfinished[b]) n = pad;
-      if (n == eos) unfinished[b] = 0;
+    const bool was = unfinished[b] != 0;
+    if (eos >= 0 || per_row) {  // (a ragged batch also uses `unfinished` as the row-occupied mask)
+      if (!was) n = pad;
+      if (eos >= 0 && n == eos) unfinished[b] = 0;
       if (unfinished[b]) atomicAdd(&cnt, 1);
     } else {
       atomicAdd(&cnt, 1);
     }
     if (st < seq_ld) seq[(long)b * seq_ld + st] = n;
     tok[b] = n;
+    if (inc_pos && per_row && was) pos[b] += 1;  // idle rows keep re-writing one scratch position
   }
-  if (inc_pos)
+  if (inc_pos && !per_row)
     for (int r = threadIdx.x; r < pos_rows; r += 256) pos[r] += 1;
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -614,6 +617,7 @@ extern "C" int gr_greedy_advance(const long* nxt, long* tok, long* unfinished, l
                                  int* n_unfinished, int rows, long eos, long pad, int seq_ld, int pos_rows, int inc_pos,
                                  hipStream_t stream) {
   if (!nxt || !tok || !unfinished || !seq || !pos || !step || !n_unfinished || rows <= 0 || seq_ld <= 0) return GR_EINVAL;
+  if (inc_pos < 0 || inc_pos > 2 || (inc_pos == 2 && pos_rows != rows)) return GR_EINVAL;
   hipLaunchKernelGGL(greedy_advance_kernel, dim3(1), dim3(256), 0, stream, nxt, tok, unfinished, seq, pos, step,
                      n_unfinished, rows, eos, pad, seq_ld, pos_rows, inc_pos);
   GR_CHECK_LAUNCH();

@@ -1,0 +1,264 @@
+"""Continuous-batch decode loop + KV-cache manager.
+
+The reference serves one request at a time, one python-driven forward per token
+(groma/serve/model_worker.py:287-338: prefill with `model(input_ids, images=..., use_cache=True)`, then
+`model(input_ids=[[token]], past_key_values=...)` per token, arg-max / multinomial on the host, stop on EOS or a
+stop id).  Decode is HBM-bound on the 13.2 GB weight stream, and that stream is shared by every row of
+a step -- so the MI355X design batches the decode steps of *different requests*:
+
+  * a fixed arena of `max_rows` KV slots ([rows, H, max_len, hd] per layer, K and V^T) -- the KV manager hands a slot
+    to a request at admission and takes it back when the request finishes; nothing is copied or compacted;
+  * a request is prefilled ALONE (batch 1) straight into its slot, so its prompt pass is bit-identical to
+    `GromaModel.forward` on that request and independent of whatever else is being served;
+  * every decode step advances ALL occupied rows with one captured hipGraph: per-row positions live on the device
+    (`pos_dev`, stride 1 -- csrc/decode.hip), idle rows are masked, the host only reads back the `max_rows` new ids;
+  * rows are computed independently by every kernel of the step (GEMV rows, per-(row, head) attention), so a
+    request's tokens do not depend on its neighbours or on when it was admitted (tests/test_serving_gpu.py).
+
+Ragged lengths are exact here: each row attends to its own [0, pos] -- the padded-prefix artefact of batched HF
+generate cannot occur because rows are never padded against each other.
+"""
+from collections import deque
+from dataclasses import dataclass, field
+from typing import List, Optional
+
+import torch
+
+from . import engine, ops
+
+I32, I64, F32 = torch.int32, torch.int64, torch.float32
+
+
+class SlotTable:
+    """KV-arena bookkeeping (host side, no device work): which row belongs to which request."""
+
+    def __init__(self, n):
+        self.n = n
+        self.owner = [None] * n
+        self._free = deque(range(n))
+
+    def acquire(self, rid):
+        if not self._free:
+            return None
+        s = self._free.popleft()
+        self.owner[s] = rid
+        return s
+
+    def release(self, slot):
+        if self.owner[slot] is None:
+            raise ValueError(f"slot {slot} is not in use")
+        self.owner[slot] = None
+        self._free.append(slot)
+
+    @property
+    def n_free(self):
+        return len(self._free)
+
+    def active(self):
+        return [s for s in range(self.n) if self.owner[s] is not None]
+
+
+@dataclass
+class Request:
+    rid: int
+    input_ids: torch.Tensor                 # [P] int64 (un-expanded prompt: <image> / <region> placeholders)
+    image: torch.Tensor                     # [3, S, S] float
+    max_new_tokens: int = 256
+    refer_boxes: Optional[torch.Tensor] = None
+    ground_boxes: Optional[torch.Tensor] = None
+    eos_token_id: Optional[int] = None
+    stop_token_id: Optional[int] = None     # model_worker.py:277-283 `stop` when it tokenises to one id
+    seed: Optional[int] = None              # torch.manual_seed before the prefill (region shuffle)
+    tokens: List[int] = field(default_factory=list)
+    pred_boxes: Optional[torch.Tensor] = None
+    slot: Optional[int] = None
+    prompt_len: int = 0                     # expanded length L in the cache
+    done: bool = False
+    error: Optional[str] = None
+
+
+class _RowView:
+    """KVCache interface over ONE arena row, so GromaModel.forward prefills directly into the slot."""
+
+    def __init__(self, arena, row):
+        self.k = [t[row:row + 1] for t in arena.k]
+        self.vt = [t[row:row + 1] for t in arena.vt]
+        self.bs, self.smax, self.seq_len = 1, arena.smax, 0
+
+    def __len__(self):
+        return len(self.k)
+
+    def __getitem__(self, l):
+        S = self.seq_len
+        return (self.k[l][:, :, :S], self.vt[l][:, :, :, :S].transpose(2, 3))
+
+    def __bool__(self):
+        return True
+
+    def grow(self, smax):
+        raise RuntimeError("a KV slot cannot grow: the request exceeds max_len")
+
+
+class ContinuousBatcher:
+    def __init__(self, model, max_rows=8, max_len=1024, use_graph=True):
+        if max_rows < 1 or max_rows > 8:
+            raise ValueError("max_rows must be in 1..8 (decode GEMV row block)")
+        if max_len % 64 or max_len > 8192:
+            raise ValueError("max_len must be a multiple of 64 and <= 8192")
+        if model.fp8:
+            raise NotImplementedError("the continuous batcher drives the bf16 decode kernels")
+        self.model, self.llm = model, model.llm
+        self.rows, self.max_len, self.use_graph = max_rows, max_len, use_graph
+        dev = model.device
+        self.arena = self.llm.new_cache(max_rows, max_len, dev)
+        self.slots = SlotTable(max_rows)
+        self.queue = deque()
+        self.live = {}
+        self._next_rid = 0
+        # device-resident loop state: one entry per row
+        self.tok = torch.zeros((max_rows,), dtype=I64, device=dev)
+        self.nxt = torch.zeros((max_rows,), dtype=I64, device=dev)
+        self.occupied = torch.zeros((max_rows,), dtype=I64, device=dev)   # gr_greedy_advance `unfinished`
+        self.pos = torch.zeros((max_rows,), dtype=I32, device=dev)  # idle rows rewrite position 0 of their own (free) slot
+        self.step_ctr = torch.zeros((1,), dtype=I32, device=dev)
+        self.n_live = torch.zeros((1,), dtype=I32, device=dev)
+        self._seq = torch.zeros((max_rows, 1), dtype=I64, device=dev)
+        self.h = torch.zeros((max_rows, self.llm.T), dtype=F32, device=dev)
+        self.graph = None
+        self.steps = 0
+
+    # ------------------------------------------------------------------ request intake
+    def submit(self, input_ids, image, max_new_tokens=256, refer_boxes=None, ground_boxes=None, eos_token_id="config",
+               stop_token_id=None, seed=None):
+        if eos_token_id == "config":
+            eos_token_id = self.model.generation_config.eos_token_id
+        r = Request(self._next_rid, input_ids.reshape(-1).to(I64).cpu(), image, int(max_new_tokens), refer_boxes, ground_boxes,
+                    eos_token_id, stop_token_id, seed)
+        self._next_rid += 1
+        self.queue.append(r)
+        self.live[r.rid] = r
+        return r.rid
+
+    # ------------------------------------------------------------------ one decode step of every occupied row
+    def _decode(self):
+        llm = self.llm
+        ops.embed_gather(self.tok, llm.w["embed"], llm.w["new_embed"], out=self.h)
+        llm.forward(self.h, self.rows, 1, self.arena, pos_dev=self.pos, pos_stride=1)
+        ops.argmax_rows(llm.ws.get("llm_logits", (self.rows, llm.Vpad), F32), llm.V, out=self.nxt)
+        ops.greedy_advance(self.nxt, self.tok, self.occupied, self._seq, self.pos, self.step_ctr, self.n_live,
+                           eos=None, pad=0, inc_pos=2)
+
+    def _capture(self):
+        """Capture the step once, before any request owns a slot (the warm-up steps write KV at the idle position)."""
+        side = torch.cuda.Stream(device=self.tok.device)
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                self._decode()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            self._decode()
+        self.graph = g
+
+    # ------------------------------------------------------------------ admission: prefill alone, into the slot
+    def _admit(self, r):
+        m = self.model
+        slot = self.slots.acquire(r.rid)
+        if slot is None:
+            return False
+        view = _RowView(self.arena, slot)
+        try:
+            if r.seed is not None:
+                torch.manual_seed(r.seed)
+            out = m.forward(input_ids=r.input_ids[None].clone(), images=r.image[None],
+                            refer_boxes=[r.refer_boxes] if r.refer_boxes is not None else None,
+                            ground_boxes=[r.ground_boxes] if r.ground_boxes is not None else None,
+                            use_cache=True, return_dict=True, output_hidden_states=True, _last_logits_only=True,
+                            _reserve=r.max_new_tokens, _cache=view)
+        except RuntimeError as e:
+            self.slots.release(slot)
+            r.done, r.error = True, str(e)
+            return True
+        r.slot, r.prompt_len = slot, view.seq_len
+        r.pred_boxes = out.hidden_states[1]["pred_boxes"][0]
+        first = int(ops.argmax_rows(out.logits[:, -1, :].contiguous(), out.logits.shape[-1])[0])
+        self._emit(r, first)
+        if not r.done:
+            self.tok[slot] = first
+            self.pos[slot] = r.prompt_len
+            self.occupied[slot] = 1
+        return True
+
+    def _emit(self, r, token):
+        r.tokens.append(token)
+        if (r.eos_token_id is not None and token == r.eos_token_id) or \
+                (r.stop_token_id is not None and token == r.stop_token_id) or len(r.tokens) >= r.max_new_tokens:
+            self._finish(r)
+
+    def _finish(self, r):
+        r.done = True
+        if r.slot is not None:
+            s = r.slot
+            self.occupied[s] = 0
+            self.pos[s] = 0
+            self.slots.release(s)
+            r.slot = None
+
+    # ------------------------------------------------------------------ scheduler tick
+    def step(self):
+        """Admit what fits, then advance every occupied row by one token.  Returns [(rid, token, done), ...]."""
+        if self.use_graph and self.graph is None:
+            if self.slots.n_free != self.rows:
+                raise RuntimeError("capture must precede the first admission")
+            self._capture()
+        events = []
+        while self.queue and self.slots.n_free:
+            r = self.queue.popleft()
+            self._admit(r)
+            if r.error is None:
+                events.append((r.rid, r.tokens[-1], r.done))
+            else:
+                events.append((r.rid, None, True))
+        act = self.slots.active()
+        if not act:
+            return events
+        if self.use_graph:
+            self.graph.replay()
+        else:
+            self._decode()
+        self.steps += 1
+        new = self.tok.tolist()  # the only per-step host read: max_rows ids
+        for s in act:
+            r = self.live[self.slots.owner[s]]
+            self._emit(r, int(new[s]))
+            events.append((r.rid, r.tokens[-1], r.done))
+        return events
+
+    def run_until_done(self, max_steps=100000):
+        for _ in range(max_steps):
+            if not self.queue and not self.slots.active():
+                break
+            self.step()
+        return {rid: r for rid, r in self.live.items()}
+
+    def result(self, rid, pop=True):
+        r = self.live.pop(rid) if pop else self.live[rid]
+        return r
+
+    # ------------------------------------------------------------------ model_worker.generate_stream analogue
+    def generate_stream(self, input_ids, image, max_new_tokens=256, stream_interval=1, **kw):
+        """Yield the generated ids of ONE request every `stream_interval` tokens while other requests keep decoding
+        (groma/serve/model_worker.py:287-338 yields the decoded text; tokenisation stays with the caller)."""
+        rid = self.submit(input_ids, image, max_new_tokens=max_new_tokens, **kw)
+        r = self.live[rid]
+        sent = 0
+        while not r.done:
+            self.step()
+            if r.error:
+                raise RuntimeError(r.error)
+            if len(r.tokens) - sent >= stream_interval or r.done:
+                sent = len(r.tokens)
+                yield list(r.tokens)
+        self.live.pop(rid, None)

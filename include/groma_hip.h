@@ -151,7 +151,9 @@ int gr_scatter_rows_f32(const float* src, const int* row_idx, float* dst, long n
 int gr_argmax_rows(const float* x, long* out, int rows, int V, long ld, hipStream_t stream);
 /* one step of HF 4.32 GenerationMixin.greedy_search bookkeeping on the device (reference: the loop HF runs around
  * groma/model/groma.py:176-200): n = unfinished ? nxt : pad; seq[:, *step] = n; tok = n; unfinished &= n != eos;
- * ++*step; pos[0..pos_rows) += inc_pos; *n_unfinished = sum(unfinished).  eos < 0 = no stopping token. */
+ * ++*step; pos[0..pos_rows) += inc_pos; *n_unfinished = sum(unfinished).  eos < 0 = no stopping token.
+ * inc_pos == 2 (pos_rows == rows) is the ragged (continuous-batching) form: only rows with unfinished != 0 advance
+ * their own position and emit a token; idle rows emit pad and stay put. */
 int gr_greedy_advance(const long* nxt, long* tok, long* unfinished, long* seq, int* pos, int* step, int* n_unfinished,
                       int rows, long eos, long pad, int seq_ld, int pos_rows, int inc_pos, hipStream_t stream);
 

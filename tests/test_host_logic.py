@@ -108,3 +108,17 @@ def test_shard_range_covers_batch():
             spans = [shard_range(B, W, r) for r in range(W)]
             assert spans[0][0] == 0 and spans[-1][1] == B
             assert all(spans[i][1] == spans[i + 1][0] for i in range(W - 1))
+
+
+def test_slot_table():
+    from groma_amd.serving import SlotTable
+    t = SlotTable(3)
+    a, b, c = t.acquire("a"), t.acquire("b"), t.acquire("c")
+    assert sorted([a, b, c]) == [0, 1, 2] and t.acquire("d") is None and t.n_free == 0
+    t.release(b)
+    assert t.n_free == 1 and t.active() == sorted([a, c])
+    assert t.acquire("d") == b and t.owner[b] == "d"
+    import pytest as _pt
+    t.release(a)
+    with _pt.raises(ValueError):
+        t.release(a)
