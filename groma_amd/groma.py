@@ -186,7 +186,7 @@ class GromaModel:
         selected, aux = self.propose(hidden4, refer_boxes, ground_boxes, debug)
         return hidden4, selected, aux
 
-    def propose(self, hidden4, refer_boxes=None, ground_boxes=None, debug=None):
+    def propose(self, hidden4, refer_boxes=None, ground_boxes=None, debug=None, seeds=None):
         """Steps C-E: DDETR proposer -> fused scores -> on-device NMS -> host randperm (one D2H of <1 KB/image)."""
         cfg = self.config
         bs = hidden4[0].shape[0]
@@ -219,6 +219,8 @@ class GromaModel:
         for i in range(bs):
             nk = int(n_keep_h[i])
             if nk > 0:  # groma.py:273-276 -- torch.randperm on the CPU global RNG (T4)
+                if seeds is not None and seeds[i] is not None:  # serving: each request owns its shuffle seed
+                    torch.manual_seed(int(seeds[i]))
                 inds = keep_h[i, :nk]
                 inds = inds[torch.randperm(nk)]
             else:       # groma.py:277-279
@@ -251,7 +253,8 @@ class GromaModel:
     # ------------------------------------------------------------------ forward
     def forward(self, input_ids=None, inputs_embeds=None, labels=None, attention_mask=None, images=None,
                 refer_boxes=None, ground_boxes=None, past_key_values=None, use_cache=False, output_attentions=False,
-                output_hidden_states=False, return_dict=False, _last_logits_only=False, _reserve=0, _cache=None):
+                output_hidden_states=False, return_dict=False, _last_logits_only=False, _reserve=0, _cache=None,
+                _seeds=None):
         if not self._loaded:
             raise RuntimeError("GromaModel has no weights: use from_pretrained / from_state_dict / from_synthetic")
         if output_attentions:
@@ -274,7 +277,7 @@ class GromaModel:
                     mid = ops.gemm(s2d, self.bridge["w0"], bias=self.bridge["b0"], act=1)
                     image_features = ops.gemm(mid, self.bridge["w2"], bias=self.bridge["b2"], out_f32=True)
                     image_features.record_stream(main)
-                selected_boxes, aux = self.propose(hidden4, refer_boxes, ground_boxes)
+                selected_boxes, aux = self.propose(hidden4, refer_boxes, ground_boxes, seeds=_seeds)
                 main.wait_stream(side)
                 bs = len(selected_boxes)
                 ids_h = input_ids.cpu()
@@ -343,6 +346,7 @@ class GromaModel:
                 vis_outputs = {'pred_boxes': selected_boxes,
                                'image_features': image_features.view(bs, n_img_tok, -1),
                                'region_features': region_features}
+                aux["lengths"] = mask_h.sum(-1).tolist()  # expanded length of every row (right padding excluded)
                 self._last_aux = aux
             else:
                 cache = past_key_values

@@ -78,12 +78,12 @@ class Request:
 
 
 class _RowView:
-    """KVCache interface over ONE arena row, so GromaModel.forward prefills directly into the slot."""
+    """KVCache interface over the first `n` rows of a cache, so GromaModel.forward prefills straight into it."""
 
-    def __init__(self, arena, row):
-        self.k = [t[row:row + 1] for t in arena.k]
-        self.vt = [t[row:row + 1] for t in arena.vt]
-        self.bs, self.smax, self.seq_len = 1, arena.smax, 0
+    def __init__(self, arena, n):
+        self.k = [t[:n] for t in arena.k]
+        self.vt = [t[:n] for t in arena.vt]
+        self.bs, self.smax, self.seq_len = n, arena.smax, 0
 
     def __len__(self):
         return len(self.k)
@@ -111,6 +111,7 @@ class ContinuousBatcher:
         self.rows, self.max_len, self.use_graph = max_rows, max_len, use_graph
         dev = model.device
         self.arena = self.llm.new_cache(max_rows, max_len, dev)
+        self.staging = self.llm.new_cache(max_rows, max_len, dev)  # batched prefills land here, then move to their slots
         self.slots = SlotTable(max_rows)
         self.queue = deque()
         self.live = {}
@@ -162,34 +163,57 @@ class ContinuousBatcher:
             self._decode()
         self.graph = g
 
-    # ------------------------------------------------------------------ admission: prefill alone, into the slot
-    def _admit(self, r):
-        m = self.model
-        slot = self.slots.acquire(r.rid)
-        if slot is None:
-            return False
-        view = _RowView(self.arena, slot)
+    # ------------------------------------------------------------------ admission: one batched prefill per tick
+    def _admit(self, reqs):
+        """Prefill `reqs` (<= free slots) in ONE forward and move each row's KV into its slot.  Row results of the
+        prefill are bit-identical to a batch-1 forward of the same request (every kernel of the path is row- /
+        image-independent, tests/test_fullsize_properties_gpu.py), so admission order and company never change a
+        request's tokens; each request's region shuffle draws from its own seed."""
+        m, k = self.model, len(reqs)
+        P = max(r.input_ids.numel() for r in reqs)
+        ids = torch.full((k, P), int(m.pad_token_id), dtype=I64)
+        for i, r in enumerate(reqs):
+            ids[i, : r.input_ids.numel()] = r.input_ids
+        empty = torch.zeros((0, 4))
+        rb = [r.refer_boxes if r.refer_boxes is not None else empty for r in reqs] if any(r.refer_boxes is not None for r in reqs) else None
+        gb = [r.ground_boxes if r.ground_boxes is not None else empty for r in reqs] if any(r.ground_boxes is not None for r in reqs) else None
+        view = _RowView(self.staging, k)
         try:
-            if r.seed is not None:
-                torch.manual_seed(r.seed)
-            out = m.forward(input_ids=r.input_ids[None].clone(), images=r.image[None],
-                            refer_boxes=[r.refer_boxes] if r.refer_boxes is not None else None,
-                            ground_boxes=[r.ground_boxes] if r.ground_boxes is not None else None,
-                            use_cache=True, return_dict=True, output_hidden_states=True, _last_logits_only=True,
-                            _reserve=r.max_new_tokens, _cache=view)
+            out = m.forward(input_ids=ids, images=torch.stack([r.image for r in reqs]), refer_boxes=rb, ground_boxes=gb,
+                            use_cache=True, return_dict=True, output_hidden_states=True, _cache=view,
+                            _seeds=[r.seed for r in reqs])
         except RuntimeError as e:
-            self.slots.release(slot)
-            r.done, r.error = True, str(e)
-            return True
-        r.slot, r.prompt_len = slot, view.seq_len
-        r.pred_boxes = out.hidden_states[1]["pred_boxes"][0]
-        first = int(ops.argmax_rows(out.logits[:, -1, :].contiguous(), out.logits.shape[-1])[0])
-        self._emit(r, first)
-        if not r.done:
-            self.tok[slot] = first
-            self.pos[slot] = r.prompt_len
-            self.occupied[slot] = 1
-        return True
+            if k == 1:
+                reqs[0].done, reqs[0].error = True, str(e)
+                return
+            for r in reqs:  # isolate the offender: admit one by one
+                self._admit([r])
+            return
+        lengths = m._last_aux["lengths"]
+        rows, slots = [], []
+        for i, r in enumerate(reqs):
+            r.prompt_len = int(lengths[i])
+            r.pred_boxes = out.hidden_states[1]["pred_boxes"][i]
+            if r.prompt_len + r.max_new_tokens > self.max_len:
+                r.done, r.error = True, "prompt + max_new_tokens exceeds the KV slot (max_len)"
+                continue
+            first = int(ops.argmax_rows(out.logits[i, r.prompt_len - 1][None].contiguous(), out.logits.shape[-1])[0])
+            self._emit(r, first)
+            if r.done:
+                continue
+            r.slot = self.slots.acquire(r.rid)
+            rows.append(i)
+            slots.append(r.slot)
+            self.tok[r.slot] = first
+            self.pos[r.slot] = r.prompt_len
+            self.occupied[r.slot] = 1
+        if rows:
+            dev = self.tok.device
+            src = torch.tensor(rows, dtype=I64, device=dev)
+            dst = torch.tensor(slots, dtype=I64, device=dev)
+            for l in range(len(self.arena.k)):
+                self.arena.k[l].index_copy_(0, dst, self.staging.k[l].index_select(0, src))
+                self.arena.vt[l].index_copy_(0, dst, self.staging.vt[l].index_select(0, src))
 
     def _emit(self, r, token):
         r.tokens.append(token)
@@ -214,13 +238,11 @@ class ContinuousBatcher:
                 raise RuntimeError("capture must precede the first admission")
             self._capture()
         events = []
-        while self.queue and self.slots.n_free:
-            r = self.queue.popleft()
-            self._admit(r)
-            if r.error is None:
-                events.append((r.rid, r.tokens[-1], r.done))
-            else:
-                events.append((r.rid, None, True))
+        if self.queue and self.slots.n_free:
+            batch = [self.queue.popleft() for _ in range(min(len(self.queue), self.slots.n_free))]
+            self._admit(batch)
+            for r in batch:
+                events.append((r.rid, r.tokens[-1] if r.tokens else None, r.done))
         act = self.slots.active()
         if not act:
             return events
