@@ -137,7 +137,7 @@ class GromaModel:
                 sd.update(torch.load(f, map_location="cpu"))
         if not sd:
             raise FileNotFoundError(f"no weight shards under {path}")
-        return cls.from_state_dict(config, sd, device)
+        return cls.from_state_dict(config, sd, device, fp8=bool(kw.get("fp8", False)))
 
     def cuda(self, device=None):
         return self
