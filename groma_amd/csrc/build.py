@@ -17,6 +17,7 @@ SOURCES = {
     "decode.hip": [],
     "norm.hip": [],
     "pack.hip": [],
+    "preprocess.hip": [],
     "ddetr.hip": [],
     # index-exact kernels: plain IEEE fp32 sequences, no FMA contraction (see oracle/roi_nms.c)
     "select.hip": ["-ffp-contract=off"],

@@ -128,6 +128,15 @@ int gr_decode_attention(const void* q, const void* k, const void* vt, void* out,
                         int kv_stride, int head_dim, int q_pos0, float scale, const int* pos_dev, int pos_stride,
                         int nsplit, float* parts, hipStream_t stream);
 
+/* ---------------------------------------------------------------------- image preprocessing -- */
+/* PIL Image.resize (BICUBIC, 8-bit fixed point, two passes; groma/eval/run_groma.py:79) on interleaved uint8 RGB, with
+ * Pillow's host-computed window table bounds [out,2] = (first index, count) and 22-bit fixed-point coef [out,ksize];
+ * the vertical pass optionally emits the HF processor's rescale+normalise through lut f32 [3,256] as f32 [3,Hout,W]. */
+int gr_resize_h_u8(const void* in, void* out, const int* bounds, const int* coef, int H, int Win, int Wout, int ksize,
+                   hipStream_t stream);
+int gr_resize_v_norm(const void* in, void* out_u8, float* out_f32, const int* bounds, const int* coef, const float* lut,
+                     int Hin, int Hout, int W, int ksize, hipStream_t stream);
+
 /* ------------------------------------------------------------------------- packing / movement -- */
 int gr_patchify(const float* images, void* out, int B, int S, int P, int Kpad, hipStream_t stream);
 int gr_fill_rows_f32(const float* src, float* dst, int rows, int C, long ld_dst, hipStream_t stream);
