@@ -122,3 +122,19 @@ def test_slot_table():
     t.release(a)
     with _pt.raises(ValueError):
         t.release(a)
+
+
+def test_prompt_templates_match_reference_goldens():
+    """tests/golden/prompt_golden.json was produced by the reference's own conversation.py (make_prompt_golden.py)"""
+    import json, os
+    from groma_amd import prompt
+    cases = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "prompt_golden.json")))
+    assert len(cases) >= 14
+    for c in cases:
+        if c["dialog"] == "run_groma":
+            got = prompt.groma_query_prompt(c["query"], c["template"])
+        elif c["template"] == "simple":
+            got = prompt.render("simple", c["turns"])
+        else:
+            got = prompt.render(c["template"], [(r, tuple(m) if isinstance(m, list) else m) for r, m in c["turns"]])
+        assert got == c["prompt"], (c["template"], c["dialog"])
