@@ -18,7 +18,17 @@ def _worker(rank, world, port, q):
     counts = [gdist.shard_range(B, world, r)[1] - gdist.shard_range(B, world, r)[0] for r in range(world)]
     got = gdist.all_gather_rows(local, counts)
     even = gdist.all_gather_rows(torch.full((2, 4), float(rank)))
-    q.put((rank, torch.equal(got, full * 2.0), even[:, 0].tolist()))
+    # eval counters (groma/eval/eval_rec.py:122-124: three scalar reduces) -> one all-reduce of the RecMeter state
+    from groma_amd import evalkit
+    m = evalkit.RecMeter(0.5)
+    tok = list(range(32014, 32114))
+    seq = torch.tensor([[5, 6, tok[0]], [5, 6, 7]]) if rank == 0 else torch.tensor([[5, 6, tok[1]]])
+    box = [torch.tensor([[0.5, 0.5, 0.2, 0.2], [0.1, 0.1, 0.1, 0.1]])] * seq.shape[0]
+    gt = [torch.tensor([[0.5, 0.5, 0.2, 0.2]])] * seq.shape[0]
+    m.update(seq, 2, box, gt, tok)
+    summ = m.summary()
+    q.put((rank, torch.equal(got, full * 2.0) and summ["count"] == 3 and abs(summ["iou@0.5 accu"] - 1 / 3) < 1e-12
+           and abs(summ["missing percentage"] - 1 / 3) < 1e-12, even[:, 0].tolist()))
     dist.barrier()
     dist.destroy_process_group()
 

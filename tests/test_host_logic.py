@@ -138,3 +138,60 @@ def test_prompt_templates_match_reference_goldens():
         else:
             got = prompt.render(c["template"], [(r, tuple(m) if isinstance(m, list) else m) for r, m in c["turns"]])
         assert got == c["prompt"], (c["template"], c["dialog"])
+
+
+def _ref_rec_loop(seqs, P, boxes, gts, tok_ids, thr):
+    """the reference's per-image loop (groma/eval/eval_rec.py:103-121), restated literally as the checker"""
+    import torch
+    m_iou = hits = invalid = 0.0
+    for i in range(seqs.shape[0]):
+        pred = boxes[i]
+        toks = [int(t) for t in seqs[i, P:] if int(t) in tok_ids]
+        inds = [tok_ids.index(t) for t in toks]
+        inds = [k for k in inds if k < len(pred)]
+        if not inds:
+            invalid += 1
+            continue
+        sel = pred[inds]
+        def c2c(b):
+            return torch.stack([b[:, 0] - b[:, 2] / 2, b[:, 1] - b[:, 3] / 2, b[:, 0] + b[:, 2] / 2, b[:, 1] + b[:, 3] / 2], -1)
+        a, g = c2c(sel), c2c(gts[i])
+        iou = torch.zeros((a.shape[0], g.shape[0]))
+        for x in range(a.shape[0]):
+            for y in range(g.shape[0]):
+                iw = max(0.0, float(min(a[x, 2], g[y, 2]) - max(a[x, 0], g[y, 0])))
+                ih = max(0.0, float(min(a[x, 3], g[y, 3]) - max(a[x, 1], g[y, 1])))
+                inter = iw * ih
+                ua = float((a[x, 2] - a[x, 0]) * (a[x, 3] - a[x, 1]) + (g[y, 2] - g[y, 0]) * (g[y, 3] - g[y, 1])) - inter
+                iou[x, y] = inter / ua
+        best = iou.max(-1).values
+        m_iou += float(best[0])
+        hits += 1.0 if float(best[0]) > thr else 0.0
+    return hits, m_iou, invalid
+
+
+def test_rec_meter_matches_reference_loop():
+    import torch
+    from groma_amd import evalkit
+    g = torch.Generator().manual_seed(0)
+    tok_ids = list(range(32014, 32114))
+    bs, P, new = 12, 9, 5
+    seqs = torch.randint(3, 31000, (bs, P + new), generator=g)
+    boxes, gts = [], []
+    for i in range(bs):
+        n = int(torch.randint(1, 30, (1,), generator=g))
+        b = torch.rand((n, 4), generator=g) * 0.5 + 0.2
+        boxes.append(b)
+        gts.append(torch.cat([b[:1] + 0.02 * torch.randn((1, 4), generator=g), torch.rand((2, 4), generator=g)]))
+        if i % 4 != 3:   # 3 of 4 answers contain <r_k> ids, some out of range for that image
+            seqs[i, P + 1] = tok_ids[int(torch.randint(0, 40, (1,), generator=g))]
+            seqs[i, P + 3] = tok_ids[0]
+    m = evalkit.RecMeter(0.5)
+    m.update(seqs[:7], P, boxes[:7], gts[:7], tok_ids)
+    m.update(seqs[7:], P, boxes[7:], gts[7:], tok_ids)
+    s = m.summary()
+    hits, miou, invalid = _ref_rec_loop(seqs, P, boxes, gts, tok_ids, 0.5)
+    assert s["count"] == bs and abs(s["iou@0.5 accu"] - hits / bs) < 1e-12 and abs(s["missing percentage"] - invalid / bs) < 1e-12
+    assert abs(s["m_iou"] - miou / bs) < 1e-6 and invalid > 0 and hits > 0
+    res = evalkit.lvis_results(seqs[:2], P, boxes[:2], [7, 8], [1, 2], [(480, 640), (100, 200)], tok_ids)
+    assert all(set(r) == {"image_id", "category_id", "bbox", "score"} for r in res)
