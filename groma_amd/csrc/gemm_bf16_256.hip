@@ -51,6 +51,14 @@ __device__ __forceinline__ f32x4 mfma_fp8x2(bf16x8 a, bf16x8 b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(ua.h[1], ub.h[1], c, 0, 0, 0);
 }
 #define MFMA16(a, b, c) mfma_fp8x2(a, b, c)
+#elif defined(G256_QKV)
+// a separate kernel for the fused-QKV epilogue: its extra code (partner-column reads, cos/sin, transposed V stores)
+// must not cost the plain kernel registers -- compiled into the same kernel it pushed SGPRs to scratch and slowed
+// EVERY GEMM by 20-30 %
+#define G256_KERNEL gemm_bf16_256_qkv_kernel
+#define G256_LAUNCH gr_launch_gemm256_qkv
+#define ESZ 2
+#define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0)
 #else
 #define G256_KERNEL gemm_bf16_256_kernel
 #define G256_LAUNCH gr_launch_gemm256
@@ -336,6 +344,9 @@ __global__ __launch_bounds__(NT) void G256_KERNEL(GemmArgs p) {
   EpiCols<4> ec4;
   EpiCols<2> ec2;
   EpiCols<1> ec1;
+#ifdef G256_QKV
+  const int qkv_which = n0 / (p.qkv_H * p.qkv_hd);  // tile-uniform: 0 = q, 1 = k, 2 = v
+#endif
   if (p.act == 3) ec4.load(p, n0 + (tid & 15) * 16);
   else if (!p.out_f32 && p.splits == 1) ec2.load(p, n0 + (tid & 31) * 8);
   else ec1.load(p, n0 + (tid & 63) * 4);
@@ -359,6 +370,23 @@ __global__ __launch_bounds__(NT) void G256_KERNEL(GemmArgs p) {
 #endif
     __syncthreads();
     // staged row sr -> tile row (sr>>5)*128 + q*32 + (sr&31)
+#ifdef G256_QKV
+    {
+      if (qkv_which < 2) {
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+          const int idx = it * NT + tid, sr = idx >> 5;
+          epi_qk_from_stage<T256>(p, buf, sr, (idx & 31) * 2, m0 + (sr >> 5) * 128 + q * 32 + (sr & 31), n0, qkv_which, ec2);
+        }
+      } else {
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+          const int idx = it * NT + tid, sr0 = (idx >> 8) * 8;  // 8 consecutive staged rows = 8 consecutive tokens
+          epi_v_from_stage<T256>(p, buf, sr0, idx & 255, m0 + (sr0 >> 5) * 128 + q * 32 + (sr0 & 31), n0);
+        }
+      }
+    }
+#else
     if (p.act == 3) {
 #pragma unroll
       for (int it = 0; it < 2; ++it) {
@@ -378,6 +406,7 @@ __global__ __launch_bounds__(NT) void G256_KERNEL(GemmArgs p) {
         epi_from_stage<T256, 1>(p, buf, sr, idx & 63, m0 + (sr >> 5) * 128 + q * 32 + (sr & 31), n0, z, ec1);
       }
     }
+#endif
   }
   CLK_MARK(2)
 }

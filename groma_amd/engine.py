@@ -16,6 +16,13 @@ from . import ops
 BF16, F32, I32, I64 = torch.bfloat16, torch.float32, torch.int32, torch.int64
 
 
+# QKV GEMMs can split / rotate / write the cache in their epilogue (gr_gemm_desc.act = 4, gemm_qkv_256.hip).  Measured
+# SLOWER on MI355X (LLaMA QKV 885 us fused vs 621 us GEMM + 99 us gr_qkv_split at 14 img/GPU): the rotation's cos/sin
+# loads and the transposed V stores sit in the lock-step epilogue where nothing overlaps them, while the separate split
+# kernel streams at ~4 TB/s.  Kept (tested) behind this switch; off by default.
+FUSED_QKV = False
+
+
 def _ru(x, m):
     return (x + m - 1) // m * m
 
@@ -86,9 +93,13 @@ class VitEngine:
                 return ops.gemm(x8, wt[0], a_scale=sx, w_scale=wt[1], **kw)
             return ops.gemm(x_bf16, wt[0], **kw)
 
+        fused_qkv = FUSED_QKV and not fp8 and D % 256 == 0 and 256 % hd == 0
         for i, L in enumerate(w["layers"]):
-            qkv = lin(h, L["ln1_g"], L["ln1_b"], L["wqkv"], bias=L["bqkv"], out=ws.get("vit_qkv", (M, 3 * D), BF16))
-            ops.qkv_split(qkv, q, k, vt, B=bs, H=H, L=T, hd=hd)
+            if fused_qkv:  # the QKV GEMM's epilogue writes q / k / v^T itself (no [M, 3D] round trip)
+                lin(h, L["ln1_g"], L["ln1_b"], L["wqkv"], bias=L["bqkv"], qkv=dict(q=q, k=k, vt=vt, H=H, hd=hd, L=T))
+            else:
+                qkv = lin(h, L["ln1_g"], L["ln1_b"], L["wqkv"], bias=L["bqkv"], out=ws.get("vit_qkv", (M, 3 * D), BF16))
+                ops.qkv_split(qkv, q, k, vt, B=bs, H=H, L=T, hd=hd)
             ctx = ops.attention(q, k, vt, Skv=T, causal=False, out=ws.get("vit_ctx", (M, D), BF16))
             lin_bf16(ctx, L["wo"], bias=L["bo"], scale=L["ls1"], resid=h, out=mid, out_f32=True)
             y = lin(mid, L["ln2_g"], L["ln2_b"], L["w1"], bias=L["b1"], act=1,
@@ -329,10 +340,15 @@ class LlamaEngine:
                 return ops.gemm(x8, wt[0], a_scale=sx, w_scale=wt[1], **kw)
             return ops.gemm(x_bf16, wt[0], **kw)
 
+        fused_qkv = FUSED_QKV and not fp8 and not dyn and M > 8 and T % 256 == 0 and 256 % hd == 0
         for i, Lw in enumerate(w["layers"]):
-            qkv = lin(h, Lw["n1"], Lw["wqkv"], out=ws.get("llm_qkv", (M, 3 * T), BF16))
-            ops.qkv_split(qkv, q, cache.k[i], cache.vt[i], B=bs, H=H, L=L, hd=hd, pos0=past, cos=w["cos"], sin=w["sin"],
-                          pos_dev=pos_dev, pos_stride=pos_stride)
+            if fused_qkv:  # RoPE + split + KV-cache write in the QKV GEMM's epilogue
+                lin(h, Lw["n1"], Lw["wqkv"], qkv=dict(q=q, k=cache.k[i], vt=cache.vt[i], cos=w["cos"], sin=w["sin"], H=H, hd=hd,
+                                                       L=L, pos0=past))
+            else:
+                qkv = lin(h, Lw["n1"], Lw["wqkv"], out=ws.get("llm_qkv", (M, 3 * T), BF16))
+                ops.qkv_split(qkv, q, cache.k[i], cache.vt[i], B=bs, H=H, L=L, hd=hd, pos0=past, cos=w["cos"], sin=w["sin"],
+                              pos_dev=pos_dev, pos_stride=pos_stride)
             ctx = ops.attention(q, cache.k[i], cache.vt[i], Skv=cache.smax if dyn else past + L, causal=True, q_pos0=past,
                                 kv_len=kv_len, out=ws.get("llm_ctx", (M, T), BF16), pos_dev=pos_dev, pos_stride=pos_stride)
             lin_bf16(ctx, Lw["wo"], resid=h, out=h, out_f32=True)
