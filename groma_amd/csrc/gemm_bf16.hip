@@ -118,31 +118,13 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16_kernel(GemmArgs p) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) stage_write4<BN>(smem, wm * 64 + i * 16 + fr, wn * 16 + j * 4 + fg, acc[j][i]);
   __syncthreads();
-  if (p.act == 3) {
-    EpiCols<4> ec;
-    ec.load(p, n0 + (tid & 7) * 16);
-#pragma unroll
-    for (int it = 0; it < 4; ++it) {
-      const int idx = it * NTHREADS + tid;
-      epi_from_stage<BN, 4>(p, smem, idx >> 3, (idx & 7) * 4, m0 + (idx >> 3), n0, z, ec);
-    }
-  } else if (!p.out_f32 && p.splits == 1) {
-    EpiCols<2> ec;
-    ec.load(p, n0 + (tid & 15) * 8);
-#pragma unroll
-    for (int it = 0; it < 8; ++it) {
-      const int idx = it * NTHREADS + tid;
-      epi_from_stage<BN, 2>(p, smem, idx >> 4, (idx & 15) * 2, m0 + (idx >> 4), n0, z, ec);
-    }
-  } else {
-    EpiCols<1> ec;
-    ec.load(p, n0 + (tid & 31) * 4);
-#pragma unroll
-    for (int it = 0; it < 16; ++it) {
-      const int idx = it * NTHREADS + tid;
-      epi_from_stage<BN, 1>(p, smem, idx >> 5, idx & 31, m0 + (idx >> 5), n0, z, ec);
-    }
-  }
+  EpiCols<4> ec4;
+  EpiCols<2> ec2;
+  EpiCols<1> ec1;
+  if (p.act == 3) ec4.load(p, n0 + (tid & 7) * 16);
+  else if (!p.out_f32 && p.splits == 1) ec2.load(p, n0 + (tid & 15) * 8);
+  else ec1.load(p, n0 + (tid & 31) * 4);
+  epi_dispatch<BN, NTHREADS, BM, false>(p, smem, tid, n0, z, ec4, ec2, ec1, [](int sr) { return sr; }, [&](int sr) { return m0 + sr; });
 }
 
 // split-K reduce + epilogue: one thread per 4 consecutive n

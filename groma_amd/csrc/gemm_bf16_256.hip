@@ -79,12 +79,12 @@ __device__ __forceinline__ f32x4 mfma_fp8x2(bf16x8 a, bf16x8 b, f32x4 c) {
 #define LDS_SWZ(row) ((row) & 7)
 #endif
 
-#if defined(G256_CLK) && !G256_FP8  // diagnostic build only (tests/diag/build_clk.py): shader/wall clocks of block 0 at start, loop end, exit
-__device__ unsigned long long g256_clk[6];
+#if defined(G256_CLK) && !G256_FP8 && !defined(G256_QKV)  // diagnostic build only (tests/diag/build_clk.py): shader/wall clocks of block 0 at start, loop end, exit
+__device__ unsigned long long g256_clk[24];
 extern "C" int gr_diag_clk(unsigned long long* out) {
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g256_clk), sizeof(g256_clk));
 }
-#define CLK_MARK(i) if (threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0) { g256_clk[i] = clock64(); g256_clk[3 + i] = wall_clock64(); }
+#define CLK_MARK(i) if (threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0) { g256_clk[i] = clock64(); g256_clk[12 + i] = wall_clock64(); }
 #else
 #define CLK_MARK(i)
 #endif
@@ -369,6 +369,7 @@ __global__ __launch_bounds__(NT) void G256_KERNEL(GemmArgs p) {
       for (int j = 0; j < 4; ++j) stage_write4<T256>(buf, wm * 32 + e * 16 + fr, wn * 16 + j * 4 + fg, acc[2 * q + e][j]);
 #endif
     __syncthreads();
+    CLK_MARK(3 + 2 * q)
     // staged row sr -> tile row (sr>>5)*128 + q*32 + (sr&31)
 #ifdef G256_QKV
     {
@@ -387,26 +388,11 @@ __global__ __launch_bounds__(NT) void G256_KERNEL(GemmArgs p) {
       }
     }
 #else
-    if (p.act == 3) {
-#pragma unroll
-      for (int it = 0; it < 2; ++it) {
-        const int idx = it * NT + tid, sr = idx >> 4;
-        epi_from_stage<T256, 4>(p, buf, sr, (idx & 15) * 4, m0 + (sr >> 5) * 128 + q * 32 + (sr & 31), n0, z, ec4);
-      }
-    } else if (!p.out_f32 && p.splits == 1) {
-#pragma unroll
-      for (int it = 0; it < 4; ++it) {
-        const int idx = it * NT + tid, sr = idx >> 5;
-        epi_from_stage<T256, 2>(p, buf, sr, (idx & 31) * 2, m0 + (sr >> 5) * 128 + q * 32 + (sr & 31), n0, z, ec2);
-      }
-    } else {
-#pragma unroll
-      for (int it = 0; it < 8; ++it) {
-        const int idx = it * NT + tid, sr = idx >> 6;
-        epi_from_stage<T256, 1>(p, buf, sr, idx & 63, m0 + (sr >> 5) * 128 + q * 32 + (sr & 31), n0, z, ec1);
-      }
-    }
+    // staged row sr of this pass -> tile row (sr>>5)*128 + q*32 + (sr&31)
+    epi_dispatch<T256, NT, 64, (G256_FP8 != 0)>(p, buf, tid, n0, z, ec4, ec2, ec1, [](int sr) { return sr; },
+                               [&](int sr) { return m0 + (sr >> 5) * 128 + q * 32 + (sr & 31); });
 #endif
+    CLK_MARK(4 + 2 * q)
   }
   CLK_MARK(2)
 }

@@ -228,6 +228,155 @@ __device__ __forceinline__ void epi_from_stage(const GemmArgs& p, const char* ba
   }
 }
 
+// ---- batched epilogue: NIT staged rows per thread in ONE straight-line sequence ---------------------------------
+// vmcnt is an in-order counter shared by loads and stores: a row-at-a-time epilogue with a (possibly skipped) residual /
+// scale load inside each row made the compiler put `s_waitcnt vmcnt(0)` on the common path, so every 16-B store had to
+// COMPLETE (~800 clk round trip) before the next row started -- 3300 clk per 64-row pass, 8 us per 256x256 tile,
+// measured with tests/diag/gemm_clk.py.  Here (1) every global LOAD of the pass (residual rows, per-row dequant
+// scales) is issued first, (2) then LDS reads + math + stores run back to back with no load in between, and the
+// variants without loads are separate instantiations with no wait at all.
+// rm(it) -> staged row; mm(it) -> global row m.
+template <int COLS, int W4, int NIT, bool F32OUT, bool RESID, bool DEQ, class SR, class MR>
+__device__ __forceinline__ void epi_rows(const GemmArgs& p, const char* base, int c4, int n0, const EpiCols<W4>& ec, SR rm, MR mm) {
+  const int n = n0 + c4 * 4;
+  constexpr int NB = RESID ? (DEQ ? 1 : (NIT < 4 ? NIT : 4)) : (DEQ ? 1 : NIT);  // rows per load batch (register budget; the fp8 build is at the 256-VGPR limit)
+  auto out_row = [&](int m) -> long {
+    return p.c_group > 0 ? (long)(m / p.c_group) * p.c_group_stride + p.c_row_off + (m % p.c_group) : (long)m;
+  };
+#pragma unroll
+  for (int b0 = 0; b0 < NIT; b0 += NB) {
+    f32x4 r[RESID ? NB : 1][W4];
+    float as[DEQ ? NB : 1];
+    if (DEQ) {
+#pragma unroll
+      for (int i = 0; i < NB; ++i) {
+        const int m = mm(b0 + i);
+        as[DEQ ? i : 0] = (p.a_scale && m < p.M) ? p.a_scale[m] : 1.f;
+      }
+    }
+    if (RESID) {
+#pragma unroll
+      for (int i = 0; i < NB; ++i) {
+        const int m = mm(b0 + i);
+        const long rrow = p.resid_mod > 0 ? (long)(m % p.resid_mod) : out_row(m);
+#pragma unroll
+        for (int w = 0; w < W4; ++w)
+          r[RESID ? i : 0][w] = (m < p.M && n + 4 * w < p.N) ? *(const f32x4*)(p.resid + rrow * p.ldr + n + 4 * w)
+                                                            : (f32x4){0.f, 0.f, 0.f, 0.f};
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      const int m = mm(b0 + i);
+      if (m >= p.M) continue;
+      const long orow = out_row(m);
+      f32x4 v[W4];
+#pragma unroll
+      for (int w = 0; w < W4; ++w) {
+        v[w] = stage_read4<COLS>(base, rm(b0 + i), c4 + w);
+        if (DEQ) v[w] = v[w] * ec.wsc[w] * as[DEQ ? i : 0];
+        v[w] += ec.bias[w];
+        if (p.act == 1 || p.act == 2) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[w][e] = act_apply(v[w][e], p.act);
+        }
+        v[w] *= ec.scale[w];
+        if (RESID) v[w] += r[RESID ? i : 0][w];
+      }
+      if (F32OUT) {
+#pragma unroll
+        for (int w = 0; w < W4; ++w)
+          if (n + 4 * w < p.N) *(f32x4*)((float*)p.C + orow * p.ldc + n + 4 * w) = v[w];
+      } else {
+        bf16_t* dst = (bf16_t*)p.C + orow * p.ldc + n;
+        if (W4 == 2 && n + 8 <= p.N && (p.ldc & 7) == 0) {
+          *(uint4*)dst = make_uint4(pack2bf(v[0][0], v[0][1]), pack2bf(v[0][2], v[0][3]), pack2bf(v[W4 - 1][0], v[W4 - 1][1]),
+                                    pack2bf(v[W4 - 1][2], v[W4 - 1][3]));
+        } else {
+#pragma unroll
+          for (int w = 0; w < W4; ++w)
+            if (n + 4 * w < p.N) {
+              uint2 pk;
+              pk.x = pack2bf(v[w][0], v[w][1]);
+              pk.y = pack2bf(v[w][2], v[w][3]);
+              *(uint2*)(dst + 4 * w) = pk;
+            }
+        }
+      }
+    }
+  }
+}
+// SwiGLU over interleaved (gate, up) columns: 16 fused columns -> 8 bf16 outputs per thread-row; no loads
+template <int COLS, int NIT, bool DEQ, class SR, class MR>
+__device__ __forceinline__ void epi_rows_swiglu(const GemmArgs& p, const char* base, int c4, int n0, const EpiCols<4>& ec, SR rm, MR mm) {
+  const int n = n0 + c4 * 4;
+  float as[DEQ ? NIT : 1];
+  if (DEQ) {
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int m = mm(it);
+      as[DEQ ? it : 0] = (p.a_scale && m < p.M) ? p.a_scale[m] : 1.f;
+    }
+  }
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int m = mm(it);
+    if (m >= p.M) continue;
+    long orow = m;
+    if (p.c_group > 0) orow = (long)(m / p.c_group) * p.c_group_stride + p.c_row_off + (m % p.c_group);
+    uint32_t o[4];
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      f32x4 x = stage_read4<COLS>(base, rm(it), c4 + w);
+      if (DEQ) x = x * ec.wsc[w] * as[DEQ ? it : 0];
+      x += ec.bias[w];
+      o[w] = pack2bf(silu_f(x[0]) * x[1], silu_f(x[2]) * x[3]);
+    }
+    bf16_t* dst = (bf16_t*)p.C + orow * p.ldc + (n >> 1);
+    if (n + 16 <= p.N && (p.ldc & 7) == 0) {
+      *(uint4*)dst = make_uint4(o[0], o[1], o[2], o[3]);
+    } else {
+#pragma unroll
+      for (int w = 0; w < 4; ++w)
+        if (n + 4 * w < p.N) *(uint32_t*)(dst + 2 * w) = o[w];
+    }
+  }
+}
+// split-K partial tile -> workspace [z, M, N] f32 (raw accumulators; the reduce kernel applies the epilogue)
+template <int COLS, int NIT, class SR, class MR>
+__device__ __forceinline__ void epi_rows_splitk(const GemmArgs& p, const char* base, int c4, int n0, int z, SR rm, MR mm) {
+  const int n = n0 + c4 * 4;
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int m = mm(it);
+    if (m < p.M && n < p.N) *(f32x4*)(p.ws + ((long)z * p.M + m) * p.N + n) = stage_read4<COLS>(base, rm(it), c4);
+  }
+}
+// mode dispatch shared by both tile kernels: TPR1/2/4 = threads per staged row for 4/8/16 columns per thread
+template <int COLS, int NTH, int ROWS, bool DEQ, class SR, class MR>
+__device__ __forceinline__ void epi_dispatch(const GemmArgs& p, const char* base, int tid, int n0, int z, const EpiCols<4>& ec4,
+                                             const EpiCols<2>& ec2, const EpiCols<1>& ec1, SR rm, MR mm) {
+  constexpr int T4 = COLS / 16, T2 = COLS / 8, T1 = COLS / 4;          // threads per row
+  constexpr int N4 = ROWS * T4 / NTH, N2 = ROWS * T2 / NTH, N1 = ROWS * T1 / NTH;  // rows per thread
+  if (p.splits > 1) {
+    epi_rows_splitk<COLS, N1>(p, base, tid % T1, n0, z, [&](int it) { return rm(it * (NTH / T1) + tid / T1); },
+                              [&](int it) { return mm(it * (NTH / T1) + tid / T1); });
+  } else if (p.act == 3) {
+    epi_rows_swiglu<COLS, N4, DEQ>(p, base, (tid % T4) * 4, n0, ec4, [&](int it) { return rm(it * (NTH / T4) + tid / T4); },
+                              [&](int it) { return mm(it * (NTH / T4) + tid / T4); });
+  } else if (!p.out_f32) {
+    auto r = [&](int it) { return rm(it * (NTH / T2) + tid / T2); };
+    auto m = [&](int it) { return mm(it * (NTH / T2) + tid / T2); };
+    if (p.resid) epi_rows<COLS, 2, N2, false, true, DEQ>(p, base, (tid % T2) * 2, n0, ec2, r, m);
+    else epi_rows<COLS, 2, N2, false, false, DEQ>(p, base, (tid % T2) * 2, n0, ec2, r, m);
+  } else {
+    auto r = [&](int it) { return rm(it * (NTH / T1) + tid / T1); };
+    auto m = [&](int it) { return mm(it * (NTH / T1) + tid / T1); };
+    if (p.resid) epi_rows<COLS, 1, N1, true, true, DEQ>(p, base, tid % T1, n0, ec1, r, m);
+    else epi_rows<COLS, 1, N1, true, false, DEQ>(p, base, tid % T1, n0, ec1, r, m);
+  }
+}
+
 // ---- act == 4: fused-QKV epilogue (q / k path).  One thread = 8 consecutive columns (one 16-B bf16 store) of one
 // staged row.  The projection is rounded to bf16 FIRST -- exactly what the unfused path stores before gr_qkv_split
 // reads it back -- then HF rotate_half RoPE in f32 with the partner columns taken from the same LDS image.

@@ -6,7 +6,7 @@ from groma_amd import ops, _lib
 
 lib = _lib.load()
 lib.gr_diag_clk.argtypes = [ctypes.c_void_p]
-buf = (ctypes.c_ulonglong * 6)()
+buf = (ctypes.c_ulonglong * 24)()
 for (M, N, K) in [(8192, 8192, 8192), (8148, 22016, 4096), (8148, 4096, 4096), (8148, 4096, 11008)]:
     a = (torch.randn((M, K), device="cuda") * 0.5).bfloat16()
     w = (torch.randn((N, K), device="cuda") * 0.5).bfloat16()
@@ -23,9 +23,11 @@ for (M, N, K) in [(8192, 8192, 8192), (8148, 22016, 4096), (8148, 4096, 4096), (
     ms = e0.elapsed_time(e1) / 20
     lib.gr_diag_clk(buf)
     c = list(buf)
-    mhz = (c[2] - c[0]) / max(c[5] - c[3], 1) * 100
-    loop_us = (c[4] - c[3]) / 100.0
-    epi_us = (c[5] - c[4]) / 100.0
+    mhz = (c[2] - c[0]) / max(c[14] - c[12], 1) * 100
+    loop_us = (c[13] - c[12]) / 100.0
+    epi_us = (c[14] - c[13]) / 100.0
+    marks = [c[1]] + [c[3 + i] for i in range(8)]
+    print("   epilogue clk: " + " ".join(f"{'stage' if i % 2 == 0 else 'store'}{i // 2}={marks[i + 1] - marks[i]}" for i in range(8)))
     ks = K // 64
     print(f"{M}x{N}x{K}: {ms * 1e3:.1f} us, {2.0 * M * N * K / ms / 1e9:.0f} TF | block0: shader clock {mhz:.0f} MHz, "
           f"prologue+loop {loop_us:.1f} us ({(c[1] - c[0]) / ks:.0f} clk per K-step; MFMA-bound floor 2048), epilogue {epi_us:.1f} us")
