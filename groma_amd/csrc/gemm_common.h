@@ -236,6 +236,11 @@ __device__ __forceinline__ void epi_from_stage(const GemmArgs& p, const char* ba
 // scales) is issued first, (2) then LDS reads + math + stores run back to back with no load in between, and the
 // variants without loads are separate instantiations with no wait at all.
 // rm(it) -> staged row; mm(it) -> global row m.
+#ifdef GR_EPI_NT
+#define EPI_ST(ptr, val) __builtin_nontemporal_store((val), (ptr))
+#else
+#define EPI_ST(ptr, val) (*(ptr) = (val))
+#endif
 template <int COLS, int W4, int NIT, bool F32OUT, bool RESID, bool DEQ, class SR, class MR>
 __device__ __forceinline__ void epi_rows(const GemmArgs& p, const char* base, int c4, int n0, const EpiCols<W4>& ec, SR rm, MR mm) {
   const int n = n0 + c4 * 4;
@@ -286,12 +291,14 @@ __device__ __forceinline__ void epi_rows(const GemmArgs& p, const char* base, in
       if (F32OUT) {
 #pragma unroll
         for (int w = 0; w < W4; ++w)
-          if (n + 4 * w < p.N) *(f32x4*)((float*)p.C + orow * p.ldc + n + 4 * w) = v[w];
+          if (n + 4 * w < p.N) EPI_ST((f32x4*)((float*)p.C + orow * p.ldc + n + 4 * w), v[w]);
       } else {
         bf16_t* dst = (bf16_t*)p.C + orow * p.ldc + n;
         if (W4 == 2 && n + 8 <= p.N && (p.ldc & 7) == 0) {
-          *(uint4*)dst = make_uint4(pack2bf(v[0][0], v[0][1]), pack2bf(v[0][2], v[0][3]), pack2bf(v[W4 - 1][0], v[W4 - 1][1]),
-                                    pack2bf(v[W4 - 1][2], v[W4 - 1][3]));
+          typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+          const u32x4 pk4 = {pack2bf(v[0][0], v[0][1]), pack2bf(v[0][2], v[0][3]), pack2bf(v[W4 - 1][0], v[W4 - 1][1]),
+                             pack2bf(v[W4 - 1][2], v[W4 - 1][3])};
+          EPI_ST((u32x4*)dst, pk4);
         } else {
 #pragma unroll
           for (int w = 0; w < W4; ++w)
