@@ -73,6 +73,9 @@ __device__ __forceinline__ f32x4 mfma_fp8x2(bf16x8 a, bf16x8 b, f32x4 c) {
 #ifndef G256_MFMA32
 #define G256_MFMA32 0
 #endif
+#ifndef G256_2PHASE
+#define G256_2PHASE 1  // two 32-MFMA phases per K-tile (0 = the four-phase schedule)
+#endif
 #if G256_MFMA32
 #define LDS_SWZ(row) (((row) >> 1) & 7)
 #else
@@ -80,13 +83,20 @@ __device__ __forceinline__ f32x4 mfma_fp8x2(bf16x8 a, bf16x8 b, f32x4 c) {
 #endif
 
 #if defined(G256_CLK) && !G256_FP8 && !defined(G256_QKV)  // diagnostic build only (tests/diag/build_clk.py): shader/wall clocks of block 0 at start, loop end, exit
-__device__ unsigned long long g256_clk[24];
+__device__ unsigned long long g256_clk[40];
 extern "C" int gr_diag_clk(unsigned long long* out) {
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g256_clk), sizeof(g256_clk));
 }
 #define CLK_MARK(i) if (threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0) { g256_clk[i] = clock64(); g256_clk[12 + i] = wall_clock64(); }
+// per-phase marks of K-tiles 8 and 9 (wave 0 of block 0): before / after the 16-MFMA segment of each phase
+#define PH_DECL unsigned long long phm[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#define PH_MARK(i) if ((t == 8 || t == 9) && blockIdx.x == 0) phm[(t - 8) * 8 + (i)] = __builtin_readcyclecounter();
+#define PH_FLUSH if (threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0) { for (int i = 0; i < 16; ++i) g256_clk[24 + i] = phm[i]; }
 #else
 #define CLK_MARK(i)
+#define PH_DECL
+#define PH_MARK(i)
+#define PH_FLUSH
 #endif
 
 __global__ __launch_bounds__(NT) void G256_KERNEL(GemmArgs p) {
@@ -207,12 +217,20 @@ __global__ __launch_bounds__(NT) void G256_KERNEL(GemmArgs p) {
   const int a_lane = (wm * 128 + fr) * 128;
   const int b_lane = B_OFF + (wn * 64 + fr) * 128;
 
+#if G256_2PHASE
+  // ---- prologue: P(0) = {A0,B0,B1}(0), Q(0) = {A1}(0), P(1) ; P(0) must have landed before the first reads
+  issue(HT_A0, 0); issue(HT_B0, 0); issue(HT_B1, 0); issue(HT_A1, 0);
+  issue(HT_A0, 1); issue(HT_B0, 1); issue(HT_B1, 1);
+  if (nt >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#else
   // ---- prologue: A0(0) B0(0) A1(0) B1(0) A0(1) | wait | B0(1)
   issue(HT_A0, 0); issue(HT_B0, 0); issue(HT_A1, 0); issue(HT_B1, 0);
   issue(HT_A0, 1);
   if (nt >= 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");  // A0(0), B0(0) landed
   else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   issue(HT_B0, 1);
+#endif
   __builtin_amdgcn_s_barrier();
   if (wm == 1) __builtin_amdgcn_s_barrier();  // stagger the second wave group by one interval
 
@@ -276,20 +294,82 @@ __global__ __launch_bounds__(NT) void G256_KERNEL(GemmArgs p) {
   bf16x8 af[4][2], b0f[2][2], b1f[2][2];
 
 // barrier -> 16 MFMAs (A sub-block rows I0.., B sub-block cols J0.. with fragment set BF) -> barrier
-#define COMPUTE_PHASE(I0, J0, BF)                                                                         \
+#define COMPUTE_PHASE_P(P, I0, J0, BF)                                                                    \
   __builtin_amdgcn_sched_barrier(0);                                                                      \
   __builtin_amdgcn_s_barrier();                                                                           \
   __builtin_amdgcn_sched_barrier(0);                                                                      \
+  PH_MARK(2 * (P))                                                                                        \
   __builtin_amdgcn_s_setprio(1);                                                                          \
   _Pragma("unroll") for (int kk = 0; kk < 2; ++kk)                                                        \
     _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                         \
       _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                       \
         acc[I0 + i][J0 + j] = MFMA16(BF[j][kk], af[i][kk], acc[I0 + i][J0 + j]);                          \
   __builtin_amdgcn_s_setprio(0);                                                                          \
+  PH_MARK(2 * (P) + 1)                                                                                    \
   __builtin_amdgcn_sched_barrier(0);                                                                      \
   __builtin_amdgcn_s_barrier();                                                                           \
   __builtin_amdgcn_sched_barrier(0);
 
+  PH_DECL
+#if G256_2PHASE
+  // Two 32-MFMA phases per K-tile instead of four 16-MFMA ones: every phase boundary costs ~80 clk of barrier round
+  // trip on top of the MFMA segment (tests/diag/gemm_clk.py), so halving the boundaries is worth ~11 % of the loop.
+  //   X(t): reads P(t) = A0,B0,B1 -> af, bf ; issues Q(t+1) = A1(t+1) ; 32 MFMA  acc[0..3][*] += A0 x B
+  //   Y(t): reads Q(t) = A1       -> af     ; issues P(t+2)            ; 32 MFMA  acc[4..7][*] += A1 x B
+  // A region is refilled one phase after BOTH wave groups finished reading it: the reads are drained (lgkmcnt(0))
+  // before the barrier that ends their load segment.  vmcnt: at X only P(t+1) (6 pieces) may stay in flight, at Y
+  // only Q(t+1) (2 pieces).
+  bf16x8 bfr[4][2];
+#define PHASE32(P, I0)                                                                                    \
+  __builtin_amdgcn_sched_barrier(0);                                                                      \
+  __builtin_amdgcn_s_barrier();                                                                           \
+  __builtin_amdgcn_sched_barrier(0);                                                                      \
+  PH_MARK(2 * (P))                                                                                        \
+  __builtin_amdgcn_s_setprio(1);                                                                          \
+  _Pragma("unroll") for (int kk = 0; kk < 2; ++kk)                                                        \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                         \
+      _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                       \
+        acc[I0 + i][j] = MFMA16(bfr[j][kk], af[i][kk], acc[I0 + i][j]);                                   \
+  __builtin_amdgcn_s_setprio(0);                                                                          \
+  PH_MARK(2 * (P) + 1)                                                                                    \
+  __builtin_amdgcn_sched_barrier(0);                                                                      \
+  __builtin_amdgcn_s_barrier();                                                                           \
+  __builtin_amdgcn_sched_barrier(0);
+  for (int t = 0; t < nt; ++t) {
+    const char* st = smem + (t & 1) * STAGE_BYTES;
+    const bool steady = t + 2 < nt;
+    // ===== X
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      bfr[j][0] = *(const bf16x8*)(st + b_lane + j * 2048 + off0);
+      bfr[j][1] = *(const bf16x8*)(st + b_lane + j * 2048 + (off0 ^ 64));
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      af[i][0] = *(const bf16x8*)(st + a_lane + i * 2048 + off0);
+      af[i][1] = *(const bf16x8*)(st + a_lane + i * 2048 + (off0 ^ 64));
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    WAIT_VM(6);
+    issue_at(HT_A1, t + 1, aoff1);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    PHASE32(0, 0)
+    // ===== Y
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      af[i][0] = *(const bf16x8*)(st + a_lane + (4 + i) * 2048 + off0);
+      af[i][1] = *(const bf16x8*)(st + a_lane + (4 + i) * 2048 + (off0 ^ 64));
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    WAIT_VM(2);
+    issue_at(HT_A0, t + 2, aoff2);
+    issue_at(HT_B0, t + 2, (long)(ks_begin + t + 2) * KT);
+    issue_at(HT_B1, t + 2, (long)(ks_begin + t + 2) * KT);
+    advance();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    PHASE32(1, 4)
+  }
+#else
   for (int t = 0; t < nt; ++t) {
     const char* st = smem + (t & 1) * STAGE_BYTES;
     const bool steady = t + 2 < nt;  // every half-tile of the schedule up to this tile's issues really exists
@@ -308,7 +388,7 @@ __global__ __launch_bounds__(NT) void G256_KERNEL(GemmArgs p) {
     __builtin_amdgcn_sched_barrier(0);
     WAIT_VM(4);
     issue_at(HT_A1, t + 1, aoff1);
-    COMPUTE_PHASE(0, 0, b0f)
+    COMPUTE_PHASE_P(0, 0, 0, b0f)
     // ===== phase 1 : reads B1 ; computes A0 x B1 ; issues B1(t+1) ; retires A1(t) (read in phase 2)
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -318,7 +398,7 @@ __global__ __launch_bounds__(NT) void G256_KERNEL(GemmArgs p) {
     __builtin_amdgcn_sched_barrier(0);
     WAIT_VM(8);
     issue_at(HT_B1, t + 1, (long)(ks_begin + t + 1) * KT);
-    COMPUTE_PHASE(0, 2, b1f)
+    COMPUTE_PHASE_P(1, 0, 2, b1f)
     // ===== phase 2 : reads A1 ; computes A1 x B1 ; issues A0(t+2) ; nothing to retire (phase 3 reads nothing)
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -328,13 +408,15 @@ __global__ __launch_bounds__(NT) void G256_KERNEL(GemmArgs p) {
     __builtin_amdgcn_sched_barrier(0);
     if (!steady) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     issue_at(HT_A0, t + 2, aoff2);
-    COMPUTE_PHASE(4, 2, b1f)
+    COMPUTE_PHASE_P(2, 4, 2, b1f)
     // ===== phase 3 : no LDS reads ; computes A1 x B0 ; issues B0(t+2) ; retires A0(t+1), B0(t+1) (next phase 0)
     WAIT_VM(6);
     issue_at(HT_B0, t + 2, (long)(ks_begin + t + 2) * KT);
     advance();
-    COMPUTE_PHASE(4, 0, b0f)
+    COMPUTE_PHASE_P(3, 4, 0, b0f)
   }
+#endif
+  PH_FLUSH
 #endif
   if (wm == 0) __builtin_amdgcn_s_barrier();  // re-align the groups (same barrier count for every wave)
 

@@ -6,8 +6,8 @@ from groma_amd import ops, _lib
 
 lib = _lib.load()
 lib.gr_diag_clk.argtypes = [ctypes.c_void_p]
-buf = (ctypes.c_ulonglong * 24)()
-for (M, N, K) in [(8192, 8192, 8192), (8148, 22016, 4096), (8148, 4096, 4096), (8148, 4096, 11008)]:
+buf = (ctypes.c_ulonglong * 40)()
+for (M, N, K) in [(256, 256, 2048), (256, 256, 8192), (256, 2048, 4096), (2048, 2048, 8192), (8192, 8192, 8192)]:
     a = (torch.randn((M, K), device="cuda") * 0.5).bfloat16()
     w = (torch.randn((N, K), device="cuda") * 0.5).bfloat16()
     out = torch.empty((M, N), device="cuda", dtype=torch.bfloat16)
@@ -27,6 +27,12 @@ for (M, N, K) in [(8192, 8192, 8192), (8148, 22016, 4096), (8148, 4096, 4096), (
     loop_us = (c[13] - c[12]) / 100.0
     epi_us = (c[14] - c[13]) / 100.0
     marks = [c[1]] + [c[3 + i] for i in range(8)]
+    ph = c[24:40]
+    if ph[0]:
+        segs = []
+        for i in range(15):
+            segs.append(f"{'mfma' if i % 2 == 0 else 'gap '}{ph[i + 1] - ph[i]}")
+        print("   K-tiles 8-9, wave 0: " + " ".join(segs) + f" | K-tile period {ph[8] - ph[0]} clk")
     print("   epilogue clk: " + " ".join(f"{'stage' if i % 2 == 0 else 'store'}{i // 2}={marks[i + 1] - marks[i]}" for i in range(8)))
     ks = K // 64
     print(f"{M}x{N}x{K}: {ms * 1e3:.1f} us, {2.0 * M * N * K / ms / 1e9:.0f} TF | block0: shader clock {mhz:.0f} MHz, "

@@ -1,4 +1,5 @@
-"""Empirical MFMA ceiling + sustained shader clock on the box (diagnostic; see DESIGN.md 'what bounds the GEMM')."""
+"""Empirical MFMA ceiling + sustained shader clock on the box (diagnostic; see DESIGN.md 'what bounds the GEMM').
+Also: how many waves per SIMD does it take to keep the matrix pipe full?  (1 wave/SIMD = what a ping-pong phase has.)"""
 import ctypes, os, subprocess, sys
 import torch
 
@@ -13,9 +14,9 @@ sink = torch.zeros(4, device="cuda")
 clk = torch.zeros(2, dtype=torch.int64, device="cuda")
 st = torch.cuda.current_stream().cuda_stream
 for shape in (16, 32):
-    for threads in (256, 512):
+    for threads, occ in ((256, 1), (256, 2), (512, 1), (256, 4)):
         for dur in (200000, 200001):
-            blocks = 256 * (512 // threads) * 2
+            blocks = 256 * occ
             lib.diag_mfma_peak(shape, blocks, threads, 2000, sink.data_ptr(), clk.data_ptr(), st)
             torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -25,5 +26,7 @@ for shape in (16, 32):
             torch.cuda.synchronize()
             ms = e0.elapsed_time(e1)
             c = clk.tolist()
-            print(f"mfma {shape}: {blocks} blocks x {threads} thr, iters {dur} ({'random' if dur & 1 else 'constant'} operands): {ms:.2f} ms -> {fl / ms / 1e9:.0f} TFLOP/s; "
-                  f"block0 shader clock {c[0] / max(c[1], 1) * 100:.0f} MHz")
+            mhz = c[0] / max(c[1], 1) * 100
+            per = c[0] / (dur * (16 if shape == 16 else 8))
+            print(f"mfma {shape}: {threads * occ // 256} wave(s)/SIMD ({blocks} x {threads}), {'random' if dur & 1 else 'constant'} operands: "
+                  f"{fl / ms / 1e9:.0f} TFLOP/s at {mhz:.0f} MHz; {per:.1f} clk per MFMA per wave")
