@@ -36,6 +36,14 @@ struct AttnArgs {
   float scale_log2;  // softmax scale * log2(e)
 };
 
+#ifdef G256_CLK  // diagnostic build (tests/diag/build_clk.py): per-iteration segment clocks of block 0 / wave 0
+__device__ unsigned long long att_clk[64];
+extern "C" int gr_diag_att_clk(unsigned long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(att_clk), sizeof(att_clk)); }
+#define ATT_MARK(i) if (blockIdx.x == gridDim.x - 1 && blockIdx.y == 0 && t >= 2 && t < 6) am[(t - 2) * 5 + (i)] = __builtin_readcyclecounter();
+#else
+#define ATT_MARK(i)
+#endif
+
 template <int HD>
 __global__ __launch_bounds__(256, 2) void attention_kernel(AttnArgs p) {
   constexpr int KV = 64;
@@ -126,11 +134,16 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(AttnArgs p) {
     }
   };
 
+#ifdef G256_CLK
+  unsigned long long am[20] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#endif
   if (ntiles > 0) stage(0);
   for (int t = 0; t < ntiles; ++t) {
     const int kv0 = t * KV;
+    ATT_MARK(0)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();  // tile t landed for every wave; everyone finished reading the other buffer
+    ATT_MARK(1)
     if (t + 1 < ntiles) stage(t + 1);
     if (kv0 >= wav_limit) continue;  // wave-uniform: every key of this tile is masked for all of this wave's rows
     const char* ksm = smem + (t & 1) * STAGE;
@@ -142,17 +155,33 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(AttnArgs p) {
     for (int u = 0; u < QT; ++u)
 #pragma unroll
       for (int j = 0; j < 4; ++j) s[u][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // K fragments are read one group AHEAD of the MFMAs that use them (double buffer, GK fragments per group): the
+    // LDS latency of the next group hides behind this group's MFMAs instead of stalling every MFMA pair
+    constexpr int GK = 2;                       // fragments per group (register budget: hd 128 sits at 256 VGPRs)
+    constexpr int NKG = 4 * (HD / 32) / GK;     // groups over (j, kk)
+    bf16x8 kfr[2][GK];
+    auto load_k = [&](int g, bf16x8* dst) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int row = (j >> 1) * 32 + (fr >> 2) * 8 + (j & 1) * 4 + (fr & 3);
-#pragma unroll
-      for (int kk = 0; kk < HD / 32; ++kk) {
-        const int c = kk * 4 + fg;
-        const bf16x8 kf = *(const bf16x8*)(ksm + row * KROW + ((c ^ kswz(row)) << 4));
-#pragma unroll
-        for (int u = 0; u < QT; ++u) s[u][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[u][kk], s[u][j], 0, 0, 0);
+      for (int e = 0; e < GK; ++e) {
+        const int step = g * GK + e, j = step / (HD / 32), kk = step % (HD / 32);
+        const int row = (j >> 1) * 32 + (fr >> 2) * 8 + (j & 1) * 4 + (fr & 3);
+        dst[e] = *(const bf16x8*)(ksm + row * KROW + (((kk * 4 + fg) ^ kswz(row)) << 4));
       }
+    };
+    load_k(0, kfr[0]);
+#pragma unroll
+    for (int g = 0; g < NKG; ++g) {
+      if (g + 1 < NKG) load_k(g + 1, kfr[(g + 1) & 1]);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int e = 0; e < GK; ++e) {
+        const int step = g * GK + e, j = step / (HD / 32), kk = step % (HD / 32);
+#pragma unroll
+        for (int u = 0; u < QT; ++u) s[u][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfr[g & 1][e], qf[u][kk], s[u][j], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
     }
+    ATT_MARK(2)
     // ---- online softmax; lane holds keys kv0 + (j>>1)*32 + fg*8 + (j&1)*4 + r of query fr (per q-tile).
     // The running max is kept in RAW score units and the softmax scale is folded into one fma per element
     // (e = exp2(s*c - m*c)); masking (2 cmp + 2 select per element) is compiled only into boundary tiles.
@@ -209,19 +238,40 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(AttnArgs p) {
     };
     if (kv0 + KV <= wav_min_limit) softmax_tile(std::false_type{});  // every key of the tile visible to every row
     else softmax_tile(std::true_type{});
+    ATT_MARK(3)
     // ---- O^T += Vt . P^T ; Vt fragments shared by the q-tiles
+    // same for the V^T fragments: the next group's reads are issued before this group's MFMAs
+    constexpr int GV = 2;
+    constexpr int NG = 2 * (HD / 16) / GV;  // groups of GV (tt, n) steps
+    bf16x8 vfr[2][GV];
+    auto load_v = [&](int g, bf16x8* dst) {
 #pragma unroll
-    for (int tt = 0; tt < 2; ++tt) {
-#pragma unroll
-      for (int n = 0; n < HD / 16; ++n) {
+      for (int e = 0; e < GV; ++e) {
+        const int step = g * GV + e, tt = step / (HD / 16), n = step % (HD / 16);
         const int row = n * 16 + fr;  // d index
         const int c = tt * 4 + fg;    // keys 32*tt + fg*8 .. +7 = one 16-B chunk of the Vt row
-        const bf16x8 vfrag = *(const bf16x8*)(vsm + row * 128 + ((c ^ (row & 7)) << 4));
-#pragma unroll
-        for (int u = 0; u < QT; ++u) o[u][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vfrag, pb[u][tt].v, o[u][n], 0, 0, 0);
+        dst[e] = *(const bf16x8*)(vsm + row * 128 + ((c ^ (row & 7)) << 4));
       }
+    };
+    load_v(0, vfr[0]);
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      if (g + 1 < NG) load_v(g + 1, vfr[(g + 1) & 1]);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int e = 0; e < GV; ++e) {
+        const int step = g * GV + e, tt = step / (HD / 16), n = step % (HD / 16);
+#pragma unroll
+        for (int u = 0; u < QT; ++u) o[u][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vfr[g & 1][e], pb[u][tt].v, o[u][n], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
     }
+    ATT_MARK(4)
   }
+#ifdef G256_CLK
+  if (threadIdx.x == 0 && blockIdx.x == gridDim.x - 1 && blockIdx.y == 0 && HD == 128)
+    for (int i = 0; i < 20; ++i) att_clk[i] = am[i];
+#endif
 
   // ---- epilogue: lane holds d = n*16 + fg*4 + r for query fr
 #pragma unroll
