@@ -73,6 +73,12 @@ __device__ __forceinline__ f32x4 mfma_fp8x2(bf16x8 a, bf16x8 b, f32x4 c) {
 #ifndef G256_MFMA32
 #define G256_MFMA32 0
 #endif
+#ifndef G256_DRAIN
+#define G256_DRAIN 1  // drain a load segment's ds_reads before its barrier: formally safe refills, and A/B-measured +0.4 %
+#endif
+#ifndef G256_SPLIT
+#define G256_SPLIT 0  // 1: B1(t+2) is issued in X(t+1) instead of Y(t) (4 + 4 LDS-DMA pieces per segment instead of 2 + 6)
+#endif
 #ifndef G256_2PHASE
 #define G256_2PHASE 1  // two 32-MFMA phases per K-tile (0 = the four-phase schedule)
 #endif
@@ -220,8 +226,13 @@ __global__ __launch_bounds__(NT) void G256_KERNEL(GemmArgs p) {
 #if G256_2PHASE
   // ---- prologue: P(0) = {A0,B0,B1}(0), Q(0) = {A1}(0), P(1) ; P(0) must have landed before the first reads
   issue(HT_A0, 0); issue(HT_B0, 0); issue(HT_B1, 0); issue(HT_A1, 0);
+#if G256_SPLIT
+  issue(HT_A0, 1); issue(HT_B0, 1);
+  if (nt >= 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+#else
   issue(HT_A0, 1); issue(HT_B0, 1); issue(HT_B1, 1);
   if (nt >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+#endif
   else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #else
   // ---- prologue: A0(0) B0(0) A1(0) B1(0) A0(1) | wait | B0(1)
@@ -320,20 +331,36 @@ __global__ __launch_bounds__(NT) void G256_KERNEL(GemmArgs p) {
   // before the barrier that ends their load segment.  vmcnt: at X only P(t+1) (6 pieces) may stay in flight, at Y
   // only Q(t+1) (2 pieces).
   bf16x8 bfr[4][2];
+#if G256_DRAIN
+#define DRAIN_READS asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#else
+#define DRAIN_READS
+#endif
+// The barrier that hands the matrix pipe to the partner group is issued G256_EARLY MFMAs BEFORE the end of the segment:
+// its round trip (~100 clk) then overlaps this wave's last MFMAs instead of leaving the pipe idle at every phase boundary.
+#ifndef G256_EARLY
+#define G256_EARLY 0  // measured: 6 -> 87 img/s (vs 96): the partner's load segment is as long as an MFMA segment, so the
+                      // mid-segment barrier stalls this wave instead of hiding the hand-off
+#endif
 #define PHASE32(P, I0)                                                                                    \
   __builtin_amdgcn_sched_barrier(0);                                                                      \
   __builtin_amdgcn_s_barrier();                                                                           \
   __builtin_amdgcn_sched_barrier(0);                                                                      \
   PH_MARK(2 * (P))                                                                                        \
   __builtin_amdgcn_s_setprio(1);                                                                          \
-  _Pragma("unroll") for (int kk = 0; kk < 2; ++kk)                                                        \
-    _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                         \
-      _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                       \
-        acc[I0 + i][j] = MFMA16(bfr[j][kk], af[i][kk], acc[I0 + i][j]);                                   \
+  _Pragma("unroll") for (int idx = 0; idx < 32; ++idx) {                                                  \
+    const int kk = idx >> 4, i = (idx >> 2) & 3, j = idx & 3;                                             \
+    if (idx == 32 - G256_EARLY) {                                                                         \
+      __builtin_amdgcn_sched_barrier(0);                                                                  \
+      __builtin_amdgcn_s_barrier();                                                                       \
+      __builtin_amdgcn_sched_barrier(0);                                                                  \
+    }                                                                                                     \
+    acc[I0 + i][j] = MFMA16(bfr[j][kk], af[i][kk], acc[I0 + i][j]);                                       \
+  }                                                                                                       \
   __builtin_amdgcn_s_setprio(0);                                                                          \
   PH_MARK(2 * (P) + 1)                                                                                    \
   __builtin_amdgcn_sched_barrier(0);                                                                      \
-  __builtin_amdgcn_s_barrier();                                                                           \
+  if (G256_EARLY == 0) __builtin_amdgcn_s_barrier();                                                      \
   __builtin_amdgcn_sched_barrier(0);
   for (int t = 0; t < nt; ++t) {
     const char* st = smem + (t & 1) * STAGE_BYTES;
@@ -350,9 +377,14 @@ __global__ __launch_bounds__(NT) void G256_KERNEL(GemmArgs p) {
       af[i][1] = *(const bf16x8*)(st + a_lane + i * 2048 + (off0 ^ 64));
     }
     __builtin_amdgcn_sched_barrier(0);
+#if G256_SPLIT
+    WAIT_VM(4);
+    issue_at(HT_B1, t + 1, (long)(ks_begin + t + 1) * KT);
+#else
     WAIT_VM(6);
+#endif
     issue_at(HT_A1, t + 1, aoff1);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    DRAIN_READS
     PHASE32(0, 0)
     // ===== Y
 #pragma unroll
@@ -364,9 +396,11 @@ __global__ __launch_bounds__(NT) void G256_KERNEL(GemmArgs p) {
     WAIT_VM(2);
     issue_at(HT_A0, t + 2, aoff2);
     issue_at(HT_B0, t + 2, (long)(ks_begin + t + 2) * KT);
+#if !G256_SPLIT
     issue_at(HT_B1, t + 2, (long)(ks_begin + t + 2) * KT);
+#endif
     advance();
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    DRAIN_READS
     PHASE32(1, 4)
   }
 #else
