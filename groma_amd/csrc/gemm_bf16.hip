@@ -22,6 +22,8 @@
 // time of one 256^2 K-step on a CU relative to one 128^2 K-step of two co-resident blocks (4x the MACs of one
 // block = 2x the work per CU-interval, executed ~1.45x faster per flop)
 #define G256_COST 1.41
+#define W128_DEFAULT 0
+#include <stdlib.h>
 
 __global__ __launch_bounds__(NTHREADS) void gemm_bf16_kernel(GemmArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -257,7 +259,7 @@ extern "C" int gr_gemm_bf16(const gr_gemm_desc* d, hipStream_t stream) {
   const bool gemv = d->tile == 1 || d->tile == 2;  // decode-step shape: weights streamed once, no MFMA (gemv_bf16.hip)
   const bool partials_only = d->tile == 2;         // the caller's next kernel consumes ws[splits, M, N] (decode.hip)
   if (gemv && (p.M > 8 || p.conv_C > 0 || splits != gr_cdiv(p.K, 512) || !p.ws)) return GR_EINVAL;
-  if (d->tile == 256 || d->fp8 || d->act == 4) use256 = true;  // fp8 and the fused-QKV epilogue exist for the 256x256 kernel only
+  if (d->tile == 256 || d->tile == 257 || d->fp8 || d->act == 4) use256 = true;  // fp8 and the fused-QKV epilogue exist for the 256x256 kernel only
   else if (d->tile == 0) {
     const long t128 = (long)gr_cdiv(p.M, 128) * gr_cdiv(p.N, 128), t256 = (long)gr_cdiv(p.M, 256) * gr_cdiv(p.N, 256);
     const double ksteps = (double)(p.K / 64) / splits;
@@ -288,7 +290,10 @@ extern "C" int gr_gemm_bf16(const gr_gemm_desc* d, hipStream_t stream) {
     const int rc = gr_launch_gemv(p, stream);
     if (rc != GR_OK) return rc;
   } else if (use256) {
-    const int rc = d->act == 4 ? gr_launch_gemm256_qkv(p, stream) : d->fp8 ? gr_launch_gemm256_fp8(p, stream) : gr_launch_gemm256(p, stream);
+    static int w128 = -1;  // GROMA_W128=1: plain bf16 GEMMs of the 256x256 class go to the one-wave-per-SIMD kernel
+    if (w128 < 0) { const char* e = getenv("GROMA_W128"); w128 = e ? atoi(e) : W128_DEFAULT; }
+    const bool use_w128 = (d->tile == 257 || (w128 && d->tile != 256)) && !d->fp8 && d->act != 4 && p.conv_C == 0;
+    const int rc = use_w128 ? gr_launch_gemm_w128(p, stream) : d->act == 4 ? gr_launch_gemm256_qkv(p, stream) : d->fp8 ? gr_launch_gemm256_fp8(p, stream) : gr_launch_gemm256(p, stream);
     if (rc != GR_OK) return rc;
   } else {
     hipLaunchKernelGGL(gemm_bf16_kernel, grid, dim3(NTHREADS), 65536, stream, p);

@@ -460,6 +460,8 @@ __device__ __forceinline__ void epi_v_from_stage(const GemmArgs& p, const char* 
 int gr_launch_gemv(const GemmArgs& p, hipStream_t stream);
 // 256x256x64 ping-pong kernel (gemm_bf16_256.hip)
 int gr_launch_gemm256(const GemmArgs& p, hipStream_t stream);
+// one-wave-per-SIMD 256x256 kernel (gemm_bf16_w128.hip): plain bf16 GEMM only
+int gr_launch_gemm_w128(const GemmArgs& p, hipStream_t stream);
 // the same kernel compiled with the fused-QKV epilogue (gemm_qkv_256.hip): act == 4 only
 int gr_launch_gemm256_qkv(const GemmArgs& p, hipStream_t stream);
 // OCP-fp8 build of the same kernel (gemm_fp8_256.hip); A/W are e4m3 bytes, K % 128 == 0

@@ -60,7 +60,8 @@ typedef struct gr_gemm_desc {
   int resid_mod;      /* > 0: residual row = m % resid_mod (position-embedding broadcast)          */
   /* output row remap: row(m) = (m / c_group)*c_group_stride + c_row_off + m % c_group (c_group > 0) */
   int c_group, c_group_stride, c_row_off;
-  int tile;           /* 0 = choose per shape; 128 / 256 force the 128x128 / 256x256 kernel; 1 = skinny decode
+  int tile;           /* 0 = choose per shape; 128 / 256 force the 128x128 / 256x256 kernel (257 = its one-wave-per-
+                         SIMD variant, measured slower, kept for comparison); 1 = skinny decode
                          kernel (M <= 8; requires splits == ceil(K/512) and ws); 2 = the same kernel but
                          the split-K partials are LEFT in ws [splits, M, N] f32 for a fused consumer
                          (gr_decode_reduce_norm / gr_decode_qkv_rope): C and the epilogue fields are unused */

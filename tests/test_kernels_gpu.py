@@ -533,3 +533,21 @@ def test_gemm_fused_qkv_epilogue_equals_split_path(dev, B, H, hd, L, K, rope, bi
         assert (x.float() - y.float()).abs().max().item() <= 2.0 ** -7 * max(1.0, y.float().abs().max().item())
     if not rope:
         assert torch.equal(q1, q0) and torch.equal(k1, k0)
+
+
+@pytest.mark.parametrize("M,N,K,kw", [(600, 520, 320, dict()), (1000, 1024, 4096, dict(bias=True, act=1)),
+                                      (300, 512, 1024, dict(resid=True, out_f32=True)), (513, 768, 256, dict(act=3))])
+def test_gemm_w128_variant_equals_pingpong(dev, M, N, K, kw):
+    """the one-wave-per-SIMD 256x256 kernel (tile=257, not the default) accumulates in the same order: bit-identical"""
+    ops = _ops()
+    a = rnd((M, K), dev, seed=1).bfloat16()
+    w = (rnd((N, K), dev, seed=2) * 0.1).bfloat16()
+    args = dict(act=kw.get("act", 0), out_f32=kw.get("out_f32", False))
+    if kw.get("bias"):
+        args["bias"] = rnd((N,), dev, seed=3)
+    outs = []
+    for tile in (256, 257):
+        if kw.get("resid"):
+            args["resid"] = rnd((M, N), dev, seed=4)
+        outs.append(ops.gemm(a, w, tile=tile, **args).clone())
+    assert torch.equal(outs[0], outs[1])
