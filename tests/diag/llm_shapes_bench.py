@@ -16,7 +16,7 @@ def bench(M,N,K,it=20,**kw):
     e1.record(); torch.cuda.synchronize()
     ms=e0.elapsed_time(e1)/it
     return "%.1f us %.0f TF" % (ms*1e3, 2.0*M*N*K/ms/1e9)
-print("skew", os.environ.get("GROMA_G256_SKEW"))
+print("256x256 kernel on the four LLaMA GEMM shapes at 14 img/GPU")
 print("qkv   ", bench(8148,12288,4096))
 print("o     ", bench(8148,4096,4096,resid=1,out_f32=True))
 print("gateup", bench(8148,22016,4096,act=3))
