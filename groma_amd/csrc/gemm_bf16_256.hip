@@ -6,21 +6,19 @@
 //
 // Structure (8 waves = 2(M) x 4(N), each wave a 128x64 output block = 8x4 tiles of v_mfma_f32_16x16x32_bf16):
 //  * the two wave groups (wm = 0 / 1) that share each SIMD run one barrier interval apart: while one group issues
-//    its 16 MFMAs of a phase, the other does that phase's LDS fragment reads and global->LDS DMA issue, then they
-//    swap ("8-phase" template of the guide, 4 phases per K-tile);
-//  * a phase computes one 64x32 quadrant of the wave's block over K=64.  Quadrant order (A0,B0) (A0,B1) (A1,B1)
-//    (A1,B0) keeps every fragment in registers after its single LDS read: A0,B0 are read in phase 0, B1 in phase 1,
-//    A1 in phase 2, nothing in phase 3;
+//    the 32 MFMAs of a phase, the other does its LDS fragment reads and global->LDS DMA issue, then they swap.  The
+//    partner's MFMAs hide every non-MFMA issue slot (an LDS-DMA issue alone costs ~60 clk) -- the one-wave-per-SIMD
+//    variant gemm_bf16_w128.hip shows what those cost when nothing hides them;
+//  * two phases per 64-deep K-tile:  X: A0 x (B0,B1) -> acc[0..3][*]   Y: A1 x (B0,B1) -> acc[4..7][*].  The B
+//    fragments stay in registers across both; A0's registers are reused for A1.  (Round 1 started with four 16-MFMA
+//    quadrant phases; each phase boundary costs a barrier round trip on the matrix pipe, halving them: +3.3 % e2e.)
 //  * LDS = 2 stages x (A 256x64 + B 256x64) bf16 = 128 KB.  Each stage is four 16 KB "half-tiles"
-//    {A0, B0, B1, A1} (the rows every wave needs for that fragment).  One half-tile (2 x global_load_lds_dwordx4 per
-//    lane) is issued per phase, in the order its LDS region becomes dead:
-//        phase 0 of tile t: A1(t+1)   phase 1: B1(t+1)   phase 2: A0(t+2)   phase 3: B0(t+2)
-//    -- every region is re-staged >= 2 phases after its last ds_read (so the reads' lgkmcnt wait can sit after the
-//    barrier) and every half-tile has 4-6 phases of flight time.  Counted waits retire exactly the half-tile(s) read
-//    in the NEXT phase: vmcnt(4) in phase 0 (B1), vmcnt(8) in phase 1 (A1), none in phase 2, vmcnt(6) in phase 3
-//    (A0,B0 of the next tile); the barrier that ends the phase publishes them to the other waves.  The DMA queue is
-//    never drained in steady state.  Within a phase's load segment the ds_reads are issued FIRST so they complete in
-//    the shadow of the DMA wait/issue.
+//    {A0, B0, B1, A1} (the rows every wave needs for that fragment), refilled as P = {A0,B0,B1} -- issued in Y(t) for
+//    tile t+2, after X(t)'s reads were drained before the barrier that ended X's load segment -- and Q = {A1}, issued in
+//    X(t) for tile t+1.  Every piece has one full K-tile of flight.  Counted waits: vmcnt(6) in X (Q(t) landed, P(t+1)
+//    may fly), vmcnt(2) in Y (P(t+1) landed, Q(t+1) may fly); the barrier that ends the segment publishes them.  The
+//    DMA queue is never drained in steady state.  ds_reads are issued FIRST in a segment so they complete in the shadow
+//    of the DMA wait/issue.
 //  * LDS image: 128-B rows, 16-B chunk position = k-chunk ^ (row & 7): written lane-linearly by the DMA with the
 //    XOR applied to the per-lane SOURCE address, mirrored on the ds_read_b128 side (conflict-free).
 #include "gemm_common.h"
@@ -66,27 +64,8 @@ __device__ __forceinline__ f32x4 mfma_fp8x2(bf16x8 a, bf16x8 b, f32x4 c) {
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0)
 #endif
 #define KT (128 / ESZ)  // K elements per K-tile (one 128-B LDS row)
-#define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0)
-// G256_MFMA32 = 1 (experiment, measured SLOWER: 1.22 vs 1.42 PF at 8192^3): v_mfma_f32_32x32x16_bf16 instead of
-// v_mfma_f32_16x16x32_bf16 (16 per phase, ~17 clk each; 83 % ceiling).  Fragment rows are then 32 consecutive LDS
-// rows per ds_read_b128, which wants the chunk swizzle (row>>1)&7 instead of row&7 to stay conflict-free.
-#ifndef G256_MFMA32
-#define G256_MFMA32 0
-#endif
-#ifndef G256_DRAIN
-#define G256_DRAIN 1  // drain a load segment's ds_reads before its barrier: formally safe refills, and A/B-measured +0.4 %
-#endif
-#ifndef G256_SPLIT
-#define G256_SPLIT 0  // 1: B1(t+2) is issued in X(t+1) instead of Y(t) (4 + 4 LDS-DMA pieces per segment instead of 2 + 6)
-#endif
-#ifndef G256_2PHASE
-#define G256_2PHASE 1  // two 32-MFMA phases per K-tile (0 = the four-phase schedule)
-#endif
-#if G256_MFMA32
-#define LDS_SWZ(row) (((row) >> 1) & 7)
-#else
+// (v_mfma_f32_32x32x16_bf16 was tried in place of 16x16x32 -- 1.22 vs 1.42 PF at 8192^3 -- and removed.)
 #define LDS_SWZ(row) ((row) & 7)
-#endif
 
 #if defined(G256_CLK) && !G256_FP8 && !defined(G256_QKV)  // diagnostic build only (tests/diag/build_clk.py): shader/wall clocks of block 0 at start, loop end, exit
 __device__ unsigned long long g256_clk[40];
@@ -198,19 +177,6 @@ __global__ __launch_bounds__(NT) void G256_KERNEL(GemmArgs p) {
     issue_at(h, tile, (isA && !G256_FP8) ? a_k_off(p, ks_begin + tile) : (long)(ks_begin + tile) * KT);
   };
 
-#if G256_MFMA32
-  f32x16 acc[4][2];  // [m-tile of 32][n-tile of 32]
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-  const int fr = lane & 31, fg = lane >> 5;  // fragment row, k-half of a 16-wide k-step
-  int koff[4];                               // byte offset of k-step s (chunk 2s+fg) in this lane's swizzled row
-#pragma unroll
-  for (int ks = 0; ks < 4; ++ks) koff[ks] = ((2 * ks + fg) ^ LDS_SWZ(fr)) << 4;
-#else
   f32x4 acc[8][4];  // [mi][ni]
 #pragma unroll
   for (int i = 0; i < 8; ++i)
@@ -219,29 +185,14 @@ __global__ __launch_bounds__(NT) void G256_KERNEL(GemmArgs p) {
 
   const int fr = lane & 15, fg = lane >> 4;
   const int off0 = (fg ^ (fr & 7)) << 4;  // chunk fg of a row with (row&7) == (fr&7); the kk=1 chunk is off0 ^ 64
-#endif
   const int a_lane = (wm * 128 + fr) * 128;
   const int b_lane = B_OFF + (wn * 64 + fr) * 128;
 
-#if G256_2PHASE
   // ---- prologue: P(0) = {A0,B0,B1}(0), Q(0) = {A1}(0), P(1) ; P(0) must have landed before the first reads
   issue(HT_A0, 0); issue(HT_B0, 0); issue(HT_B1, 0); issue(HT_A1, 0);
-#if G256_SPLIT
-  issue(HT_A0, 1); issue(HT_B0, 1);
-  if (nt >= 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-#else
   issue(HT_A0, 1); issue(HT_B0, 1); issue(HT_B1, 1);
   if (nt >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-#endif
   else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#else
-  // ---- prologue: A0(0) B0(0) A1(0) B1(0) A0(1) | wait | B0(1)
-  issue(HT_A0, 0); issue(HT_B0, 0); issue(HT_A1, 0); issue(HT_B1, 0);
-  issue(HT_A0, 1);
-  if (nt >= 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");  // A0(0), B0(0) landed
-  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  issue(HT_B0, 1);
-#endif
   __builtin_amdgcn_s_barrier();
   if (wm == 1) __builtin_amdgcn_s_barrier();  // stagger the second wave group by one interval
 
@@ -250,79 +201,9 @@ __global__ __launch_bounds__(NT) void G256_KERNEL(GemmArgs p) {
     if (steady) asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory");   \
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               \
   } while (0)
-#if G256_MFMA32
-  bf16x8 af[2][4], b0f[4], b1f[4];  // [m-tile within the A half][k-step], [k-step]
-// barrier -> 8 MFMAs 32x32x16 (A half rows I0.., B n-tile J with fragment set BF) -> barrier
-#define COMPUTE_PHASE(I0, J, BF)                                                                          \
-  __builtin_amdgcn_sched_barrier(0);                                                                      \
-  __builtin_amdgcn_s_barrier();                                                                           \
-  __builtin_amdgcn_sched_barrier(0);                                                                      \
-  __builtin_amdgcn_s_setprio(1);                                                                          \
-  _Pragma("unroll") for (int ks = 0; ks < 4; ++ks)                                                        \
-    _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                         \
-      acc[I0 + i][J] = MFMA32(BF[ks], af[i][ks], acc[I0 + i][J]);                                         \
-  __builtin_amdgcn_s_setprio(0);                                                                          \
-  __builtin_amdgcn_sched_barrier(0);                                                                      \
-  __builtin_amdgcn_s_barrier();                                                                           \
-  __builtin_amdgcn_sched_barrier(0);
-#define READ_A(HALF)                                                                                      \
-  _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                           \
-    _Pragma("unroll") for (int ks = 0; ks < 4; ++ks)                                                      \
-      af[i][ks] = *(const bf16x8*)(st + a_lane + ((HALF) * 2 + i) * 4096 + koff[ks]);
-#define READ_B(DST, HALF)                                                                                 \
-  _Pragma("unroll") for (int ks = 0; ks < 4; ++ks)                                                        \
-    DST[ks] = *(const bf16x8*)(st + b_lane + (HALF) * 4096 + koff[ks]);
-
-  for (int t = 0; t < nt; ++t) {
-    const char* st = smem + (t & 1) * STAGE_BYTES;
-    const bool steady = t + 2 < nt;
-    // ===== phase 0 : reads A0,B0 ; A0 x B0 ; issues A1(t+1) ; retires B1(t)
-    READ_B(b0f, 0)
-    READ_A(0)
-    __builtin_amdgcn_sched_barrier(0);
-    WAIT_VM(4);
-    issue_at(HT_A1, t + 1, aoff1);
-    COMPUTE_PHASE(0, 0, b0f)
-    // ===== phase 1 : reads B1 ; A0 x B1 ; issues B1(t+1) ; retires A1(t)
-    READ_B(b1f, 1)
-    __builtin_amdgcn_sched_barrier(0);
-    WAIT_VM(8);
-    issue_at(HT_B1, t + 1, (long)(ks_begin + t + 1) * KT);
-    COMPUTE_PHASE(0, 1, b1f)
-    // ===== phase 2 : reads A1 ; A1 x B1 ; issues A0(t+2)
-    READ_A(1)
-    __builtin_amdgcn_sched_barrier(0);
-    if (!steady) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    issue_at(HT_A0, t + 2, aoff2);
-    COMPUTE_PHASE(2, 1, b1f)
-    // ===== phase 3 : no LDS reads ; A1 x B0 ; issues B0(t+2) ; retires A0(t+1), B0(t+1)
-    WAIT_VM(6);
-    issue_at(HT_B0, t + 2, (long)(ks_begin + t + 2) * KT);
-    advance();
-    COMPUTE_PHASE(2, 0, b0f)
-  }
-#else
-  bf16x8 af[4][2], b0f[2][2], b1f[2][2];
-
-// barrier -> 16 MFMAs (A sub-block rows I0.., B sub-block cols J0.. with fragment set BF) -> barrier
-#define COMPUTE_PHASE_P(P, I0, J0, BF)                                                                    \
-  __builtin_amdgcn_sched_barrier(0);                                                                      \
-  __builtin_amdgcn_s_barrier();                                                                           \
-  __builtin_amdgcn_sched_barrier(0);                                                                      \
-  PH_MARK(2 * (P))                                                                                        \
-  __builtin_amdgcn_s_setprio(1);                                                                          \
-  _Pragma("unroll") for (int kk = 0; kk < 2; ++kk)                                                        \
-    _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                         \
-      _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                       \
-        acc[I0 + i][J0 + j] = MFMA16(BF[j][kk], af[i][kk], acc[I0 + i][J0 + j]);                          \
-  __builtin_amdgcn_s_setprio(0);                                                                          \
-  PH_MARK(2 * (P) + 1)                                                                                    \
-  __builtin_amdgcn_sched_barrier(0);                                                                      \
-  __builtin_amdgcn_s_barrier();                                                                           \
-  __builtin_amdgcn_sched_barrier(0);
+  bf16x8 af[4][2];
 
   PH_DECL
-#if G256_2PHASE
   // Two 32-MFMA phases per K-tile instead of four 16-MFMA ones: every phase boundary costs ~80 clk of barrier round
   // trip on top of the MFMA segment (tests/diag/gemm_clk.py), so halving the boundaries is worth ~11 % of the loop.
   //   X(t): reads P(t) = A0,B0,B1 -> af, bf ; issues Q(t+1) = A1(t+1) ; 32 MFMA  acc[0..3][*] += A0 x B
@@ -331,36 +212,23 @@ __global__ __launch_bounds__(NT) void G256_KERNEL(GemmArgs p) {
   // before the barrier that ends their load segment.  vmcnt: at X only P(t+1) (6 pieces) may stay in flight, at Y
   // only Q(t+1) (2 pieces).
   bf16x8 bfr[4][2];
-#if G256_DRAIN
 #define DRAIN_READS asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#else
-#define DRAIN_READS
-#endif
-// The barrier that hands the matrix pipe to the partner group is issued G256_EARLY MFMAs BEFORE the end of the segment:
-// its round trip (~100 clk) then overlaps this wave's last MFMAs instead of leaving the pipe idle at every phase boundary.
-#ifndef G256_EARLY
-#define G256_EARLY 0  // measured: 6 -> 87 img/s (vs 96): the partner's load segment is as long as an MFMA segment, so the
-                      // mid-segment barrier stalls this wave instead of hiding the hand-off
-#endif
+// (Variants A/B-measured on one box and removed -- DESIGN.md 3a: handing the pipe over 6 MFMAs early, not draining the
+// reads, splitting the LDS-DMA issue 4 + 4 over the two segments, the original four 16-MFMA phases per K-tile.)
 #define PHASE32(P, I0)                                                                                    \
   __builtin_amdgcn_sched_barrier(0);                                                                      \
   __builtin_amdgcn_s_barrier();                                                                           \
   __builtin_amdgcn_sched_barrier(0);                                                                      \
   PH_MARK(2 * (P))                                                                                        \
   __builtin_amdgcn_s_setprio(1);                                                                          \
-  _Pragma("unroll") for (int idx = 0; idx < 32; ++idx) {                                                  \
-    const int kk = idx >> 4, i = (idx >> 2) & 3, j = idx & 3;                                             \
-    if (idx == 32 - G256_EARLY) {                                                                         \
-      __builtin_amdgcn_sched_barrier(0);                                                                  \
-      __builtin_amdgcn_s_barrier();                                                                       \
-      __builtin_amdgcn_sched_barrier(0);                                                                  \
-    }                                                                                                     \
-    acc[I0 + i][j] = MFMA16(bfr[j][kk], af[i][kk], acc[I0 + i][j]);                                       \
-  }                                                                                                       \
+  _Pragma("unroll") for (int kk = 0; kk < 2; ++kk)                                                        \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                         \
+      _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                       \
+        acc[I0 + i][j] = MFMA16(bfr[j][kk], af[i][kk], acc[I0 + i][j]);                                   \
   __builtin_amdgcn_s_setprio(0);                                                                          \
   PH_MARK(2 * (P) + 1)                                                                                    \
   __builtin_amdgcn_sched_barrier(0);                                                                      \
-  if (G256_EARLY == 0) __builtin_amdgcn_s_barrier();                                                      \
+  __builtin_amdgcn_s_barrier();                                                                           \
   __builtin_amdgcn_sched_barrier(0);
   for (int t = 0; t < nt; ++t) {
     const char* st = smem + (t & 1) * STAGE_BYTES;
@@ -377,12 +245,7 @@ __global__ __launch_bounds__(NT) void G256_KERNEL(GemmArgs p) {
       af[i][1] = *(const bf16x8*)(st + a_lane + i * 2048 + (off0 ^ 64));
     }
     __builtin_amdgcn_sched_barrier(0);
-#if G256_SPLIT
-    WAIT_VM(4);
-    issue_at(HT_B1, t + 1, (long)(ks_begin + t + 1) * KT);
-#else
     WAIT_VM(6);
-#endif
     issue_at(HT_A1, t + 1, aoff1);
     DRAIN_READS
     PHASE32(0, 0)
@@ -396,62 +259,12 @@ __global__ __launch_bounds__(NT) void G256_KERNEL(GemmArgs p) {
     WAIT_VM(2);
     issue_at(HT_A0, t + 2, aoff2);
     issue_at(HT_B0, t + 2, (long)(ks_begin + t + 2) * KT);
-#if !G256_SPLIT
     issue_at(HT_B1, t + 2, (long)(ks_begin + t + 2) * KT);
-#endif
     advance();
     DRAIN_READS
     PHASE32(1, 4)
   }
-#else
-  for (int t = 0; t < nt; ++t) {
-    const char* st = smem + (t & 1) * STAGE_BYTES;
-    const bool steady = t + 2 < nt;  // every half-tile of the schedule up to this tile's issues really exists
-    // ===== phase 0 : reads A0,B0 ; computes A0 x B0 ; issues A1(t+1) ; retires B1(t) (read in phase 1)
-    // (ds_reads first: they complete in the shadow of the DMA wait + issue, before the barrier)
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      b0f[j][0] = *(const bf16x8*)(st + b_lane + j * 2048 + off0);
-      b0f[j][1] = *(const bf16x8*)(st + b_lane + j * 2048 + (off0 ^ 64));
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      af[i][0] = *(const bf16x8*)(st + a_lane + i * 2048 + off0);
-      af[i][1] = *(const bf16x8*)(st + a_lane + i * 2048 + (off0 ^ 64));
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    WAIT_VM(4);
-    issue_at(HT_A1, t + 1, aoff1);
-    COMPUTE_PHASE_P(0, 0, 0, b0f)
-    // ===== phase 1 : reads B1 ; computes A0 x B1 ; issues B1(t+1) ; retires A1(t) (read in phase 2)
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      b1f[j][0] = *(const bf16x8*)(st + b_lane + (2 + j) * 2048 + off0);
-      b1f[j][1] = *(const bf16x8*)(st + b_lane + (2 + j) * 2048 + (off0 ^ 64));
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    WAIT_VM(8);
-    issue_at(HT_B1, t + 1, (long)(ks_begin + t + 1) * KT);
-    COMPUTE_PHASE_P(1, 0, 2, b1f)
-    // ===== phase 2 : reads A1 ; computes A1 x B1 ; issues A0(t+2) ; nothing to retire (phase 3 reads nothing)
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      af[i][0] = *(const bf16x8*)(st + a_lane + (4 + i) * 2048 + off0);
-      af[i][1] = *(const bf16x8*)(st + a_lane + (4 + i) * 2048 + (off0 ^ 64));
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    if (!steady) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    issue_at(HT_A0, t + 2, aoff2);
-    COMPUTE_PHASE_P(2, 4, 2, b1f)
-    // ===== phase 3 : no LDS reads ; computes A1 x B0 ; issues B0(t+2) ; retires A0(t+1), B0(t+1) (next phase 0)
-    WAIT_VM(6);
-    issue_at(HT_B0, t + 2, (long)(ks_begin + t + 2) * KT);
-    advance();
-    COMPUTE_PHASE_P(3, 4, 0, b0f)
-  }
-#endif
   PH_FLUSH
-#endif
   if (wm == 0) __builtin_amdgcn_s_barrier();  // re-align the groups (same barrier count for every wave)
 
   // ---- epilogue through LDS in 4 passes of 64 rows (2 m-tiles per wave), double-buffered over the two stages ----
@@ -469,21 +282,10 @@ __global__ __launch_bounds__(NT) void G256_KERNEL(GemmArgs p) {
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     char* buf = smem + (q & 1) * STAGE_BYTES;
-#if G256_MFMA32
-    // C layout of 32x32: col = lane&31 (-> m), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (-> n): 4 float4 groups per tile
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const f32x4 v = {acc[q][j][4 * g], acc[q][j][4 * g + 1], acc[q][j][4 * g + 2], acc[q][j][4 * g + 3]};
-        stage_write4<T256>(buf, wm * 32 + fr, wn * 16 + j * 8 + 2 * g + fg, v);
-      }
-#else
 #pragma unroll
     for (int e = 0; e < 2; ++e)
 #pragma unroll
       for (int j = 0; j < 4; ++j) stage_write4<T256>(buf, wm * 32 + e * 16 + fr, wn * 16 + j * 4 + fg, acc[2 * q + e][j]);
-#endif
     __syncthreads();
     CLK_MARK(3 + 2 * q)
     // staged row sr -> tile row (sr>>5)*128 + q*32 + (sr&31)
