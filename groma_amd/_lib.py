@@ -48,7 +48,7 @@ SIGNATURES = {
     "gr_norm_fp8": [_P, _P, _P, _P, _P, _I, _I, _F, _I, _P],
     "gr_layernorm": [_P, _P, _P, _P, _P, _I, _I, _L, _L, _F, _I, _I, _P],
     "gr_rmsnorm": [_P, _P, _P, _I, _I, _L, _L, _F, _I, _P],
-    "gr_attention_bf16": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _F, _P, _I, _P],
+    "gr_attention_bf16": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _F, _P, _I, _L, _P, _P, _P],
     "gr_qkv_split": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _I, _P],
     "gr_decode_reduce_norm": [_P, _I, _P, _P, _P, _I, _I, _F, _P],
     "gr_decode_qkv_rope": [_P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _I, _P],
@@ -97,7 +97,7 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
         fn.argtypes = argtypes
         fn.restype = c_int
-    if lib.gr_abi_version() != 3:
+    if lib.gr_abi_version() != 4:
         raise RuntimeError("libgroma_hip.so ABI version mismatch")
     _lib = lib
     return lib

@@ -31,6 +31,12 @@ struct AttnArgs {
   const int* kv_len;  // [B] or null
   const int* pos_dev;  // or null: q_pos0 of row b = pos_dev[b * pos_stride], Skv = q_pos0 + Lq (device-resident step)
   int pos_stride;
+  // q_ld > 0: q is read straight out of the fused projection buffer [B*Lq, q_ld] (row b*Lq+i, columns h*hd..) instead of
+  // a packed [B,H,Lq,hd] copy, and, when cos/sin are given, HF rotate_half RoPE at position q_pos0 + i is applied while
+  // the fragments are loaded (the partner d +- hd/2 of a lane's 8 values sits in the same lane, fragment kk +- hd/64)
+  long q_ld;
+  const float* rope_cos;
+  const float* rope_sin;
   int B, H, Lq, Skv, kv_stride;
   int causal, q_pos0;
   float scale_log2;  // softmax scale * log2(e)
@@ -67,7 +73,8 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(AttnArgs p) {
   const int b = bh / p.H, h = bh - b * p.H;
   const int q0 = blockIdx.x * (64 * QT);
 
-  const bf16_t* Qp = p.q + (long)bh * p.Lq * HD;
+  const bf16_t* Qp = p.q_ld > 0 ? p.q + (long)b * p.Lq * p.q_ld + h * HD : p.q + (long)bh * p.Lq * HD;
+  const long q_rs = p.q_ld > 0 ? p.q_ld : HD;  // row stride
   const bf16_t* Kp = p.k + (long)bh * p.kv_stride * HD;
   const bf16_t* Vp = p.vt + (long)bh * HD * p.kv_stride;
 
@@ -86,7 +93,33 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(AttnArgs p) {
     q_valid[u] = qi[u] < p.Lq;
     if (!q_valid[u]) qi[u] = p.Lq - 1;
 #pragma unroll
-    for (int kk = 0; kk < HD / 32; ++kk) qf[u][kk] = *(const bf16x8*)(Qp + (long)qi[u] * HD + kk * 32 + fg * 8);
+    for (int kk = 0; kk < HD / 32; ++kk) qf[u][kk] = *(const bf16x8*)(Qp + (long)qi[u] * q_rs + kk * 32 + fg * 8);
+    if (p.rope_cos) {  // rotate in registers: out[d] = x[d]*cos - x[d+half]*sin (d < half), x[d]*cos + x[d-half]*sin (d >= half)
+      constexpr int HALF = HD / 2, KH = HD / 64;  // fragments per half
+      const float* cp = p.rope_cos + (long)(q_pos0 + qi[u]) * HALF + fg * 8;
+      const float* sp = p.rope_sin + (long)(q_pos0 + qi[u]) * HALF + fg * 8;
+      bf16x8 rot[HD / 32];
+#pragma unroll
+      for (int kk = 0; kk < HD / 32; ++kk) {
+        const int kp = kk < KH ? kk + KH : kk - KH;
+        const float sgn = kk < KH ? -1.f : 1.f;
+        const int dc = (kk % KH) * 32;
+        const f32x4 c0 = *(const f32x4*)(cp + dc), c1 = *(const f32x4*)(cp + dc + 4);
+        const f32x4 s0 = *(const f32x4*)(sp + dc), s1 = *(const f32x4*)(sp + dc + 4);
+        union { bf16x8 v; uint32_t w[4]; } o;
+#pragma unroll
+        for (int e = 0; e < 8; e += 2) {
+          const float ca = e < 4 ? c0[e] : c1[e - 4], cb = e < 4 ? c0[e + 1] : c1[e - 3];
+          const float sa = e < 4 ? s0[e] : s1[e - 4], sb = e < 4 ? s0[e + 1] : s1[e - 3];
+          const float r0 = bf2f((bf16_t)qf[u][kk][e]) * ca + sgn * bf2f((bf16_t)qf[u][kp][e]) * sa;
+          const float r1 = bf2f((bf16_t)qf[u][kk][e + 1]) * cb + sgn * bf2f((bf16_t)qf[u][kp][e + 1]) * sb;
+          o.w[e >> 1] = pack2bf(r0, r1);
+        }
+        rot[kk] = o.v;
+      }
+#pragma unroll
+      for (int kk = 0; kk < HD / 32; ++kk) qf[u][kk] = rot[kk];
+    }
     limit[u] = p.causal ? min(kvmax, q_pos0 + qi[u] + 1) : kvmax;  // keys [0, limit) visible
   }
   // loop bounds: block-level (staging + barriers) and wave-level (compute)
@@ -291,14 +324,17 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(AttnArgs p) {
 
 extern "C" int gr_attention_bf16(const void* q, const void* k, const void* vt, void* out, const int* kv_len, int B, int H,
                                  int Lq, int Skv, int kv_stride, int head_dim, int causal, int q_pos0, float scale,
-                                 const int* pos_dev, int pos_stride,
-                                 hipStream_t stream) {
+                                 const int* pos_dev, int pos_stride, long q_ld, const float* rope_cos,
+                                 const float* rope_sin, hipStream_t stream) {
   if (!q || !k || !vt || !out || B <= 0 || H <= 0 || Lq <= 0 || Skv <= 0) return GR_EINVAL;
   if (kv_stride % 64 != 0 || kv_stride < Skv) return GR_EINVAL;  // Vt tile reads run to the next multiple of 64
   AttnArgs p;
   p.q = (const bf16_t*)q; p.k = (const bf16_t*)k; p.vt = (const bf16_t*)vt; p.out = (bf16_t*)out;
   p.kv_len = kv_len;
   p.pos_dev = pos_dev; p.pos_stride = pos_stride;
+  if (q_ld < 0 || (q_ld > 0 && (q_ld % 8 != 0 || q_ld < (long)H * head_dim)) || (rope_cos == nullptr) != (rope_sin == nullptr))
+    return GR_EINVAL;
+  p.q_ld = q_ld; p.rope_cos = rope_cos; p.rope_sin = rope_sin;
   p.B = B; p.H = H; p.Lq = Lq; p.Skv = Skv; p.kv_stride = kv_stride;
   p.causal = causal; p.q_pos0 = q_pos0;
   p.scale_log2 = scale * 1.44269504088896340736f;

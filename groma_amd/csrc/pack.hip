@@ -42,6 +42,7 @@ __global__ __launch_bounds__(256) void qkv_split_kernel(const bf16_t* __restrict
 #pragma unroll
     for (int which = 0; which < 2; ++which) {
       const bf16_t* sp = src + (long)which * H * HD;
+      if (which == 0 && !q) continue;  // q stays in the fused buffer: gr_attention_bf16 reads (and rotates) it there
       bf16_t* dst = which == 0 ? q + (((long)b * H + h) * L + t) * HD : k + (((long)b * H + h) * kv_stride + pos) * HD;
       const bf16x8 x = *(const bf16x8*)(sp + d);
       if (cosT) {
@@ -90,7 +91,7 @@ __global__ __launch_bounds__(256) void qkv_split_kernel(const bf16_t* __restrict
 extern "C" int gr_qkv_split(const void* qkv, void* q, void* k, void* vt, const float* cosT, const float* sinT, int B,
                             int H, int L, int head_dim, int pos0, int kv_stride, const int* pos_dev, int pos_stride,
                             hipStream_t stream) {
-  if (!qkv || !q || !k || !vt || B <= 0 || H <= 0 || L <= 0) return GR_EINVAL;
+  if (!qkv || !k || !vt || B <= 0 || H <= 0 || L <= 0) return GR_EINVAL;  // q may be NULL (left in qkv)
   if ((cosT == nullptr) != (sinT == nullptr)) return GR_EINVAL;
   dim3 grid(gr_cdiv(L, 64), H, B);
   if (head_dim == 128)

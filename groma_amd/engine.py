@@ -21,6 +21,7 @@ BF16, F32, I32, I64 = torch.bfloat16, torch.float32, torch.int32, torch.int64
 # loads and the transposed V stores sit in the lock-step epilogue where nothing overlaps them, while the separate split
 # kernel streams at ~4 TB/s.  Kept (tested) behind this switch; off by default.
 FUSED_QKV = False
+Q_IN_PLACE = True  # prefill attention reads q (and applies RoPE) straight from the fused QKV projection
 
 
 def _ru(x, m):
@@ -99,8 +100,12 @@ class VitEngine:
                 lin(h, L["ln1_g"], L["ln1_b"], L["wqkv"], bias=L["bqkv"], qkv=dict(q=q, k=k, vt=vt, H=H, hd=hd, L=T))
             else:
                 qkv = lin(h, L["ln1_g"], L["ln1_b"], L["wqkv"], bias=L["bqkv"], out=ws.get("vit_qkv", (M, 3 * D), BF16))
-                ops.qkv_split(qkv, q, k, vt, B=bs, H=H, L=T, hd=hd)
-            ctx = ops.attention(q, k, vt, Skv=T, causal=False, out=ws.get("vit_ctx", (M, D), BF16))
+                ops.qkv_split(qkv, None if Q_IN_PLACE else q, k, vt, B=bs, H=H, L=T, hd=hd)
+            if Q_IN_PLACE and not fused_qkv:  # attention reads q straight from the fused projection
+                ctx = ops.attention(qkv, k, vt, Skv=T, causal=False, out=ws.get("vit_ctx", (M, D), BF16),
+                                    fused=dict(B=bs, H=H, Lq=T, hd=hd))
+            else:
+                ctx = ops.attention(q, k, vt, Skv=T, causal=False, out=ws.get("vit_ctx", (M, D), BF16))
             lin_bf16(ctx, L["wo"], bias=L["bo"], scale=L["ls1"], resid=h, out=mid, out_f32=True)
             y = lin(mid, L["ln2_g"], L["ln2_b"], L["w1"], bias=L["b1"], act=1,
                     out=ws.get("vit_y", (M, L["w1"][0].shape[0]), BF16))
@@ -347,10 +352,15 @@ class LlamaEngine:
                                                        L=L, pos0=past))
             else:
                 qkv = lin(h, Lw["n1"], Lw["wqkv"], out=ws.get("llm_qkv", (M, 3 * T), BF16))
-                ops.qkv_split(qkv, q, cache.k[i], cache.vt[i], B=bs, H=H, L=L, hd=hd, pos0=past, cos=w["cos"], sin=w["sin"],
-                              pos_dev=pos_dev, pos_stride=pos_stride)
-            ctx = ops.attention(q, cache.k[i], cache.vt[i], Skv=cache.smax if dyn else past + L, causal=True, q_pos0=past,
-                                kv_len=kv_len, out=ws.get("llm_ctx", (M, T), BF16), pos_dev=pos_dev, pos_stride=pos_stride)
+                ops.qkv_split(qkv, None if Q_IN_PLACE else q, cache.k[i], cache.vt[i], B=bs, H=H, L=L, hd=hd, pos0=past,
+                              cos=w["cos"], sin=w["sin"], pos_dev=pos_dev, pos_stride=pos_stride)
+            att_kw = dict(Skv=cache.smax if dyn else past + L, causal=True, q_pos0=past, kv_len=kv_len,
+                          out=ws.get("llm_ctx", (M, T), BF16), pos_dev=pos_dev, pos_stride=pos_stride)
+            if Q_IN_PLACE and not fused_qkv:  # q is read (and rotated) in place: no packed q copy, no round trip
+                ctx = ops.attention(qkv, cache.k[i], cache.vt[i], fused=dict(B=bs, H=H, Lq=L, hd=hd, cos=w["cos"], sin=w["sin"]),
+                                    **att_kw)
+            else:
+                ctx = ops.attention(q, cache.k[i], cache.vt[i], **att_kw)
             lin_bf16(ctx, Lw["wo"], resid=h, out=h, out_f32=True)
             y = lin(h, Lw["n2"], Lw["wgu"], act=3, out=ws.get("llm_y", (M, self.I), BF16))
             lin_bf16(y, Lw["wd"], resid=h, out=h, out_f32=True)

@@ -224,12 +224,18 @@ def rmsnorm(x, gamma, eps, *, out_bf16=True, out=None):
     return out
 
 
-def attention(q, k, vt, *, Skv, causal, q_pos0=0, kv_len=None, scale=None, out=None, pos_dev=None, pos_stride=0):
+def attention(q, k, vt, *, Skv, causal, q_pos0=0, kv_len=None, scale=None, out=None, pos_dev=None, pos_stride=0,
+              fused=None):
     """q [B,H,Lq,hd]; k [B,H,kv_stride,hd]; vt [B,H,hd,kv_stride] -> [B*Lq, H*hd].
     pos_dev (i32 device tensor): row b attends keys [0, pos_dev[b*pos_stride] + Lq) -- device-resident decode position."""
     lib = _lib.load()
     _chk(q, BF16, "q"); _chk(k, BF16, "k"); _chk(vt, BF16, "vt")
-    B, H, Lq, hd = q.shape
+    q_ld, cos, sin = 0, None, None
+    if fused is not None:  # q = the fused projection buffer [B*Lq, ld]; fused = dict(B, H, Lq, hd, cos=None, sin=None)
+        B, H, Lq, hd = fused["B"], fused["H"], fused["Lq"], fused["hd"]
+        q_ld, cos, sin = q.shape[-1], fused.get("cos"), fused.get("sin")
+    else:
+        B, H, Lq, hd = q.shape
     kv_stride = k.shape[2]
     if scale is None:
         scale = hd ** -0.5
@@ -240,11 +246,13 @@ def attention(q, k, vt, *, Skv, causal, q_pos0=0, kv_len=None, scale=None, out=N
     if pos_dev is not None:
         _chk(pos_dev, I32, "pos_dev")
     _lib.check(lib.gr_attention_bf16(_p(q), _p(k), _p(vt), _p(out), _p(kv_len), B, H, Lq, Skv, kv_stride, hd,
-                                     int(causal), q_pos0, scale, _p(pos_dev), pos_stride, _stream()), "gr_attention_bf16")
+                                     int(causal), q_pos0, scale, _p(pos_dev), pos_stride, q_ld, _p(cos), _p(sin), _stream()),
+               "gr_attention_bf16")
     return out
 
 
 def qkv_split(qkv, q, k, vt, *, B, H, L, hd, pos0=0, cos=None, sin=None, pos_dev=None, pos_stride=0):
+    """q=None: only k / v^T are written (attention(fused=...) reads q from qkv)"""
     lib = _lib.load()
     _chk(qkv, BF16, "qkv")
     if pos_dev is not None:

@@ -26,7 +26,7 @@ extern "C" {
 typedef struct ihipStream_t* hipStream_t;
 #endif
 
-#define GROMA_HIP_ABI_VERSION 3
+#define GROMA_HIP_ABI_VERSION 4
 int gr_abi_version(void);
 /* kernel timing hook used by bench.py: when enabled, every gr_gemm_bf16 launch is bracketed by HIP
  * events on its own stream; gr_prof_read drains them (sync) and returns total ms + launch count. */
@@ -111,10 +111,13 @@ int gr_rmsnorm(const float* x, const float* gamma, void* out, int rows, int C, l
  * key j visible to query i <=> j < Skv, j < kv_len[b] (if given), and (causal) j <= q_pos0 + i.  hd in {64,128}.
  * pos_dev (optional, device): q_pos0 of batch row b = pos_dev[b * pos_stride] and Skv = q_pos0 + Lq -- the step position
  * lives in device memory so a decode step can be captured once in a hipGraph and replayed (pos_stride 0 = one shared
- * counter, 1 = ragged per-row positions); Skv is then only the capacity bound that is validated. */
+ * counter, 1 = ragged per-row positions); Skv is then only the capacity bound that is validated.
+ * q_ld > 0: q points at the fused projection buffer [B*Lq, q_ld] (row b*Lq+i, columns h*hd + d) and is read in place;
+ * with rope_cos/rope_sin [pos, hd/2] HF rotate_half RoPE at position q_pos0 + i is applied while loading (the q copy
+ * and its round trip that gr_qkv_split would make disappear: pass q = NULL there). */
 int gr_attention_bf16(const void* q, const void* k, const void* vt, void* out, const int* kv_len, int B, int H, int Lq,
                       int Skv, int kv_stride, int head_dim, int causal, int q_pos0, float scale, const int* pos_dev,
-                      int pos_stride, hipStream_t stream);
+                      int pos_stride, long q_ld, const float* rope_cos, const float* rope_sin, hipStream_t stream);
 /* fused-QKV split (+ HF rotate_half RoPE when cos/sin given) into the layouts above / the KV cache */
 int gr_qkv_split(const void* qkv, void* q, void* k, void* vt, const float* cosT, const float* sinT, int B, int H, int L,
                  int head_dim, int pos0, int kv_stride, const int* pos_dev, int pos_stride, hipStream_t stream);

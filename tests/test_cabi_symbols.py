@@ -22,7 +22,7 @@ def test_header_symbols_are_exported_and_typed():
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/groma_hip.h but not exported"
     assert set(names) == set(_lib.SIGNATURES), "ctypes signature table out of sync with the header"
-    assert _lib.load().gr_abi_version() == 3
+    assert _lib.load().gr_abi_version() == 4
 
 
 def test_bad_arguments_are_rejected_without_a_gpu():
@@ -36,7 +36,7 @@ def test_bad_arguments_are_rejected_without_a_gpu():
     assert lib.gr_nms_f32(None, None, 1, 10, 0.5, 0.0, 10, None, None, None, None) == 22
     assert lib.gr_roi_align_pack(None, None, None, 0, 8, 4, 4, 14, 14, 1.0, 2, 1, 1, 0, None) == 0  # empty ROI set is fine
     assert lib.gr_roi_align_pack(None, None, None, 3, 8, 4, 4, 14, 14, 1.0, 2, 1, 1, 0, None) == 22
-    assert lib.gr_attention_bf16(None, None, None, None, None, 1, 1, 1, 1, 64, 64, 0, 0, 1.0, None, 0, None) == 22
+    assert lib.gr_attention_bf16(None, None, None, None, None, 1, 1, 1, 1, 64, 64, 0, 0, 1.0, None, 0, 0, None, None, None) == 22
     assert lib.gr_decode_attention(None, None, None, None, None, 1, 1, 1, 64, 64, 0, 1.0, None, 0, 1, None, None) == 22
     assert lib.gr_greedy_advance(None, None, None, None, None, None, None, 4, -1, 0, 8, 1, 1, None) == 22
 

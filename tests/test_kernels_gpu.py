@@ -551,3 +551,30 @@ def test_gemm_w128_variant_equals_pingpong(dev, M, N, K, kw):
             args["resid"] = rnd((M, N), dev, seed=4)
         outs.append(ops.gemm(a, w, tile=tile, **args).clone())
     assert torch.equal(outs[0], outs[1])
+
+
+@pytest.mark.parametrize("B,H,hd,L,rope,causal", [(2, 4, 128, 150, True, True), (3, 2, 64, 70, False, False), (2, 8, 64, 100, True, True)])
+def test_attention_reads_q_in_place(dev, B, H, hd, L, rope, causal):
+    """attention(fused=...) -- q read (and rotated) straight from the fused QKV buffer -- against the packed-q path
+    (gr_qkv_split writes q, attention reads it): same roundings in the same order -> equal up to fma contraction"""
+    ops = _ops()
+    T = H * hd
+    qkv = rnd((B * L, 3 * T), dev, seed=1).bfloat16()
+    stride = (L + 63) // 64 * 64
+    cos = sin = None
+    if rope:
+        inv = 1.0 / (10000 ** (torch.arange(0, hd, 2, device=dev).float() / hd))
+        fr = torch.outer(torch.arange(stride, device=dev).float(), inv)
+        cos, sin = fr.cos().contiguous(), fr.sin().contiguous()
+    q = torch.zeros((B, H, L, hd), dtype=torch.bfloat16, device=dev)
+    k = torch.zeros((B, H, stride, hd), dtype=torch.bfloat16, device=dev)
+    vt = torch.zeros((B, H, hd, stride), dtype=torch.bfloat16, device=dev)
+    ops.qkv_split(qkv, q, k, vt, B=B, H=H, L=L, hd=hd, cos=cos, sin=sin)
+    ref = ops.attention(q, k, vt, Skv=L, causal=causal)
+    k2, vt2 = torch.zeros_like(k), torch.zeros_like(vt)
+    ops.qkv_split(qkv, None, k2, vt2, B=B, H=H, L=L, hd=hd, cos=cos, sin=sin)  # q stays in the fused buffer
+    assert torch.equal(k2, k) and torch.equal(vt2, vt)
+    out = ops.attention(qkv, k2, vt2, Skv=L, causal=causal, fused=dict(B=B, H=H, Lq=L, hd=hd, cos=cos, sin=sin))
+    assert relerr(out, ref) < 2e-3
+    if not rope:
+        assert torch.equal(out, ref)
