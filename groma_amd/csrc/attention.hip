@@ -50,6 +50,10 @@ extern "C" int gr_diag_att_clk(unsigned long long* out) { return (int)hipMemcpyF
 #define ATT_MARK(i)
 #endif
 
+#ifndef ATT_G
+#define ATT_G (HD == 128 ? 8 : 2)  // K / V^T fragments per prefetch group (A/B: hd 128 -5 % with 8, hd 64 neutral)
+#endif
+
 template <int HD>
 __global__ __launch_bounds__(256, 2) void attention_kernel(AttnArgs p) {
   constexpr int KV = 64;
@@ -190,7 +194,7 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(AttnArgs p) {
       for (int j = 0; j < 4; ++j) s[u][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     // K fragments are read one group AHEAD of the MFMAs that use them (double buffer, GK fragments per group): the
     // LDS latency of the next group hides behind this group's MFMAs instead of stalling every MFMA pair
-    constexpr int GK = 2;                       // fragments per group (register budget: hd 128 sits at 256 VGPRs)
+    constexpr int GK = ATT_G;                   // fragments per group
     constexpr int NKG = 4 * (HD / 32) / GK;     // groups over (j, kk)
     bf16x8 kfr[2][GK];
     auto load_k = [&](int g, bf16x8* dst) {
@@ -274,7 +278,7 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(AttnArgs p) {
     ATT_MARK(3)
     // ---- O^T += Vt . P^T ; Vt fragments shared by the q-tiles
     // same for the V^T fragments: the next group's reads are issued before this group's MFMAs
-    constexpr int GV = 2;
+    constexpr int GV = ATT_G;
     constexpr int NG = 2 * (HD / 16) / GV;  // groups of GV (tt, n) steps
     bf16x8 vfr[2][GV];
     auto load_v = [&](int g, bf16x8* dst) {
