@@ -116,6 +116,9 @@ def main():
                     help="forward = the headline prefill metric (BASELINE configs[2]); generate = configs[3]: greedy decoding "
                          "of --new-tokens tokens per image at --batch images per GPU (use --batch 4), HBM-bound decode steps")
     ap.add_argument("--new-tokens", type=int, default=32)
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise the RCCL process group and run the per-step all-gather even with one rank (smoke test of "
+                         "the N>1 path on a 1-GPU box; launch under torch.distributed.run --nproc-per-node 1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--gemm-breakdown", default=None, help="write a per-shape GEMM table (from the HIP-event hook) here")
     args = ap.parse_args()
@@ -128,7 +131,8 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
@@ -144,29 +148,29 @@ def main():
     images, ids = synth.make_inputs(cfg, model, args.batch, seed=1234 + rank, prompt_len=P)
     images, ids = images.to(dev), ids.to(dev)
     r0 = model.box_idx_token_ids[0]
-    gathered = torch.empty((world * args.batch, 100), dtype=torch.float32, device=dev) if world > 1 else None
+    gathered = torch.empty((world * args.batch, 100), dtype=torch.float32, device=dev) if use_dist else None
 
     gen = args.mode == "generate"
     if gen:
         model.generation_config.eos_token_id = None  # random-init weights: fixed-length decode, never an early stop
-        gathered_ids = torch.empty((world * args.batch, P + args.new_tokens), dtype=torch.int64, device=dev) if world > 1 else None
+        gathered_ids = torch.empty((world * args.batch, P + args.new_tokens), dtype=torch.int64, device=dev) if use_dist else None
 
     def step(i):
         torch.manual_seed(1000 + i)  # the path draws torch.randperm (T4)
         if gen:
             seq = model.generate(ids, images=images, max_new_tokens=args.new_tokens)
-            if world > 1:
+            if use_dist:
                 dist.all_gather_into_tensor(gathered_ids, seq.contiguous())
             return seq
         logits, _ = model.forward(input_ids=ids, images=images, use_cache=False)
         region_logits = logits[:, -1, r0:r0 + 100].contiguous()
-        if world > 1:
+        if use_dist:
             dist.all_gather_into_tensor(gathered, region_logits)
         return region_logits
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -178,7 +182,7 @@ def main():
         step(args.warmup + i)
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -274,7 +278,7 @@ def main():
                 out["cpu_baseline"] = {"value": None, "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
                                        "sample": f"failed: {type(e).__name__}: {e}"}
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
