@@ -46,7 +46,10 @@ __device__ __forceinline__ void tile_of_block(int bid, int nwg, int tiles_m, int
   const int q = nwg >> 3, r = nwg & 7;
   const int xcd = bid & 7, idx = bid >> 3;
   int pid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-  const int GROUP = 8;
+#ifndef GR_TILE_GROUP
+#define GR_TILE_GROUP 8
+#endif
+  const int GROUP = GR_TILE_GROUP;
   const int per_group = GROUP * tiles_n;
   const int g = pid / per_group;
   const int first_m = g * GROUP;
