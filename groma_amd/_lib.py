@@ -30,8 +30,6 @@ class GemmDesc(ctypes.Structure):
         ("tile", c_int),
         ("fp8", c_int), ("a_scale", c_void_p), ("w_scale", c_void_p),
         ("a_parts", c_void_p), ("a_nsplit", c_int), ("a_hd", c_int),
-        ("qkv_q", c_void_p), ("qkv_k", c_void_p), ("qkv_vt", c_void_p), ("rope_cos", c_void_p), ("rope_sin", c_void_p),
-        ("qkv_H", c_int), ("qkv_hd", c_int), ("qkv_L", c_int), ("qkv_pos0", c_int), ("qkv_kv_stride", c_int),
     ]
 
 

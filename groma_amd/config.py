@@ -95,24 +95,58 @@ class GromaConfig(_Cfg):
 
     @classmethod
     def from_pretrained(cls, path):
+        """Reads the reference's config.json.  The reference writes the nested configs with `to_diff_dict()`
+        (groma/model/groma.py:72-83, ddetr.py:84-95), i.e. keys equal to the *HF class defaults* are omitted -- so
+        an absent key means the HF default (HF_DEFAULTS below), not this repo's Groma-7B default."""
         with open(os.path.join(path, "config.json")) as f:
             d = json.load(f)
-        known = dict(llm_cfg=d.pop("llm_cfg", None), perceiver_cfg=d.pop("perceiver_cfg", None),
-                     region_cfg=d.pop("region_cfg", None))
-        d.pop("vocab_size", None)
+        pc = d.get("perceiver_cfg") or {}
+        llm = _from_hf_dict(LlamaConfig, d.get("llm_cfg"), "llm_cfg")
+        vis = _from_hf_dict(Dinov2Config, pc.get("vis_encoder_cfg"), "vis_encoder_cfg")
+        det = _from_hf_dict(DeformableDetrConfig, pc.get("ddetr_cfg"), "ddetr_cfg")
         keep = {k: d[k] for k in ("num_new_token", "nms_thres", "box_score_thres", "max_region_num", "image_size")
                 if k in d}
-        # tolerate the many bookkeeping keys HF writes into config.json
-        for sub in ("llm_cfg",):
-            if isinstance(known[sub], dict):
-                known[sub] = {k: v for k, v in known[sub].items() if k in LlamaConfig._defaults}
-        if isinstance(known["perceiver_cfg"], dict):
-            pc = known["perceiver_cfg"]
-            known["perceiver_cfg"] = dict(
-                vis_encoder_cfg={k: v for k, v in (pc.get("vis_encoder_cfg") or {}).items() if k in Dinov2Config._defaults},
-                ddetr_cfg={k: v for k, v in (pc.get("ddetr_cfg") or {}).items() if k in DeformableDetrConfig._defaults},
-                vis_output_layer=pc.get("vis_output_layer", -1), zs_weight_path=pc.get("zs_weight_path"))
-        return cls(**known, **keep)
+        per = dict(vis_encoder_cfg=vis, ddetr_cfg=det, vis_output_layer=pc.get("vis_output_layer", -1),
+                   zs_weight_path=pc.get("zs_weight_path"))
+        return cls(llm_cfg=llm, perceiver_cfg=per, region_cfg=d.get("region_cfg"), **keep)
+
+
+# transformers==4.32.0 class defaults of the keys this path reads (what `to_diff_dict()` leaves out of config.json).
+HF_DEFAULTS = {
+    "llm_cfg": dict(vocab_size=32000, hidden_size=4096, intermediate_size=11008, num_hidden_layers=32,
+                    num_attention_heads=32, rms_norm_eps=1e-6, max_position_embeddings=2048, rope_theta=10000.0,
+                    bos_token_id=1, eos_token_id=2, pad_token_id=None),
+    "vis_encoder_cfg": dict(hidden_size=768, num_hidden_layers=12, num_attention_heads=12, mlp_ratio=4, patch_size=16,
+                            image_size=224, layer_norm_eps=1e-6, layerscale_value=1.0, qkv_bias=True, num_channels=3),
+    "ddetr_cfg": dict(d_model=256, encoder_layers=6, decoder_layers=6, encoder_attention_heads=8,
+                      decoder_attention_heads=8, encoder_ffn_dim=1024, decoder_ffn_dim=1024, num_feature_levels=4,
+                      encoder_n_points=4, decoder_n_points=4, num_queries=300, two_stage_num_proposals=300,
+                      two_stage=False, with_box_refine=False, num_labels=2, activation_function="relu"),
+}
+# keys that change the arithmetic but have no implementation here: refuse instead of silently running another model
+_UNSUPPORTED = {
+    "llm_cfg": dict(hidden_act="silu", rope_scaling=None, attention_bias=False, pretraining_tp=1),
+    "vis_encoder_cfg": dict(use_swiglu_ffn=False, hidden_act="gelu"),
+    "ddetr_cfg": dict(position_embedding_type="sine", activation_function="relu"),
+}
+
+
+def _from_hf_dict(cls, sub, which):
+    sub = dict(sub or {})
+    for k, want in _UNSUPPORTED[which].items():
+        if k in sub and sub[k] != want:
+            raise NotImplementedError(f"{which}.{k}={sub[k]!r} is not implemented on the MI355X path (only {want!r})")
+    if which == "llm_cfg":
+        kv = sub.get("num_key_value_heads")
+        heads = sub.get("num_attention_heads", HF_DEFAULTS[which]["num_attention_heads"])
+        if kv is not None and kv != heads:
+            raise NotImplementedError(f"grouped-query attention (num_key_value_heads={kv} != {heads}) is not implemented")
+    if which == "ddetr_cfg" and "num_labels" not in sub and isinstance(sub.get("id2label"), dict):
+        sub["num_labels"] = len(sub["id2label"])  # how PretrainedConfig serialises num_labels
+    out = {}
+    for k in cls._defaults:
+        out[k] = sub[k] if k in sub else HF_DEFAULTS[which][k]
+    return out
 
 
 # ---- named configurations -------------------------------------------------------------------------------

@@ -11,8 +11,6 @@ SOURCES = {
     "gemm_bf16_256.hip": [],
     "gemv_bf16.hip": [],
     "gemm_fp8_256.hip": [],
-    "gemm_qkv_256.hip": [],
-    "gemm_bf16_w128.hip": [],
     "fp8.hip": [],
     "gemm_f32.hip": [],
     "attention.hip": [],

@@ -22,7 +22,6 @@
 // time of one 256^2 K-step on a CU relative to one 128^2 K-step of two co-resident blocks (4x the MACs of one
 // block = 2x the work per CU-interval, executed ~1.45x faster per flop)
 #define G256_COST 1.41
-#define W128_DEFAULT 0
 #include <stdlib.h>
 
 __global__ __launch_bounds__(NTHREADS) void gemm_bf16_kernel(GemmArgs p) {
@@ -215,7 +214,7 @@ extern "C" int gr_prof_read_launches(long cap, int* mnk, float* ms, long* n_out)
 }
 
 extern "C" int gr_gemm_bf16(const gr_gemm_desc* d, hipStream_t stream) {
-  if (!d || (!d->A && !d->a_parts) || !d->W || (!d->C && d->tile != 2 && d->act != 4)) return GR_EINVAL;
+  if (!d || (!d->A && !d->a_parts) || !d->W || (!d->C && d->tile != 2)) return GR_EINVAL;
   if (d->a_parts && ((d->tile != 1 && d->tile != 2) || d->a_nsplit < 1 || d->a_hd < 8 || d->a_hd % 8 != 0 || d->K % d->a_hd != 0))
     return GR_EINVAL;
   if (d->M <= 0 || d->N <= 0 || d->K <= 0) return GR_EINVAL;
@@ -225,13 +224,7 @@ extern "C" int gr_gemm_bf16(const gr_gemm_desc* d, hipStream_t stream) {
   const int splits = d->splits > 1 ? d->splits : 1;
   if (splits > 1 && !d->ws) return GR_EINVAL;
   if (d->act == 3 && (d->resid || d->scale || d->out_f32)) return GR_EINVAL;
-  if (d->act == 4) {  // fused-QKV epilogue: whole heads per 256-wide tile, 256x256 kernel, plain A
-    if (!d->qkv_q || !d->qkv_k || !d->qkv_vt || d->qkv_H <= 0 || d->qkv_hd <= 0 || d->qkv_hd % 16 != 0 || 256 % d->qkv_hd != 0 ||
-        (d->qkv_H * d->qkv_hd) % 256 != 0 || d->N != 3 * d->qkv_H * d->qkv_hd || d->qkv_L <= 0 || d->M % d->qkv_L != 0 ||
-        d->qkv_pos0 < 0 || d->qkv_pos0 + d->qkv_L > d->qkv_kv_stride || (d->rope_cos == nullptr) != (d->rope_sin == nullptr) ||
-        d->resid || d->scale || d->out_f32 || splits > 1 || d->conv_C > 0 || d->tile == 1 || d->tile == 2 || d->tile == 128 || d->fp8)
-      return GR_EINVAL;
-  }
+  if (d->act < 0 || d->act > 3) return GR_EINVAL;
   GemmArgs p;
   p.A = (const bf16_t*)d->A;
   p.W = (const bf16_t*)d->W;
@@ -243,9 +236,6 @@ extern "C" int gr_gemm_bf16(const gr_gemm_desc* d, hipStream_t stream) {
   p.w_scale = d->fp8 ? d->w_scale : nullptr;
   p.ws = d->ws;
   p.a_parts = d->a_parts; p.a_nsplit = d->a_nsplit; p.a_hd = d->a_hd;
-  p.qkv_q = (bf16_t*)d->qkv_q; p.qkv_k = (bf16_t*)d->qkv_k; p.qkv_vt = (bf16_t*)d->qkv_vt;
-  p.rope_cos = d->rope_cos; p.rope_sin = d->rope_sin;
-  p.qkv_H = d->qkv_H; p.qkv_hd = d->qkv_hd; p.qkv_L = d->qkv_L; p.qkv_pos0 = d->qkv_pos0; p.qkv_kvs = d->qkv_kv_stride;
   p.M = d->M; p.N = d->N; p.K = d->K;
   p.lda = d->lda; p.ldw = d->ldw; p.ldc = d->ldc; p.ldr = d->ldr;
   p.act = d->act; p.out_f32 = d->out_f32; p.splits = splits;
@@ -259,7 +249,7 @@ extern "C" int gr_gemm_bf16(const gr_gemm_desc* d, hipStream_t stream) {
   const bool gemv = d->tile == 1 || d->tile == 2;  // decode-step shape: weights streamed once, no MFMA (gemv_bf16.hip)
   const bool partials_only = d->tile == 2;         // the caller's next kernel consumes ws[splits, M, N] (decode.hip)
   if (gemv && (p.M > 8 || p.conv_C > 0 || splits != gr_cdiv(p.K, 512) || !p.ws)) return GR_EINVAL;
-  if (d->tile == 256 || d->tile == 257 || d->fp8 || d->act == 4) use256 = true;  // fp8 and the fused-QKV epilogue exist for the 256x256 kernel only
+  if (d->tile == 256 || d->fp8) use256 = true;  // fp8 exists for the 256x256 kernel only
   else if (d->tile == 0) {
     const long t128 = (long)gr_cdiv(p.M, 128) * gr_cdiv(p.N, 128), t256 = (long)gr_cdiv(p.M, 256) * gr_cdiv(p.N, 256);
     const double ksteps = (double)(p.K / 64) / splits;
@@ -290,10 +280,7 @@ extern "C" int gr_gemm_bf16(const gr_gemm_desc* d, hipStream_t stream) {
     const int rc = gr_launch_gemv(p, stream);
     if (rc != GR_OK) return rc;
   } else if (use256) {
-    static int w128 = -1;  // GROMA_W128=1: plain bf16 GEMMs of the 256x256 class go to the one-wave-per-SIMD kernel
-    if (w128 < 0) { const char* e = getenv("GROMA_W128"); w128 = e ? atoi(e) : W128_DEFAULT; }
-    const bool use_w128 = (d->tile == 257 || (w128 && d->tile != 256)) && !d->fp8 && d->act != 4 && p.conv_C == 0;
-    const int rc = use_w128 ? gr_launch_gemm_w128(p, stream) : d->act == 4 ? gr_launch_gemm256_qkv(p, stream) : d->fp8 ? gr_launch_gemm256_fp8(p, stream) : gr_launch_gemm256(p, stream);
+    const int rc = d->fp8 ? gr_launch_gemm256_fp8(p, stream) : gr_launch_gemm256(p, stream);
     if (rc != GR_OK) return rc;
   } else {
     hipLaunchKernelGGL(gemm_bf16_kernel, grid, dim3(NTHREADS), 65536, stream, p);

@@ -8,7 +8,7 @@
 //  * the two wave groups (wm = 0 / 1) that share each SIMD run one barrier interval apart: while one group issues
 //    the 32 MFMAs of a phase, the other does its LDS fragment reads and global->LDS DMA issue, then they swap.  The
 //    partner's MFMAs hide every non-MFMA issue slot (an LDS-DMA issue alone costs ~60 clk) -- the one-wave-per-SIMD
-//    variant gemm_bf16_w128.hip shows what those cost when nothing hides them;
+//    (a one-wave-per-SIMD variant measured what those cost when nothing hides them: DESIGN.md 3a);
 //  * two phases per 64-deep K-tile:  X: A0 x (B0,B1) -> acc[0..3][*]   Y: A1 x (B0,B1) -> acc[4..7][*].  The B
 //    fragments stay in registers across both; A0's registers are reused for A1.  (Round 1 started with four 16-MFMA
 //    quadrant phases; each phase boundary costs a barrier round trip on the matrix pipe, halving them: +3.3 % e2e.)
@@ -49,14 +49,6 @@ __device__ __forceinline__ f32x4 mfma_fp8x2(bf16x8 a, bf16x8 b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(ua.h[1], ub.h[1], c, 0, 0, 0);
 }
 #define MFMA16(a, b, c) mfma_fp8x2(a, b, c)
-#elif defined(G256_QKV)
-// a separate kernel for the fused-QKV epilogue: its extra code (partner-column reads, cos/sin, transposed V stores)
-// must not cost the plain kernel registers -- compiled into the same kernel it pushed SGPRs to scratch and slowed
-// EVERY GEMM by 20-30 %
-#define G256_KERNEL gemm_bf16_256_qkv_kernel
-#define G256_LAUNCH gr_launch_gemm256_qkv
-#define ESZ 2
-#define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0)
 #else
 #define G256_KERNEL gemm_bf16_256_kernel
 #define G256_LAUNCH gr_launch_gemm256
@@ -67,7 +59,7 @@ __device__ __forceinline__ f32x4 mfma_fp8x2(bf16x8 a, bf16x8 b, f32x4 c) {
 // (v_mfma_f32_32x32x16_bf16 was tried in place of 16x16x32 -- 1.22 vs 1.42 PF at 8192^3 -- and removed.)
 #define LDS_SWZ(row) ((row) & 7)
 
-#if defined(G256_CLK) && !G256_FP8 && !defined(G256_QKV)  // diagnostic build only (tests/diag/build_clk.py): shader/wall clocks of block 0 at start, loop end, exit
+#if defined(G256_CLK) && !G256_FP8  // diagnostic build only (tests/diag/build_clk.py): shader/wall clocks of block 0 at start, loop end, exit
 __device__ unsigned long long g256_clk[40];
 extern "C" int gr_diag_clk(unsigned long long* out) {
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g256_clk), sizeof(g256_clk));
@@ -273,9 +265,6 @@ __global__ __launch_bounds__(NT) void G256_KERNEL(GemmArgs p) {
   EpiCols<4> ec4;
   EpiCols<2> ec2;
   EpiCols<1> ec1;
-#ifdef G256_QKV
-  const int qkv_which = n0 / (p.qkv_H * p.qkv_hd);  // tile-uniform: 0 = q, 1 = k, 2 = v
-#endif
   if (p.act == 3) ec4.load(p, n0 + (tid & 15) * 16);
   else if (!p.out_f32 && p.splits == 1) ec2.load(p, n0 + (tid & 31) * 8);
   else ec1.load(p, n0 + (tid & 63) * 4);
@@ -289,27 +278,9 @@ __global__ __launch_bounds__(NT) void G256_KERNEL(GemmArgs p) {
     __syncthreads();
     CLK_MARK(3 + 2 * q)
     // staged row sr -> tile row (sr>>5)*128 + q*32 + (sr&31)
-#ifdef G256_QKV
-    {
-      if (qkv_which < 2) {
-#pragma unroll
-        for (int it = 0; it < 4; ++it) {
-          const int idx = it * NT + tid, sr = idx >> 5;
-          epi_qk_from_stage<T256>(p, buf, sr, (idx & 31) * 2, m0 + (sr >> 5) * 128 + q * 32 + (sr & 31), n0, qkv_which, ec2);
-        }
-      } else {
-#pragma unroll
-        for (int it = 0; it < 4; ++it) {
-          const int idx = it * NT + tid, sr0 = (idx >> 8) * 8;  // 8 consecutive staged rows = 8 consecutive tokens
-          epi_v_from_stage<T256>(p, buf, sr0, idx & 255, m0 + (sr0 >> 5) * 128 + q * 32 + (sr0 & 31), n0);
-        }
-      }
-    }
-#else
     // staged row sr of this pass -> tile row (sr>>5)*128 + q*32 + (sr&31)
     epi_dispatch<T256, NT, 64, (G256_FP8 != 0)>(p, buf, tid, n0, z, ec4, ec2, ec1, [](int sr) { return sr; },
                                [&](int sr) { return m0 + (sr >> 5) * 128 + q * 32 + (sr & 31); });
-#endif
     CLK_MARK(4 + 2 * q)
   }
   CLK_MARK(2)

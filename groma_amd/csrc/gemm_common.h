@@ -20,14 +20,6 @@ struct GemmArgs {
   const float* a_scale;  // fp8 path: per-row dequantisation scale of A [M] (or null)
   const float* w_scale;  // fp8 path: per-output-channel scale of W [N] (or null)
   float* ws;
-  // act == 4 (256x256 kernel only): the fused-QKV projection is split, rotated and written to q / the KV cache by the
-  // epilogue (no [M, 3*H*hd] round trip through HBM); layouts of gr_qkv_split
-  bf16_t* qkv_q;
-  bf16_t* qkv_k;
-  bf16_t* qkv_vt;
-  const float* rope_cos;
-  const float* rope_sin;
-  int qkv_H, qkv_hd, qkv_L, qkv_pos0, qkv_kvs;
   const float* a_parts;  // decode GEMV only: A given as un-merged single-query attention slices (decode.hip), or null
   int a_nsplit, a_hd;
   int M, N, K;
@@ -387,85 +379,9 @@ __device__ __forceinline__ void epi_dispatch(const GemmArgs& p, const char* base
   }
 }
 
-// ---- act == 4: fused-QKV epilogue (q / k path).  One thread = 8 consecutive columns (one 16-B bf16 store) of one
-// staged row.  The projection is rounded to bf16 FIRST -- exactly what the unfused path stores before gr_qkv_split
-// reads it back -- then HF rotate_half RoPE in f32 with the partner columns taken from the same LDS image.
-template <int COLS>
-__device__ __forceinline__ void epi_qk_from_stage(const GemmArgs& p, const char* base, int srow, int c4, int m, int n0,
-                                                  int which, const EpiCols<2>& ec) {
-  if (m >= p.M) return;
-  const int hd = p.qkv_hd, HD = p.qkv_H * hd;
-  const int nn = n0 + c4 * 4 - which * HD;
-  const int head = nn / hd, d = nn - head * hd;
-  const float as = (p.w_scale && p.a_scale) ? p.a_scale[m] : 1.f;
-  auto rbf = [](f32x4 v) { return (f32x4){bf2f(f2bf(v[0])), bf2f(f2bf(v[1])), bf2f(f2bf(v[2])), bf2f(f2bf(v[3]))}; };
-  f32x4 x0 = stage_read4<COLS>(base, srow, c4), x1 = stage_read4<COLS>(base, srow, c4 + 1);
-  if (p.w_scale) { x0 = x0 * ec.wsc[0] * as; x1 = x1 * ec.wsc[1] * as; }
-  x0 = rbf(x0 + ec.bias[0]);
-  x1 = rbf(x1 + ec.bias[1]);
-  const int b = m / p.qkv_L, t = m - b * p.qkv_L;
-  const int pos = p.qkv_pos0 + t;
-  if (p.rope_cos) {
-    const int half = hd >> 1;
-    const bool lo = d < half;
-    const int dpc4 = lo ? c4 + (half >> 2) : c4 - (half >> 2);
-    const int np = n0 + dpc4 * 4;
-    f32x4 y0 = stage_read4<COLS>(base, srow, dpc4), y1 = stage_read4<COLS>(base, srow, dpc4 + 1);
-    if (p.w_scale) { y0 = y0 * *(const f32x4*)(p.w_scale + np) * as; y1 = y1 * *(const f32x4*)(p.w_scale + np + 4) * as; }
-    if (p.bias) { y0 += *(const f32x4*)(p.bias + np); y1 += *(const f32x4*)(p.bias + np + 4); }
-    y0 = rbf(y0);
-    y1 = rbf(y1);
-    const int dc = lo ? d : d - half;
-    const float sgn = lo ? -1.f : 1.f;
-    const float* cp = p.rope_cos + (long)pos * half + dc;
-    const float* sp = p.rope_sin + (long)pos * half + dc;
-    const f32x4 c0 = *(const f32x4*)cp, c1 = *(const f32x4*)(cp + 4), s0 = *(const f32x4*)sp, s1 = *(const f32x4*)(sp + 4);
-    x0 = x0 * c0 + sgn * y0 * s0;
-    x1 = x1 * c1 + sgn * y1 * s1;
-  }
-  bf16_t* dst = which == 0 ? p.qkv_q + (((long)b * p.qkv_H + head) * p.qkv_L + t) * hd + d
-                           : p.qkv_k + (((long)b * p.qkv_H + head) * p.qkv_kvs + pos) * hd + d;
-  *(uint4*)dst = make_uint4(pack2bf(x0[0], x0[1]), pack2bf(x0[2], x0[3]), pack2bf(x1[0], x1[1]), pack2bf(x1[2], x1[3]));
-}
-// V path: one thread = one column x 8 consecutive staged rows (= 8 consecutive tokens) -> 16 B of the TRANSPOSED cache
-template <int COLS>
-__device__ __forceinline__ void epi_v_from_stage(const GemmArgs& p, const char* base, int srow0, int c, int m_first, int n0) {
-  if (m_first >= p.M) return;
-  const int hd = p.qkv_hd, HD = p.qkv_H * hd;
-  const int n = n0 + c, nn = n - 2 * HD;
-  const int head = nn / hd, d = nn - head * hd;
-  const float bias = p.bias ? p.bias[n] : 0.f;
-  const float wsc = p.w_scale ? p.w_scale[n] : 1.f;
-  float o[8];  // (kept as f32 registers: sub-dword local arrays end up in scratch)
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int row = srow0 + i;
-    float v = *(const float*)(base + ((long)row * COLS * 4) + ((((c >> 2) ^ (row & 7))) << 4) + ((c & 3) << 2));
-    if (p.w_scale) v = v * wsc * ((p.a_scale && m_first + i < p.M) ? p.a_scale[m_first + i] : 1.f);
-    o[i] = v + bias;
-  }
-  const int b = m_first / p.qkv_L, t = m_first - b * p.qkv_L;
-  bf16_t* row0 = p.qkv_vt + (((long)b * p.qkv_H + head) * hd + d) * p.qkv_kvs + p.qkv_pos0 + t;
-  if (t + 8 <= p.qkv_L && m_first + 8 <= p.M && (((p.qkv_pos0 + t) & 7) == 0)) {
-    *(uint4*)row0 = make_uint4(pack2bf(o[0], o[1]), pack2bf(o[2], o[3]), pack2bf(o[4], o[5]), pack2bf(o[6], o[7]));
-  } else {
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int m = m_first + i;
-      if (m < p.M) {
-        const int bi = m / p.qkv_L, ti = m - bi * p.qkv_L;
-        p.qkv_vt[(((long)bi * p.qkv_H + head) * hd + d) * p.qkv_kvs + p.qkv_pos0 + ti] = f2bf(o[i]);
-      }
-    }
-  }
-}
 // skinny M<=8 streaming kernel (gemv_bf16.hip): requires p.splits == ceil(K/512) and p.ws
 int gr_launch_gemv(const GemmArgs& p, hipStream_t stream);
 // 256x256x64 ping-pong kernel (gemm_bf16_256.hip)
 int gr_launch_gemm256(const GemmArgs& p, hipStream_t stream);
-// one-wave-per-SIMD 256x256 kernel (gemm_bf16_w128.hip): plain bf16 GEMM only
-int gr_launch_gemm_w128(const GemmArgs& p, hipStream_t stream);
-// the same kernel compiled with the fused-QKV epilogue (gemm_qkv_256.hip): act == 4 only
-int gr_launch_gemm256_qkv(const GemmArgs& p, hipStream_t stream);
 // OCP-fp8 build of the same kernel (gemm_fp8_256.hip); A/W are e4m3 bytes, K % 128 == 0
 int gr_launch_gemm256_fp8(const GemmArgs& p, hipStream_t stream);

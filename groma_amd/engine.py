@@ -16,11 +16,6 @@ from . import ops
 BF16, F32, I32, I64 = torch.bfloat16, torch.float32, torch.int32, torch.int64
 
 
-# QKV GEMMs can split / rotate / write the cache in their epilogue (gr_gemm_desc.act = 4, gemm_qkv_256.hip).  Measured
-# SLOWER on MI355X (LLaMA QKV 885 us fused vs 621 us GEMM + 99 us gr_qkv_split at 14 img/GPU): the rotation's cos/sin
-# loads and the transposed V stores sit in the lock-step epilogue where nothing overlaps them, while the separate split
-# kernel streams at ~4 TB/s.  Kept (tested) behind this switch; off by default.
-FUSED_QKV = False
 Q_IN_PLACE = True  # prefill attention reads q (and applies RoPE) straight from the fused QKV projection
 
 
@@ -29,18 +24,46 @@ def _ru(x, m):
 
 
 class Workspace:
-    """Shape-keyed scratch buffers (allocated once, reused across forwards; zero-filled on first use)."""
+    """Scratch arenas, one per buffer NAME, grown geometrically and handed out as a view of the first prod(shape)
+    elements -- so ragged request shapes (L = P + 256 + 2*N_regions changes with every image, R = sum N_i) do not
+    each pin their own permanent set of buffers (HBM would grow without bound in an eval / serving loop).
+
+    zero=True: the consumer relies on untouched elements being zero (the 1-pixel borders of the 3x3-conv inputs, the
+    64-key padding of the ViT K / V^T tiles).  A fresh arena is zero-filled; when the requested shape changes the view is
+    cleared again (one memset per shape change, none in steady state).
+    exact=True: a dedicated tensor per (name, shape) that is never moved -- for buffers whose address is baked into a
+    captured hipGraph (the decode step)."""
 
     def __init__(self, device):
-        self.device, self._b = device, {}
+        self.device, self._arena, self._zshape, self._exact = device, {}, {}, {}
 
-    def get(self, name, shape, dtype):
-        key = (name, tuple(shape), dtype)
-        t = self._b.get(key)
-        if t is None:
-            t = torch.zeros(tuple(shape), dtype=dtype, device=self.device)
-            self._b[key] = t
-        return t
+    def get(self, name, shape, dtype, zero=False, exact=False):
+        shape = tuple(int(x) for x in shape)
+        if exact:
+            key = (name, shape, dtype)
+            t = self._exact.get(key)
+            if t is None:
+                t = self._exact[key] = torch.zeros(shape, dtype=dtype, device=self.device)
+            return t
+        n = math.prod(shape)
+        key = (name, dtype)
+        buf = self._arena.get(key)
+        if buf is None or buf.numel() < n:
+            if buf is not None:
+                torch.cuda.synchronize(self.device)  # the old arena may still be read on the side stream
+            cap = n if buf is None else max(n, buf.numel() * 3 // 2)
+            buf = self._arena[key] = torch.zeros((cap,), dtype=dtype, device=self.device)
+            self._zshape[key] = shape
+        view = buf[:n].view(shape)
+        if zero and self._zshape.get(key) != shape:
+            view.zero_()
+            self._zshape[key] = shape
+        elif not zero:
+            self._zshape[key] = None
+        return view
+
+    def nbytes(self):
+        return sum(t.numel() * t.element_size() for t in list(self._arena.values()) + list(self._exact.values()))
 
 
 # ------------------------------------------------------------------------------------------------ DINOv2
@@ -76,8 +99,8 @@ class VitEngine:
                  row_map=(G * G, T, 1))
         Tp = _ru(T, 64)
         q = ws.get("vit_q", (bs, H, T, hd), BF16)
-        k = ws.get("vit_k", (bs, H, Tp, hd), BF16)
-        vt = ws.get("vit_vt", (bs, H, hd, Tp), BF16)
+        k = ws.get("vit_k", (bs, H, Tp, hd), BF16, zero=True)
+        vt = ws.get("vit_vt", (bs, H, hd, Tp), BF16, zero=True)
         fp8 = w["fp8"]
 
         def lin(x_f32, ln_g, ln_b, wt, **kw):
@@ -94,14 +117,10 @@ class VitEngine:
                 return ops.gemm(x8, wt[0], a_scale=sx, w_scale=wt[1], **kw)
             return ops.gemm(x_bf16, wt[0], **kw)
 
-        fused_qkv = FUSED_QKV and not fp8 and D % 256 == 0 and 256 % hd == 0
         for i, L in enumerate(w["layers"]):
-            if fused_qkv:  # the QKV GEMM's epilogue writes q / k / v^T itself (no [M, 3D] round trip)
-                lin(h, L["ln1_g"], L["ln1_b"], L["wqkv"], bias=L["bqkv"], qkv=dict(q=q, k=k, vt=vt, H=H, hd=hd, L=T))
-            else:
-                qkv = lin(h, L["ln1_g"], L["ln1_b"], L["wqkv"], bias=L["bqkv"], out=ws.get("vit_qkv", (M, 3 * D), BF16))
-                ops.qkv_split(qkv, None if Q_IN_PLACE else q, k, vt, B=bs, H=H, L=T, hd=hd)
-            if Q_IN_PLACE and not fused_qkv:  # attention reads q straight from the fused projection
+            qkv = lin(h, L["ln1_g"], L["ln1_b"], L["wqkv"], bias=L["bqkv"], out=ws.get("vit_qkv", (M, 3 * D), BF16))
+            ops.qkv_split(qkv, None if Q_IN_PLACE else q, k, vt, B=bs, H=H, L=T, hd=hd)
+            if Q_IN_PLACE:  # attention reads q straight from the fused projection
                 ctx = ops.attention(qkv, k, vt, Skv=T, causal=False, out=ws.get("vit_ctx", (M, D), BF16),
                                     fused=dict(B=bs, H=H, Lq=T, hd=hd))
             else:
@@ -225,7 +244,7 @@ class RegionEngine:
             new_maps, new_coef = [], []
             for l in range(3):
                 top, dow = min(l + 1, 2), max(l - 1, 0)
-                pad = ws.get(f"reg_pad{l}", (bs, S[l] + 2, S[l] + 2, D), BF16)
+                pad = ws.get(f"reg_pad{l}", (bs, S[l] + 2, S[l] + 2, D), BF16, zero=True)
                 ops.fuse_shuffle((maps[l], sums[l], S[l]), (maps[top], sums[top], S[top]), (maps[dow], sums[dow], S[dow]),
                                  pad, imgs=bs, C=D, shuffle=True, pad=1)
                 out = ws.get(f"reg_conv{l}_{r & 1}", (bs * S[l] * S[l], D), BF16)
@@ -247,7 +266,7 @@ class RegionEngine:
         R = boxes.shape[0]
         P = rc.roi_size
         rois = torch.cat([img_idx[:, None], boxes * float(self.img)], dim=1).contiguous()  # (idx, "x1,y1,x2,y2") -- T1
-        tiles = ws.get("reg_tiles", (3, R, P + 2, P + 2, D), BF16)
+        tiles = ws.get("reg_tiles", (3, R, P + 2, P + 2, D), BF16, zero=True)
         for l in range(3):
             ops.roi_align_pack(feats[l], rois, tiles[l], C=D, H=S[l], W=S[l], ph=P, pw=P,
                                spatial_scale=1.0 / self.STRIDES[l], sampling_ratio=2, aligned=True, pad=1)
@@ -345,18 +364,13 @@ class LlamaEngine:
                 return ops.gemm(x8, wt[0], a_scale=sx, w_scale=wt[1], **kw)
             return ops.gemm(x_bf16, wt[0], **kw)
 
-        fused_qkv = FUSED_QKV and not fp8 and not dyn and M > 8 and T % 256 == 0 and 256 % hd == 0
         for i, Lw in enumerate(w["layers"]):
-            if fused_qkv:  # RoPE + split + KV-cache write in the QKV GEMM's epilogue
-                lin(h, Lw["n1"], Lw["wqkv"], qkv=dict(q=q, k=cache.k[i], vt=cache.vt[i], cos=w["cos"], sin=w["sin"], H=H, hd=hd,
-                                                       L=L, pos0=past))
-            else:
-                qkv = lin(h, Lw["n1"], Lw["wqkv"], out=ws.get("llm_qkv", (M, 3 * T), BF16))
-                ops.qkv_split(qkv, None if Q_IN_PLACE else q, cache.k[i], cache.vt[i], B=bs, H=H, L=L, hd=hd, pos0=past,
-                              cos=w["cos"], sin=w["sin"], pos_dev=pos_dev, pos_stride=pos_stride)
+            qkv = lin(h, Lw["n1"], Lw["wqkv"], out=ws.get("llm_qkv", (M, 3 * T), BF16))
+            ops.qkv_split(qkv, None if Q_IN_PLACE else q, cache.k[i], cache.vt[i], B=bs, H=H, L=L, hd=hd, pos0=past,
+                          cos=w["cos"], sin=w["sin"], pos_dev=pos_dev, pos_stride=pos_stride)
             att_kw = dict(Skv=cache.smax if dyn else past + L, causal=True, q_pos0=past, kv_len=kv_len,
                           out=ws.get("llm_ctx", (M, T), BF16), pos_dev=pos_dev, pos_stride=pos_stride)
-            if Q_IN_PLACE and not fused_qkv:  # q is read (and rotated) in place: no packed q copy, no round trip
+            if Q_IN_PLACE:  # q is read (and rotated) in place: no packed q copy, no round trip
                 ctx = ops.attention(qkv, cache.k[i], cache.vt[i], fused=dict(B=bs, H=H, Lq=L, hd=hd, cos=w["cos"], sin=w["sin"]),
                                     **att_kw)
             else:
@@ -371,7 +385,9 @@ class LlamaEngine:
             hn = hn.view(bs, L, T)[:, -1].contiguous()
             logits = ops.gemm(hn, w["head"], out_f32=True)
             return logits.view(bs, 1, self.Vpad)[:, :, : self.V], hn
-        logits = ops.gemm(hn, w["head"], out_f32=True, out=ws.get("llm_logits", (M, self.Vpad), F32))
+        # prefill logits are handed to the caller (GromaModel.forward returns them): a fresh tensor per call, never a
+        # recycled arena view (the caching allocator re-serves the block once the caller drops the previous result)
+        logits = ops.gemm(hn, w["head"], out_f32=True)
         return logits.view(bs, L, self.Vpad)[:, :, : self.V], hn
 
     def _decode_forward(self, h, bs, cache, kv_len, pos_dev, pos_stride, past):
@@ -379,10 +395,10 @@ class LlamaEngine:
         (csrc/decode.hip): 9 launches per layer instead of 13, and a one-block-per-(row, head) attention."""
         w, ws, T, H, hd = self.w, self.ws, self.T, self.H, self.hd
         dyn = pos_dev is not None
-        x = ws.get("dec_x", (bs, T), BF16)
-        q = ws.get("dec_q", (bs, H, 1, hd), BF16)
-        ctx = ws.get("dec_ctx", (bs, T), BF16)
-        y = ws.get("dec_y", (bs, self.I), BF16)
+        x = ws.get("dec_x", (bs, T), BF16, exact=True)
+        q = ws.get("dec_q", (bs, H, 1, hd), BF16, exact=True)
+        ctx = ws.get("dec_ctx", (bs, T), BF16, exact=True)
+        y = ws.get("dec_y", (bs, self.I), BF16, exact=True)
         part, splits = None, 0
         for i, Lw in enumerate(w["layers"]):
             ops.decode_reduce_norm(part, splits, h, Lw["n1"], x, self.eps)  # (+ previous layer's down-proj partials)
@@ -402,7 +418,7 @@ class LlamaEngine:
         if not dyn:
             cache.seq_len = past + 1
         ops.decode_reduce_norm(part, splits, h, w["norm"], x, self.eps)
-        logits = ops.gemm(x, w["head"], out_f32=True, out=ws.get("llm_logits", (bs, self.Vpad), F32))
+        logits = ops.gemm(x, w["head"], out_f32=True, out=ws.get("dec_logits", (bs, self.Vpad), F32, exact=True))
         return logits.view(bs, 1, self.Vpad)[:, :, : self.V], x
 
 
@@ -438,7 +454,7 @@ class GreedyDecoder:
         llm = self.llm
         ops.embed_gather(self.tok, llm.w["embed"], llm.w["new_embed"], out=self.h)
         llm.forward(self.h, self.bs, 1, self.cache, pos_dev=self.pos, pos_stride=0)
-        ops.argmax_rows(llm.ws.get("llm_logits", (self.bs, llm.Vpad), F32), llm.V, out=self.nxt)
+        ops.argmax_rows(llm.ws.get("dec_logits", (self.bs, llm.Vpad), F32, exact=True), llm.V, out=self.nxt)
         self._advance(1)
 
     def capture(self):

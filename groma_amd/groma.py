@@ -122,6 +122,10 @@ class GromaModel:
     def from_pretrained(cls, path, torch_dtype=None, device="cuda", **kw):
         """Reads a reference checkpoint directory: config.json + *.safetensors / pytorch_model*.bin shards with the
         reference's parameter names (groma/eval/eval_rec.py:69).  Weights are repacked to bf16 device layouts."""
+        if torch_dtype not in (None, "auto", torch.float32, torch.float16, torch.bfloat16):
+            raise NotImplementedError(f"torch_dtype={torch_dtype}: the MI355X path computes in bf16 (fp32 accumulate)")
+        # torch_dtype only states how the CALLER would have held the weights (fp32 in eval_rec.py:69, fp16 in run_groma.py):
+        # they are always repacked to bf16 GEMM operands + fp32 norms / biases / proposer
         for unsupported in ("load_in_8bit", "load_in_4bit", "quantization_config"):
             if kw.get(unsupported):
                 raise NotImplementedError(f"{unsupported} is not supported by the MI355X path (bf16 / fp32 only)")
@@ -139,13 +143,27 @@ class GromaModel:
             raise FileNotFoundError(f"no weight shards under {path}")
         return cls.from_state_dict(config, sd, device, fp8=bool(kw.get("fp8", False)))
 
+    def _same_device(self, device):
+        if device is None:
+            return
+        d = torch.device("cuda", device) if isinstance(device, int) else torch.device(device)
+        if d.type != "cuda" or (d.index is not None and self.device.index is not None and d.index != self.device.index):
+            raise NotImplementedError(f"weights were packed for {self.device}; load the model on the target device "
+                                      f"(from_pretrained(..., device=...)) instead of moving it to {d}")
+
     def cuda(self, device=None):
+        self._same_device(device)
         return self
 
     def eval(self):
         return self
 
     def to(self, *a, **k):
+        """Device moves are rejected (the packed weights live where they were loaded); dtype requests are ignored: the
+        path always computes with bf16 operands / fp32 accumulation and fp32 residual streams."""
+        for x in list(a) + [k.get("device")]:
+            if isinstance(x, (str, int, torch.device)):
+                self._same_device(x)
         return self
 
     def init_special_token_id(self, tokenizer):  # groma/model/groma.py:136-144
@@ -219,10 +237,13 @@ class GromaModel:
         for i in range(bs):
             nk = int(n_keep_h[i])
             if nk > 0:  # groma.py:273-276 -- torch.randperm on the CPU global RNG (T4)
-                if seeds is not None and seeds[i] is not None:  # serving: each request owns its shuffle seed
-                    torch.manual_seed(int(seeds[i]))
                 inds = keep_h[i, :nk]
-                inds = inds[torch.randperm(nk)]
+                if seeds is not None and seeds[i] is not None:
+                    # serving: each request owns its shuffle seed.  A local generator yields exactly what the global RNG
+                    # would after torch.manual_seed(seed), without reseeding the process-wide CPU / device generators
+                    inds = inds[torch.randperm(nk, generator=torch.Generator().manual_seed(int(seeds[i])))]
+                else:
+                    inds = inds[torch.randperm(nk)]
             else:       # groma.py:277-279
                 nv = Q + n_extra[i]
                 inds = torch.max(scores_all[i, :nv], dim=0).indices.reshape(1).cpu()
@@ -347,6 +368,8 @@ class GromaModel:
                                'image_features': image_features.view(bs, n_img_tok, -1),
                                'region_features': region_features}
                 aux["lengths"] = mask_h.sum(-1).tolist()  # expanded length of every row (right padding excluded)
+                aux["hidden4"] = hidden4  # the four ViT states the path consumed (arena views: valid until the next forward)
+                aux["input_ids"] = new_ids_h
                 self._last_aux = aux
             else:
                 cache = past_key_values
@@ -365,7 +388,14 @@ class GromaModel:
             lab = labels.to(dev)
             loss = torch.nn.functional.cross_entropy(logits[..., :-1, :].reshape(-1, self.config.vocab_size).float(),
                                                      lab[..., 1:].reshape(-1), ignore_index=IGNORE_INDEX)
-        hidden_states = (hn.view(bs, -1, hn.shape[-1]),) if output_hidden_states else None
+        # Everything returned is the caller's: decode-step logits and the final hidden state live in recycled scratch
+        # buffers internally, so the boundary hands out copies (KB-sized); `_last_logits_only` marks the internal
+        # generate() loop, which consumes the views immediately.
+        if past_key_values is not None and not _last_logits_only:
+            logits = logits.clone()
+        hidden_states = (hn.view(bs, -1, hn.shape[-1]).clone(),) if output_hidden_states else None
+        if not use_cache and past_key_values is None:
+            cache = None  # HF returns past_key_values=None without use_cache; the scratch KV buffer is recycled
         if not return_dict:
             output = (logits, cache)
             return (loss,) + output if loss is not None else output

@@ -46,9 +46,8 @@ def _gemv_ws(splits, M, N, device):
 
 def gemm(a, w, *, out=None, bias=None, scale=None, resid=None, act=0, out_f32=False, splits=1, ws=None,
          M=None, lda=None, conv=None, resid_mod=0, row_map=None, ldc=None, ldr=None, tile=0,
-         a_scale=None, w_scale=None, qkv=None):
-    """out[M,N] = epilogue(a[M,K] @ w[N,K]^T).  qkv=dict(q, k, vt, cos, sin, H, hd, L, pos0): the epilogue splits the fused
-    projection into q / the KV cache (+RoPE) instead of writing out (act 4).  `conv=(imgs,H,W,C,seg_stride)` switches A to the implicit
+         a_scale=None, w_scale=None):
+    """out[M,N] = epilogue(a[M,K] @ w[N,K]^T).  `conv=(imgs,H,W,C,seg_stride)` switches A to the implicit
     3x3 gather over zero-bordered NHWC maps (then M = imgs*H*W, K = w.shape[1])."""
     lib = _lib.load()
     fp8 = w.dtype == FP8
@@ -78,26 +77,19 @@ def gemm(a, w, *, out=None, bias=None, scale=None, resid=None, act=0, out_f32=Fa
         tile, splits = 1, (K + 511) // 512  # decode step: weight-streaming kernel + deterministic split-K reduce
         ws = _gemv_ws(splits, M, N, a.device)
     n_out = N // 2 if act == 3 else N
-    if qkv is not None:
-        act = 4
-        d.qkv_q, d.qkv_k, d.qkv_vt = qkv["q"].data_ptr(), qkv["k"].data_ptr(), qkv["vt"].data_ptr()
-        d.rope_cos = qkv["cos"].data_ptr() if qkv.get("cos") is not None else None
-        d.rope_sin = qkv["sin"].data_ptr() if qkv.get("sin") is not None else None
-        d.qkv_H, d.qkv_hd, d.qkv_L, d.qkv_pos0, d.qkv_kv_stride = qkv["H"], qkv["hd"], qkv["L"], qkv.get("pos0", 0), qkv["k"].shape[2]
-    elif out is None:
+    if out is None:
         out = torch.empty((M, n_out), dtype=F32 if out_f32 else BF16, device=a.device)
-    if out is not None:
-        _chk(out, F32 if out_f32 else BF16, "out")
+    _chk(out, F32 if out_f32 else BF16, "out")
     if splits > 1 and ws is None:
         ws = torch.empty((splits, M, N), dtype=F32, device=a.device)
-    d.A, d.W, d.C = a.data_ptr(), w.data_ptr(), (out.data_ptr() if out is not None else None)
+    d.A, d.W, d.C = a.data_ptr(), w.data_ptr(), out.data_ptr()
     d.bias = _chk(bias, F32, "bias").data_ptr() if bias is not None else None
     d.scale = _chk(scale, F32, "scale").data_ptr() if scale is not None else None
     d.resid = _chk(resid, F32, "resid").data_ptr() if resid is not None else None
     d.ws = ws.data_ptr() if ws is not None else None
     d.M, d.N, d.K = M, N, K
     d.ldw = w.stride(0)
-    d.ldc = ldc if ldc is not None else (out.shape[-1] if out is not None else N)
+    d.ldc = ldc if ldc is not None else out.shape[-1]
     d.ldr = ldr if ldr is not None else (resid.shape[-1] if resid is not None else 0)
     d.act, d.out_f32, d.splits = act, int(out_f32), splits
     d.resid_mod = resid_mod

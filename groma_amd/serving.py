@@ -145,7 +145,7 @@ class ContinuousBatcher:
         llm = self.llm
         ops.embed_gather(self.tok, llm.w["embed"], llm.w["new_embed"], out=self.h)
         llm.forward(self.h, self.rows, 1, self.arena, pos_dev=self.pos, pos_stride=1)
-        ops.argmax_rows(llm.ws.get("llm_logits", (self.rows, llm.Vpad), F32), llm.V, out=self.nxt)
+        ops.argmax_rows(llm.ws.get("dec_logits", (self.rows, llm.Vpad), F32, exact=True), llm.V, out=self.nxt)
         ops.greedy_advance(self.nxt, self.tok, self.occupied, self._seq, self.pos, self.step_ctr, self.n_live,
                            eos=None, pad=0, inc_pos=2)
 

@@ -49,7 +49,7 @@ typedef struct gr_gemm_desc {
   int M, N, K;        /* K % 64 == 0, N % 4 == 0                                                   */
   long lda, ldw, ldc, ldr;
   int act;            /* 0 none, 1 GELU(erf), 2 ReLU, 3 SwiGLU over interleaved (gate,up) rows of W:
-                         C is [M, N/2] bf16 = silu(gate)*up; 4 = fused-QKV split (+RoPE) epilogue, see qkv_*  */
+                         C is [M, N/2] bf16 = silu(gate)*up */
   int out_f32;        /* C element type                                                            */
   int splits;         /* split-K factor >= 1                                                       */
   /* implicit 3x3 / pad 1 convolution gather for A (conv_C > 0): row m = output pixel (img,y,x) of
@@ -60,8 +60,7 @@ typedef struct gr_gemm_desc {
   int resid_mod;      /* > 0: residual row = m % resid_mod (position-embedding broadcast)          */
   /* output row remap: row(m) = (m / c_group)*c_group_stride + c_row_off + m % c_group (c_group > 0) */
   int c_group, c_group_stride, c_row_off;
-  int tile;           /* 0 = choose per shape; 128 / 256 force the 128x128 / 256x256 kernel (257 = its one-wave-per-
-                         SIMD variant, measured slower, kept for comparison); 1 = skinny decode
+  int tile;           /* 0 = choose per shape; 128 / 256 force the 128x128 / 256x256 kernel; 1 = skinny decode
                          kernel (M <= 8; requires splits == ceil(K/512) and ws); 2 = the same kernel but
                          the split-K partials are LEFT in ws [splits, M, N] f32 for a fused consumer
                          (gr_decode_reduce_norm / gr_decode_qkv_rope): C and the epilogue fields are unused */
@@ -75,17 +74,6 @@ typedef struct gr_gemm_desc {
    * merges the slices (in slice order) while loading its x operand and rounds to bf16 exactly as the nsplit = 1 path */
   const float* a_parts;
   int a_nsplit, a_hd;
-  /* act == 4: W is the fused [3*H*hd, K] QKV weight and the epilogue does the work of gr_qkv_split -- rounds the
-   * projection (+bias) to bf16, applies HF rotate_half RoPE to q and k when cos/sin are given, and writes
-   * q [B,H,L,hd], k[b,h,pos0+t,:], vt[b,h,:,pos0+t] for row m = b*L + t; C is unused.  Needs (H*hd) % 256 == 0 and
-   * 256 % hd == 0 (whole heads per 256-column tile).  Replaces HF LlamaAttention / Dinov2SelfAttention's
-   * q/k/v reshapes + apply_rotary_pos_emb + cache concat. */
-  void* qkv_q;
-  void* qkv_k;
-  void* qkv_vt;
-  const float* rope_cos;
-  const float* rope_sin;
-  int qkv_H, qkv_hd, qkv_L, qkv_pos0, qkv_kv_stride;
 } gr_gemm_desc;
 int gr_gemm_bf16(const gr_gemm_desc* d, hipStream_t stream);
 

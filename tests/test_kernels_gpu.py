@@ -498,61 +498,6 @@ def test_decode_attention(dev, B, H, hd, S, mode, nsplit):
         assert relerr(out, mf) < 1e-2
 
 
-@pytest.mark.parametrize("B,H,hd,L,K,rope,bias,pos0", [(2, 8, 128, 70, 256, True, False, 0), (3, 4, 64, 33, 128, False, True, 0),
-                                                      (2, 32, 128, 582, 4096, True, False, 0), (1, 4, 64, 40, 64, True, True, 24)])
-def test_gemm_fused_qkv_epilogue_equals_split_path(dev, B, H, hd, L, K, rope, bias, pos0):
-    """act=4 (QKV GEMM writes q / K-cache / V^T-cache itself) against GEMM -> bf16 -> gr_qkv_split: same roundings in the
-    same order, so q, k and v^T must match to <= 1 bf16 ulp (fma contraction inside the rotation), V exactly."""
-    ops = _ops()
-    M, N = B * L, 3 * H * hd
-    a = rnd((M, K), dev, seed=1).bfloat16()
-    w = (rnd((N, K), dev, seed=2) * 0.1).bfloat16()
-    bvec = rnd((N,), dev, seed=3) if bias else None
-    stride = (pos0 + L + 63) // 64 * 64
-    cos = sin = None
-    if rope:
-        inv = 1.0 / (10000 ** (torch.arange(0, hd, 2, device=dev).float() / hd))
-        fr = torch.outer(torch.arange(stride, device=dev).float(), inv)
-        cos, sin = fr.cos().contiguous(), fr.sin().contiguous()
-    res = []
-    for fused in (True, False):
-        q = torch.zeros((B, H, L, hd), dtype=torch.bfloat16, device=dev)
-        k = torch.zeros((B, H, stride, hd), dtype=torch.bfloat16, device=dev)
-        vt = torch.zeros((B, H, hd, stride), dtype=torch.bfloat16, device=dev)
-        if fused:
-            ops.gemm(a, w, bias=bvec, qkv=dict(q=q, k=k, vt=vt, cos=cos, sin=sin, H=H, hd=hd, L=L, pos0=pos0))
-        else:
-            qkv = ops.gemm(a, w, bias=bvec, tile=256)
-            ops.qkv_split(qkv, q, k, vt, B=B, H=H, L=L, hd=hd, pos0=pos0, cos=cos, sin=sin)
-        res.append((q, k, vt))
-    (q1, k1, v1), (q0, k0, v0) = res
-    assert (q0 != 0).any() and (k0 != 0).any() and (v0 != 0).any()
-    assert torch.equal(v1, v0)
-    for x, y in ((q1, q0), (k1, k0)):
-        assert relerr(x, y) < 2e-3
-        assert (x.float() - y.float()).abs().max().item() <= 2.0 ** -7 * max(1.0, y.float().abs().max().item())
-    if not rope:
-        assert torch.equal(q1, q0) and torch.equal(k1, k0)
-
-
-@pytest.mark.parametrize("M,N,K,kw", [(600, 520, 320, dict()), (1000, 1024, 4096, dict(bias=True, act=1)),
-                                      (300, 512, 1024, dict(resid=True, out_f32=True)), (513, 768, 256, dict(act=3))])
-def test_gemm_w128_variant_equals_pingpong(dev, M, N, K, kw):
-    """the one-wave-per-SIMD 256x256 kernel (tile=257, not the default) accumulates in the same order: bit-identical"""
-    ops = _ops()
-    a = rnd((M, K), dev, seed=1).bfloat16()
-    w = (rnd((N, K), dev, seed=2) * 0.1).bfloat16()
-    args = dict(act=kw.get("act", 0), out_f32=kw.get("out_f32", False))
-    if kw.get("bias"):
-        args["bias"] = rnd((N,), dev, seed=3)
-    outs = []
-    for tile in (256, 257):
-        if kw.get("resid"):
-            args["resid"] = rnd((M, N), dev, seed=4)
-        outs.append(ops.gemm(a, w, tile=tile, **args).clone())
-    assert torch.equal(outs[0], outs[1])
-
-
 @pytest.mark.parametrize("B,H,hd,L,rope,causal", [(2, 4, 128, 150, True, True), (3, 2, 64, 70, False, False), (2, 8, 64, 100, True, True)])
 def test_attention_reads_q_in_place(dev, B, H, hd, L, rope, causal):
     """attention(fused=...) -- q read (and rotated) straight from the fused QKV buffer -- against the packed-q path
