@@ -29,6 +29,42 @@ from . import cref
 
 IGNORE_INDEX = -100
 
+# ------------------------------------------------------------------------------------------------ operand rounding
+# The "bf16-rounded oracle" (SURVEY 'Hard parts', BASELINE north_star "logits within 1e-3"): the same fp32 restatement,
+# with GEMM operands rounded to bf16 at exactly the points where the MI355X path holds bf16 in HBM:
+# weights of the ViT / bridge / region-encoder / LLaMA linears and convs, normalisation outputs, projection outputs,
+# soft-max probabilities, attention context, activation outputs.  Accumulation, residual streams, soft-max statistics,
+# normalisation statistics, biases and the whole DDETR proposer stay fp32 (as on the device).  With rounding off (the
+# default) every _r() below is the identity, so the fp32 oracle and its goldens are untouched.
+_ROUND = [None]
+
+
+class rounding:
+    """with rounding("bf16"): ...   -- evaluate the oracle with bf16-rounded operands (None = pure fp32)."""
+
+    def __init__(self, mode):
+        assert mode in (None, "bf16")
+        self.mode = mode
+
+    def __enter__(self):
+        self.prev, _ROUND[0] = _ROUND[0], self.mode
+
+    def __exit__(self, *a):
+        _ROUND[0] = self.prev
+
+
+def _r(x):
+    return x if _ROUND[0] is None else x.to(torch.bfloat16).to(torch.float32)
+
+
+def _lin16(x, sd, name, bias=True):
+    """a Linear the device runs as a bf16 MFMA GEMM: bf16 operands, fp32 accumulate, fp32 bias"""
+    return F.linear(_r(x), _r(sd[name + ".weight"]), sd.get(name + ".bias") if bias else None)
+
+
+def _conv16(x, w, b=None, **kw):
+    return F.conv2d(_r(x), _r(w), b, **kw)
+
 
 # ------------------------------------------------------------------------------------------------ helpers
 def _lin(x, sd, name, bias=True):
@@ -81,6 +117,15 @@ def vit_pos_embed(sd, vc, grid, prefix="perceiver.vis_encoder."):
     return torch.cat((cls_pos.unsqueeze(0), patch_pos), dim=1)
 
 
+def _softmax_pv(scores, v):
+    """softmax(scores) @ v.  Rounded mode mirrors the flash kernel: un-normalised exp() rounded to bf16 for the P.V
+    product, the row sum kept in fp32 from the un-rounded values, context rounded to bf16 after the division."""
+    if _ROUND[0] is None:
+        return torch.softmax(scores, dim=-1, dtype=torch.float32) @ v
+    e = torch.exp(scores - scores.amax(dim=-1, keepdim=True))
+    return _r((_r(e) @ v) / e.sum(dim=-1, keepdim=True))
+
+
 def vit_forward(sd, cfg, images, prefix="perceiver.vis_encoder."):
     """HF Dinov2Model(images, output_hidden_states=True).hidden_states  (called at R: groma/model/groma.py:222).
     Returns the tuple (embeddings, layer_1, ..., layer_N); the final LayerNorm is never applied."""
@@ -89,8 +134,8 @@ def vit_forward(sd, cfg, images, prefix="perceiver.vis_encoder."):
     eps = vc["layer_norm_eps"]
     bs, _, S, _ = images.shape
     grid = S // P
-    x = F.conv2d(images, sd[prefix + "embeddings.patch_embeddings.projection.weight"],
-                 sd[prefix + "embeddings.patch_embeddings.projection.bias"], stride=P)
+    x = _conv16(images, sd[prefix + "embeddings.patch_embeddings.projection.weight"],
+                sd[prefix + "embeddings.patch_embeddings.projection.bias"], stride=P)
     x = x.flatten(2).transpose(1, 2)
     x = torch.cat((sd[prefix + "embeddings.cls_token"].expand(bs, -1, -1), x), dim=1)
     x = x + vit_pos_embed(sd, vc, grid, prefix)
@@ -99,14 +144,13 @@ def vit_forward(sd, cfg, images, prefix="perceiver.vis_encoder."):
     for i in range(vc["num_hidden_layers"]):
         p = f"{prefix}encoder.layer.{i}."
         y = _ln(x, sd, p + "norm1", eps)
-        q = _lin(y, sd, p + "attention.attention.query").view(bs, -1, heads, hd).transpose(1, 2)
-        k = _lin(y, sd, p + "attention.attention.key").view(bs, -1, heads, hd).transpose(1, 2)
-        v = _lin(y, sd, p + "attention.attention.value").view(bs, -1, heads, hd).transpose(1, 2)
-        att = torch.softmax(q @ k.transpose(-1, -2) / math.sqrt(hd), dim=-1)
-        ctx = (att @ v).transpose(1, 2).reshape(bs, -1, D)
-        x = x + sd[p + "layer_scale1.lambda1"] * _lin(ctx, sd, p + "attention.output.dense")
+        q = _r(_lin16(y, sd, p + "attention.attention.query")).view(bs, -1, heads, hd).transpose(1, 2)
+        k = _r(_lin16(y, sd, p + "attention.attention.key")).view(bs, -1, heads, hd).transpose(1, 2)
+        v = _r(_lin16(y, sd, p + "attention.attention.value")).view(bs, -1, heads, hd).transpose(1, 2)
+        ctx = _softmax_pv(q @ k.transpose(-1, -2) / math.sqrt(hd), v).transpose(1, 2).reshape(bs, -1, D)
+        x = x + sd[p + "layer_scale1.lambda1"] * _lin16(ctx, sd, p + "attention.output.dense")
         y = _ln(x, sd, p + "norm2", eps)
-        y = _lin(F.gelu(_lin(y, sd, p + "mlp.fc1")), sd, p + "mlp.fc2")
+        y = _lin16(F.gelu(_lin16(y, sd, p + "mlp.fc1")), sd, p + "mlp.fc2")
         x = x + sd[p + "layer_scale2.lambda1"] * y
         hidden.append(x)
     return tuple(hidden)
@@ -210,6 +254,41 @@ def stable_topk(x, k):
     return torch.sort(x, dim=1, descending=True, stable=True)[1][:, :k]
 
 
+def ddetr_encoder_layer(sd, p, x, pos, ref, shapes, heads, n_points):
+    """HF 4.32 DeformableDetrEncoderLayer (post-LN): x = LN(x + MSDA(x + pos, value = x)); x = LN(x + fc2(relu(fc1 x)))
+    (instantiated at R: groma/model/ddetr_transformer.py:299-301 through HF DeformableDetrEncoder)."""
+    y = _msda_module(sd, p + "self_attn.", x + pos, x, ref, shapes, heads, n_points)
+    x = _ln(x + y, sd, p + "self_attn_layer_norm", 1e-5)
+    y = _lin(F.relu(_lin(x, sd, p + "fc1")), sd, p + "fc2")
+    return _ln(x + y, sd, p + "final_layer_norm", 1e-5)
+
+
+def ddetr_decoder_layer(sd, p, hs, query_pos, memory, ref_in, shapes, heads, n_points):
+    """HF 4.32 DeformableDetrDecoderLayer as called at R: groma/model/ddetr_transformer.py:136-145: MHA self-attention
+    (q = k = hs + pos, v = hs, q scaled by hd^-0.5) -> LN -> MSDA cross-attention over `memory` -> LN -> FFN -> LN."""
+    bs, _, d = hs.shape
+    hd = d // heads
+    qk_in = hs + query_pos
+    q = (_lin(qk_in, sd, p + "self_attn.q_proj") * hd ** -0.5).view(bs, -1, heads, hd).transpose(1, 2)
+    k = _lin(qk_in, sd, p + "self_attn.k_proj").view(bs, -1, heads, hd).transpose(1, 2)
+    v = _lin(hs, sd, p + "self_attn.v_proj").view(bs, -1, heads, hd).transpose(1, 2)
+    att = torch.softmax(q @ k.transpose(-1, -2), dim=-1)
+    y = _lin((att @ v).transpose(1, 2).reshape(bs, -1, d), sd, p + "self_attn.out_proj")
+    hs = _ln(hs + y, sd, p + "self_attn_layer_norm", 1e-5)
+    y = _msda_module(sd, p + "encoder_attn.", hs + query_pos, memory, ref_in, shapes, heads, n_points)
+    hs = _ln(hs + y, sd, p + "encoder_attn_layer_norm", 1e-5)
+    y = _lin(F.relu(_lin(hs, sd, p + "fc1")), sd, p + "fc2")
+    return _ln(hs + y, sd, p + "final_layer_norm", 1e-5)
+
+
+def encoder_reference_points(bs, h, w):
+    """HF DeformableDetrEncoder.get_reference_points with valid_ratio = 1, one level: ((i + 0.5) / size) grid"""
+    ref_y, ref_x = torch.meshgrid(torch.linspace(0.5, h - 0.5, h, dtype=torch.float32),
+                                  torch.linspace(0.5, w - 0.5, w, dtype=torch.float32), indexing="ij")
+    ref = torch.stack((ref_x.reshape(-1)[None] / w, ref_y.reshape(-1)[None] / h), -1)  # [1, hw, 2]
+    return ref[:, :, None].expand(bs, -1, 1, -1)
+
+
 def ddetr_forward(sd, cfg, ddetr_inputs, prefix="perceiver."):
     """input_proj + DeformableDetrTransformer.forward (R: groma/model/groma.py:243-246; ddetr.py:146-155;
     ddetr_transformer.py:484-609, 668-728).  ddetr_inputs: [bs, C, h, w] (mean of the last 4 ViT states)."""
@@ -227,16 +306,9 @@ def ddetr_forward(sd, cfg, ddetr_inputs, prefix="perceiver."):
     x = src.flatten(2).transpose(1, 2)
     shapes = [(h, w)]
     # encoder reference points (HF DeformableDetrEncoder.get_reference_points, valid_ratio = 1)
-    ref_y, ref_x = torch.meshgrid(torch.linspace(0.5, h - 0.5, h, dtype=torch.float32),
-                                  torch.linspace(0.5, w - 0.5, w, dtype=torch.float32), indexing="ij")
-    ref = torch.stack((ref_x.reshape(-1)[None] / w, ref_y.reshape(-1)[None] / h), -1)  # [1, hw, 2]
-    enc_ref = ref[:, :, None].expand(bs, -1, 1, -1)
+    enc_ref = encoder_reference_points(bs, h, w)
     for i in range(dc["encoder_layers"]):
-        p = f"{t}encoder.layers.{i}."
-        y = _msda_module(sd, p + "self_attn.", x + pos, x, enc_ref, shapes, heads, dc["encoder_n_points"])
-        x = _ln(x + y, sd, p + "self_attn_layer_norm", 1e-5)
-        y = _lin(F.relu(_lin(x, sd, p + "fc1")), sd, p + "fc2")
-        x = _ln(x + y, sd, p + "final_layer_norm", 1e-5)
+        x = ddetr_encoder_layer(sd, f"{t}encoder.layers.{i}.", x, pos, enc_ref, shapes, heads, dc["encoder_n_points"])
     memory = x
     # two-stage proposals (R: ddetr_transformer.py:546-568)
     object_query, output_proposals = gen_encoder_output_proposals(sd, t, memory, h, w)
@@ -254,22 +326,11 @@ def ddetr_forward(sd, cfg, ddetr_inputs, prefix="perceiver."):
     hs = sd[t + "query_position_embeddings.weight"].unsqueeze(0).expand(bs, -1, -1)
     # decoder (R: ddetr_transformer.py:107-172; HF 4.32 DeformableDetrDecoderLayer); refs never refined (T3)
     dheads = dc["decoder_attention_heads"]
-    hd = d // dheads
     ref_in = reference_points[:, :, None]  # * valid_ratios (=1)
     inter, inter_ref = [], []
     for i in range(n_dec):
-        p = f"{t}decoder.layers.{i}."
-        qk_in = hs + query_pos
-        q = (_lin(qk_in, sd, p + "self_attn.q_proj") * hd ** -0.5).view(bs, -1, dheads, hd).transpose(1, 2)
-        k = _lin(qk_in, sd, p + "self_attn.k_proj").view(bs, -1, dheads, hd).transpose(1, 2)
-        v = _lin(hs, sd, p + "self_attn.v_proj").view(bs, -1, dheads, hd).transpose(1, 2)
-        att = torch.softmax(q @ k.transpose(-1, -2), dim=-1)
-        y = _lin((att @ v).transpose(1, 2).reshape(bs, -1, d), sd, p + "self_attn.out_proj")
-        hs = _ln(hs + y, sd, p + "self_attn_layer_norm", 1e-5)
-        y = _msda_module(sd, p + "encoder_attn.", hs + query_pos, memory, ref_in, shapes, dheads, dc["decoder_n_points"])
-        hs = _ln(hs + y, sd, p + "encoder_attn_layer_norm", 1e-5)
-        y = _lin(F.relu(_lin(hs, sd, p + "fc1")), sd, p + "fc2")
-        hs = _ln(hs + y, sd, p + "final_layer_norm", 1e-5)
+        hs = ddetr_decoder_layer(sd, f"{t}decoder.layers.{i}.", hs, query_pos, memory, ref_in, shapes, dheads,
+                                 dc["decoder_n_points"])
         tmp = _mlp_head(hs, sd, f"{t}bbox_embed.{i}")
         new_ref = (tmp + inverse_sigmoid(reference_points)).sigmoid()
         inter.append(hs)
@@ -340,7 +401,7 @@ def region_fuse(sd, cfg, mlvl_tokens, prefix="region_encoder."):
         y, x = torch.meshgrid(y_range, x_range, indexing="ij")
         coord = torch.cat([x.expand(bs, 1, -1, -1), y.expand(bs, 1, -1, -1)], 1)
         f = torch.cat([f, coord], dim=1)
-        new.append(F.conv2d(f, sd[f"{m}input_conv.{lvl}.weight"], sd[f"{m}input_conv.{lvl}.bias"]))
+        new.append(_r(_conv16(f, sd[f"{m}input_conv.{lvl}.weight"], sd[f"{m}input_conv.{lvl}.bias"])))
     inputs = new
     shuffle, remain = C // 4, C - 2 * (C // 4)
     for r in range(rc["num_fuse"]):
@@ -354,10 +415,12 @@ def region_fuse(sd, cfg, mlvl_tokens, prefix="region_encoder."):
                                       mode="bilinear", align_corners=True)
             fused.append(torch.cat([tar[:, :remain], from_top, from_down], dim=1))
         # mmcv ConvModule: conv(no bias) -> GN(groups) -> ReLU (R: mmcv/mmcv/cnn/bricks/conv_module.py:196-206)
-        inputs = [F.relu(F.group_norm(F.conv2d(x, sd[f"{m}fuse_convs.{r}.conv.weight"], None, padding=1),
+        # (rounded mode: the conv output is stored as bf16 and the GN statistics are taken from the stored values; the
+        #  normalised map is only rounded again where it is consumed -- as the next conv's / RoIAlign's bf16 input)
+        inputs = [F.relu(F.group_norm(_r(_conv16(x, sd[f"{m}fuse_convs.{r}.conv.weight"], None, padding=1)),
                                       rc["gn_groups"], sd[f"{m}fuse_convs.{r}.gn.weight"],
                                       sd[f"{m}fuse_convs.{r}.gn.bias"], 1e-5)) for x in fused]
-    return inputs
+    return [_r(x) for x in inputs]
 
 
 def roi_extract(sd, cfg, feats, rois_list, prefix="region_encoder.roi_align."):
@@ -379,12 +442,12 @@ def roi_extract(sd, cfg, feats, rois_list, prefix="region_encoder.roi_align."):
     for lvl, f in enumerate(feats):
         rf = torch.from_numpy(cref.roi_align_avg(f.float().contiguous().numpy(), rois.float().numpy(), (P, P),
                                                  1.0 / strides[lvl], 2, True))
-        y = F.conv2d(rf, sd[f"{prefix}pconvs.{lvl}.weight"], sd[f"{prefix}pconvs.{lvl}.bias"], padding=1)
+        y = _conv16(rf, sd[f"{prefix}pconvs.{lvl}.weight"], sd[f"{prefix}pconvs.{lvl}.bias"], padding=1)
         acc = y if acc is None else acc + y
     x = F.relu(acc).flatten(1, -1)
-    x = _lin(x, sd, prefix + "flatten_linear")
+    x = _lin16(x, sd, prefix + "flatten_linear")
     x = x + pe
-    x = _lin(x, sd, prefix + "updims")
+    x = _lin16(x, sd, prefix + "updims")
     return [x[rois[:, 0] == i] for i in range(len(rois_list))]
 
 
@@ -431,23 +494,22 @@ def llama_forward(sd, cfg, inputs_embeds, attention_mask, past=None, prefix="llm
     for i in range(lc["num_hidden_layers"]):
         p = f"{prefix}layers.{i}."
         x = rms(h, sd[p + "input_layernorm.weight"])
-        q = F.linear(x, sd[p + "self_attn.q_proj.weight"]).view(bs, L, H, hd).transpose(1, 2)
-        k = F.linear(x, sd[p + "self_attn.k_proj.weight"]).view(bs, L, H, hd).transpose(1, 2)
-        v = F.linear(x, sd[p + "self_attn.v_proj.weight"]).view(bs, L, H, hd).transpose(1, 2)
-        q = q * cos + _rot_half(q) * sin
-        k = k * cos + _rot_half(k) * sin
+        q = _r(_lin16(x, sd, p + "self_attn.q_proj", False)).view(bs, L, H, hd).transpose(1, 2)
+        k = _r(_lin16(x, sd, p + "self_attn.k_proj", False)).view(bs, L, H, hd).transpose(1, 2)
+        v = _r(_lin16(x, sd, p + "self_attn.v_proj", False)).view(bs, L, H, hd).transpose(1, 2)
+        q = _r(q * cos + _rot_half(q) * sin)
+        k = _r(k * cos + _rot_half(k) * sin)
         if past is not None:
             k = torch.cat([past[i][0], k], dim=2)
             v = torch.cat([past[i][1], v], dim=2)
         new_past.append((k, v))
         att = q @ k.transpose(2, 3) / math.sqrt(hd) + mask
         att = torch.max(att, torch.tensor(fmin))
-        att = torch.softmax(att, dim=-1, dtype=torch.float32)
-        y = (att @ v).transpose(1, 2).reshape(bs, L, D)
-        h = h + F.linear(y, sd[p + "self_attn.o_proj.weight"])
+        y = _softmax_pv(att, v).transpose(1, 2).reshape(bs, L, D)
+        h = h + _lin16(y, sd, p + "self_attn.o_proj", False)
         x = rms(h, sd[p + "post_attention_layernorm.weight"])
-        x = F.linear(F.silu(F.linear(x, sd[p + "mlp.gate_proj.weight"])) * F.linear(x, sd[p + "mlp.up_proj.weight"]),
-                     sd[p + "mlp.down_proj.weight"])
+        x = _lin16(F.silu(_lin16(x, sd, p + "mlp.gate_proj", False)) * _lin16(x, sd, p + "mlp.up_proj", False),
+                   sd, p + "mlp.down_proj", False)
         h = h + x
         if layer_hook is not None:
             layer_hook(i, h)
@@ -456,7 +518,7 @@ def llama_forward(sd, cfg, inputs_embeds, attention_mask, past=None, prefix="llm
 
 def get_input_embeddings(sd, input_ids):
     """R: groma/model/groma.py:165-174"""
-    W0, W1 = sd["llm.model.embed_tokens.weight"], sd["new_input_embs.weight"]
+    W0, W1 = _r(sd["llm.model.embed_tokens.weight"]), _r(sd["new_input_embs.weight"])  # bf16 tables on the device
     mask = input_ids >= W0.shape[0]
     ori = F.embedding(input_ids.masked_fill(mask, 0), W0)
     new = F.embedding((input_ids - W0.shape[0]).masked_fill(~mask, 0), W1)
@@ -466,7 +528,12 @@ def get_input_embeddings(sd, input_ids):
 
 def lm_logits(sd, hidden):
     """R: groma/model/groma.py:399-402"""
-    return torch.cat((F.linear(hidden, sd["llm.lm_head.weight"]), F.linear(hidden, sd["extra_lm_head.weight"])), dim=-1)
+    return torch.cat((_lin16(hidden, sd, "llm.lm_head", False), _lin16(hidden, sd, "extra_lm_head", False)), dim=-1)
+
+
+def bridge(sd, image_features):
+    """img_txt_bridge: Linear -> GELU -> Linear (R: groma/model/groma.py:112-116, applied :361)"""
+    return _lin16(F.gelu(_lin16(image_features, sd, "img_txt_bridge.0")), sd, "img_txt_bridge.2")
 
 
 # ------------------------------------------------------------------------------------------------ glue (groma.py:202-427)
@@ -563,7 +630,7 @@ def groma_forward(sd, cfg, tok, input_ids, images, refer_boxes=None, ground_boxe
     new_ids, attention_mask = splice_placeholders(input_ids, image_features.shape[1], [x.shape[0] for x in region_features],
                                                   tok)
     embeds = get_input_embeddings(sd, new_ids)
-    img = _lin(F.gelu(_lin(image_features, sd, "img_txt_bridge.0")), sd, "img_txt_bridge.2")
+    img = bridge(sd, image_features)
     reg = torch.cat(region_features)
     embeds.masked_scatter_((new_ids == tok["img_token_id"])[:, :, None], img)
     embeds.masked_scatter_((new_ids == tok["reg_token_id"])[:, :, None], reg)
