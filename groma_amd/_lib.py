@@ -74,7 +74,10 @@ SIGNATURES = {
     "gr_box_refine": [_P, _P, _P, _L, _P],
     "gr_score_fuse": [_P, _P, _P, _L, _L, _P],
     "gr_topk_desc": [_P, _P, _I, _I, _I, _L, _P],
-    "gr_nms_f32": [_P, _P, _I, _I, _F, _F, _I, _P, _P, _P, _P],
+    "gr_nms_workspace_bytes": [_I, _I],
+    "gr_nms_f32": [_P, _P, _I, _I, _F, _F, _I, _P, _P, _P, _P, _P],
+    "gr_nms": [_P, _P, _I, _F, _I, _P, _P, _P, _P],
+    "gr_roi_align_forward": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _I, _I, _I, _P],
     "gr_roi_align_pack": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _I, _I, _I, _I, _P],
 }
 
@@ -94,8 +97,8 @@ def load():
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
         fn.argtypes = argtypes
-        fn.restype = c_int
-    if lib.gr_abi_version() != 4:
+        fn.restype = c_long if name == "gr_nms_workspace_bytes" else c_int
+    if lib.gr_abi_version() != 5:
         raise RuntimeError("libgroma_hip.so ABI version mismatch")
     _lib = lib
     return lib

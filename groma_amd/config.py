@@ -155,12 +155,21 @@ def groma_7b(**kw):
     return GromaConfig(num_new_token=114, **kw)
 
 
-def groma_tiny(**kw):
+def groma_7b_width(vit_layers=3, num_fuse=1, llm_layers=1, **kw):
+    """Groma-7B WIDTH (every GEMM / conv / attention shape of the benchmark: D 1024 x 16 heads, C 1024 pyramid,
+    27 648-deep per-ROI conv, 200 704-deep flatten_linear, LLaMA 4096 / 11 008 / 32 heads, 32 114-wide head, full-depth
+    6+6 DDETR) at reduced DEPTH, so the fp32 CPU oracle finishes in seconds: the full-width parity configuration."""
+    return GromaConfig(llm_cfg=dict(num_hidden_layers=llm_layers),
+                       perceiver_cfg=dict(vis_encoder_cfg=dict(num_hidden_layers=vit_layers)),
+                       region_cfg=dict(num_fuse=num_fuse), num_new_token=114, **kw)
+
+
+def groma_tiny(ddetr_layers=2, **kw):
     """Structurally identical, small enough for the fp32 CPU oracle to finish in seconds (parity tests)."""
     return GromaConfig(
         llm_cfg=dict(hidden_size=512, intermediate_size=1408, num_hidden_layers=2, num_attention_heads=4,
                      vocab_size=32000),
         perceiver_cfg=dict(vis_encoder_cfg=dict(hidden_size=256, num_hidden_layers=4, num_attention_heads=4),
-                           ddetr_cfg=dict(encoder_layers=2, decoder_layers=2)),
+                           ddetr_cfg=dict(encoder_layers=ddetr_layers, decoder_layers=ddetr_layers)),
         region_cfg=dict(num_fuse=2, mid_dim=256),
         num_new_token=114, **kw)

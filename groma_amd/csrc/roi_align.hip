@@ -109,3 +109,91 @@ extern "C" int gr_roi_align_pack(const void* feat_nhwc, const float* rois, void*
   GR_CHECK_LAUNCH();
   return GR_OK;
 }
+
+
+// ---- the reference op's own layout: NCHW fp32 in, [K,C,PH,PW] fp32 out, avg or max pooling -------------------------
+// (mmcv `_ext.roi_align_forward`, pybind.cpp:596).  One lane per output element with pw fastest, so the 64 lanes of a
+// wave read neighbouring taps of one channel plane; same fp32 operation order as roi_align_cuda_kernel.cuh:17-108.
+__device__ __forceinline__ float bilinear1(const float* __restrict__ plane, int H, int W, float y, float x) {
+  if (y < -1.0f || y > (float)H || x < -1.0f || x > (float)W) return 0.f;
+  if (y <= 0.f) y = 0.f;
+  if (x <= 0.f) x = 0.f;
+  int y_low = (int)y, x_low = (int)x, y_high, x_high;
+  if (y_low >= H - 1) { y_high = y_low = H - 1; y = (float)y_low; } else { y_high = y_low + 1; }
+  if (x_low >= W - 1) { x_high = x_low = W - 1; x = (float)x_low; } else { x_high = x_low + 1; }
+  const float ly = y - y_low, lx = x - x_low;
+  const float hy = 1.f - ly, hx = 1.f - lx;
+  const float v1 = plane[y_low * W + x_low], v2 = plane[y_low * W + x_high];
+  const float v3 = plane[y_high * W + x_low], v4 = plane[y_high * W + x_high];
+  const float w1 = hy * hx, w2 = hy * lx, w3 = ly * hx, w4 = ly * lx;
+  return w1 * v1 + w2 * v2 + w3 * v3 + w4 * v4;
+}
+__global__ __launch_bounds__(256) void roi_align_nchw_kernel(long total, const float* __restrict__ input,
+                                                             const float* __restrict__ rois, float* __restrict__ output,
+                                                             float* __restrict__ argmax_y, float* __restrict__ argmax_x,
+                                                             int C, int H, int W, int PH, int PW, float spatial_scale,
+                                                             int sampling_ratio, int pool_mode, int aligned) {
+  for (long index = (long)blockIdx.x * 256 + threadIdx.x; index < total; index += (long)gridDim.x * 256) {
+    const int pw = (int)(index % PW);
+    const int ph = (int)((index / PW) % PH);
+    const int c = (int)((index / PW / PH) % C);
+    const long n = index / PW / PH / C;
+    const float* r = rois + n * 5;
+    const int batch = (int)r[0];
+    const float offset = aligned ? 0.5f : 0.0f;
+    const float roi_start_w = r[1] * spatial_scale - offset;
+    const float roi_start_h = r[2] * spatial_scale - offset;
+    const float roi_end_w = r[3] * spatial_scale - offset;
+    const float roi_end_h = r[4] * spatial_scale - offset;
+    float roi_width = roi_end_w - roi_start_w;
+    float roi_height = roi_end_h - roi_start_h;
+    if (!aligned) {
+      roi_width = fmaxf(roi_width, 1.f);
+      roi_height = fmaxf(roi_height, 1.f);
+    }
+    const float bin_size_h = roi_height / (float)PH;
+    const float bin_size_w = roi_width / (float)PW;
+    const float* plane = input + ((long)batch * C + c) * H * W;
+    const int grid_h = sampling_ratio > 0 ? sampling_ratio : (int)ceilf(roi_height / (float)PH);
+    const int grid_w = sampling_ratio > 0 ? sampling_ratio : (int)ceilf(roi_width / (float)PW);
+    if (pool_mode == 0) {
+      float maxval = -3.402823466e+38f, my = -1.f, mx = -1.f;
+      for (int iy = 0; iy < grid_h; ++iy) {
+        const float y = roi_start_h + ph * bin_size_h + ((float)iy + .5f) * bin_size_h / (float)grid_h;
+        for (int ix = 0; ix < grid_w; ++ix) {
+          const float x = roi_start_w + pw * bin_size_w + ((float)ix + .5f) * bin_size_w / (float)grid_w;
+          const float val = bilinear1(plane, H, W, y, x);
+          if (val > maxval) { maxval = val; my = y; mx = x; }
+        }
+      }
+      output[index] = maxval;
+      argmax_y[index] = my;
+      argmax_x[index] = mx;
+    } else {
+      const float count = (float)max(grid_h * grid_w, 1);
+      float acc = 0.f;
+      for (int iy = 0; iy < grid_h; ++iy) {
+        const float y = roi_start_h + ph * bin_size_h + ((float)iy + .5f) * bin_size_h / (float)grid_h;
+        for (int ix = 0; ix < grid_w; ++ix) {
+          const float x = roi_start_w + pw * bin_size_w + ((float)ix + .5f) * bin_size_w / (float)grid_w;
+          acc += bilinear1(plane, H, W, y, x);
+        }
+      }
+      output[index] = acc / count;
+    }
+  }
+}
+extern "C" int gr_roi_align_forward(const float* input, const float* rois, float* output, float* argmax_y, float* argmax_x,
+                                    int K, int C, int H, int W, int aligned_height, int aligned_width, float spatial_scale,
+                                    int sampling_ratio, int pool_mode, int aligned, hipStream_t stream) {
+  if (K < 0 || C <= 0 || H <= 0 || W <= 0 || aligned_height <= 0 || aligned_width <= 0) return GR_EINVAL;
+  if (pool_mode != 0 && pool_mode != 1) return GR_EINVAL;
+  if (K == 0) return GR_OK;
+  if (!input || !rois || !output || (pool_mode == 0 && (!argmax_y || !argmax_x))) return GR_EINVAL;
+  const long total = (long)K * C * aligned_height * aligned_width;
+  const int blocks = (int)((total + 255) / 256 < 65536L * 16 ? (total + 255) / 256 : 65536L * 16);
+  hipLaunchKernelGGL(roi_align_nchw_kernel, dim3(blocks), dim3(256), 0, stream, total, input, rois, output, argmax_y,
+                     argmax_x, C, H, W, aligned_height, aligned_width, spatial_scale, sampling_ratio, pool_mode, aligned);
+  GR_CHECK_LAUNCH();
+  return GR_OK;
+}

@@ -23,6 +23,18 @@ def _ru(x, m):
     return (x + m - 1) // m * m
 
 
+# Parity instrumentation: set engine.TRACE = {} and the next forward stores a copy of every intermediate that crosses a
+# kernel boundary in the FIRST layer of each stage (tests/test_fullwidth_parity_gpu.py feeds each kernel's actual input to
+# the oracle's version of that one operation).  None (the default) = no copies, no overhead.
+TRACE = None
+
+
+def _trace(name, t):
+    if TRACE is not None:
+        TRACE[name] = t.detach().clone()
+    return t
+
+
 class Workspace:
     """Scratch arenas, one per buffer NAME, grown geometrically and handed out as a view of the first prod(shape)
     elements -- so ragged request shapes (L = P + 256 + 2*N_regions changes with every image, R = sum N_i) do not
@@ -103,12 +115,14 @@ class VitEngine:
         vt = ws.get("vit_vt", (bs, H, hd, Tp), BF16, zero=True)
         fp8 = w["fp8"]
 
-        def lin(x_f32, ln_g, ln_b, wt, **kw):
+        def lin(x_f32, ln_g, ln_b, wt, tag=None, **kw):
             """LayerNorm -> GEMM (bf16 operands, or e4m3 operands with dynamic per-row activation scales)"""
             if fp8:
                 x8, sx = ops.norm_fp8(x_f32, ln_g, ln_b, self.eps, False)
                 return ops.gemm(x8, wt[0], a_scale=sx, w_scale=wt[1], **kw)
             x = ops.layernorm(x_f32, ln_g, ln_b, self.eps, out_bf16=True, out=ws.get("vit_x", (M, D), BF16))
+            if tag:
+                _trace(tag, x)
             return ops.gemm(x, wt[0], **kw)
 
         def lin_bf16(x_bf16, wt, **kw):
@@ -118,7 +132,11 @@ class VitEngine:
             return ops.gemm(x_bf16, wt[0], **kw)
 
         for i, L in enumerate(w["layers"]):
-            qkv = lin(h, L["ln1_g"], L["ln1_b"], L["wqkv"], bias=L["bqkv"], out=ws.get("vit_qkv", (M, 3 * D), BF16))
+            t0 = TRACE is not None and i == 0
+            if t0:
+                _trace("vit0.h_in", h)
+            qkv = lin(h, L["ln1_g"], L["ln1_b"], L["wqkv"], tag="vit0.ln1" if t0 else None, bias=L["bqkv"],
+                      out=ws.get("vit_qkv", (M, 3 * D), BF16))
             ops.qkv_split(qkv, None if Q_IN_PLACE else q, k, vt, B=bs, H=H, L=T, hd=hd)
             if Q_IN_PLACE:  # attention reads q straight from the fused projection
                 ctx = ops.attention(qkv, k, vt, Skv=T, causal=False, out=ws.get("vit_ctx", (M, D), BF16),
@@ -126,10 +144,12 @@ class VitEngine:
             else:
                 ctx = ops.attention(q, k, vt, Skv=T, causal=False, out=ws.get("vit_ctx", (M, D), BF16))
             lin_bf16(ctx, L["wo"], bias=L["bo"], scale=L["ls1"], resid=h, out=mid, out_f32=True)
-            y = lin(mid, L["ln2_g"], L["ln2_b"], L["w1"], bias=L["b1"], act=1,
+            y = lin(mid, L["ln2_g"], L["ln2_b"], L["w1"], tag="vit0.ln2" if t0 else None, bias=L["b1"], act=1,
                     out=ws.get("vit_y", (M, L["w1"][0].shape[0]), BF16))
             hn = out_buf(i + 1)
             lin_bf16(y, L["w2"], bias=L["b2"], scale=L["ls2"], resid=mid, out=hn, out_f32=True)
+            if t0:
+                _trace("vit0.qkv", qkv), _trace("vit0.ctx", ctx), _trace("vit0.mid", mid), _trace("vit0.fc1", y), _trace("vit0.out", hn)
             h = hn
         first = nl + 1 - self.keep
         return [out_buf(j) for j in range(max(first, 0), nl + 1)]
@@ -238,8 +258,9 @@ class RegionEngine:
         S = [G * 4, G * 2, G]
         maps, sums = [], [None, None, None]
         for l in range(3):
-            a = ops.upsample_coord_pack(hidden3[l], G, S[l], w["Cpad"])
-            maps.append(ops.gemm(a, w["in_w"][l], bias=w["in_b"][l], out=ws.get(f"reg_in{l}", (bs * S[l] * S[l], D), BF16)))
+            a = _trace(f"reg.up{l}", ops.upsample_coord_pack(hidden3[l], G, S[l], w["Cpad"]))
+            maps.append(_trace(f"reg.in{l}", ops.gemm(a, w["in_w"][l], bias=w["in_b"][l],
+                                                      out=ws.get(f"reg_in{l}", (bs * S[l] * S[l], D), BF16))))
         for r in range(rc.num_fuse):
             new_maps, new_coef = [], []
             for l in range(3):
@@ -249,6 +270,8 @@ class RegionEngine:
                                  pad, imgs=bs, C=D, shuffle=True, pad=1)
                 out = ws.get(f"reg_conv{l}_{r & 1}", (bs * S[l] * S[l], D), BF16)
                 ops.gemm(pad, w["fuse"][r]["w"], conv=(bs, S[l], S[l], D, 0), out=out)
+                if r == 0:
+                    _trace(f"reg.pad{l}", pad), _trace(f"reg.conv{l}", out)
                 new_maps.append(out)
                 # GN of THIS round's conv (fuse_convs[r].gn), applied where the map is consumed next
                 new_coef.append(ops.gn_coef(out, bs, S[l] * S[l], D, rc.gn_groups, w["fuse"][r]["g"], w["fuse"][r]["b"], 1e-5))
@@ -257,6 +280,8 @@ class RegionEngine:
         for l in range(3):
             f = ws.get(f"reg_feat{l}", (bs, S[l], S[l], D), BF16)
             ops.fuse_shuffle((maps[l], sums[l], S[l]), None, None, f, imgs=bs, C=D, shuffle=False, pad=0)
+            if rc.num_fuse == 1:  # then maps[l] is the traced round-0 conv output: feat = ReLU(GN(conv))
+                _trace(f"reg.feat{l}", f)
             feats.append(f)
         return feats, S
 
@@ -272,6 +297,7 @@ class RegionEngine:
                                spatial_scale=1.0 / self.STRIDES[l], sampling_ratio=2, aligned=True, pad=1)
         pc = ops.gemm(tiles, w["pconv_w"], bias=w["pconv_b"], act=2, conv=(R, P, P, D, R * (P + 2) * (P + 2) * D),
                       out=ws.get("reg_pc", (R * P * P, D), BF16))
+        _trace("reg.rois", rois), _trace("reg.tiles", tiles), _trace("reg.pc", pc)
         # pos_embedd(rois) on the UNSCALED cxcywh boxes (roi_align.py:278)
         b16 = torch.zeros((R, 16), dtype=F32, device=boxes.device)
         b16[:, :4] = boxes
@@ -282,7 +308,8 @@ class RegionEngine:
         K = P * P * D
         splits = max(1, min(32, K // 4096))
         fl = ops.gemm(pc.view(R, K), w["flat_w"], bias=w["flat_b"], resid=pe, splits=splits)
-        return ops.gemm(fl, w["up_w"], bias=w["up_b"], out_f32=True)
+        _trace("reg.pe", pe), _trace("reg.fl", fl)
+        return _trace("reg.out", ops.gemm(fl, w["up_w"], bias=w["up_b"], out_f32=True))
 
 
 # ------------------------------------------------------------------------------------------------ LLaMA
@@ -350,12 +377,14 @@ class LlamaEngine:
         q = ws.get("llm_q", (bs, H, L, hd), BF16)
         fp8 = w["fp8"]
 
-        def lin(x_f32, gain, wt, **kw):
+        def lin(x_f32, gain, wt, tag=None, **kw):
             """RMSNorm -> GEMM (bf16 operands, or e4m3 operands with dynamic per-row activation scales)"""
             if fp8:
                 x8, sx = ops.norm_fp8(x_f32, gain, None, self.eps, True)
                 return ops.gemm(x8, wt[0], a_scale=sx, w_scale=wt[1], **kw)
             x = ops.rmsnorm(x_f32, gain, self.eps, out=ws.get("llm_x", (M, T), BF16))
+            if tag:
+                _trace(tag, x)
             return ops.gemm(x, wt[0], **kw)
 
         def lin_bf16(x_bf16, wt, **kw):
@@ -365,7 +394,10 @@ class LlamaEngine:
             return ops.gemm(x_bf16, wt[0], **kw)
 
         for i, Lw in enumerate(w["layers"]):
-            qkv = lin(h, Lw["n1"], Lw["wqkv"], out=ws.get("llm_qkv", (M, 3 * T), BF16))
+            t0 = TRACE is not None and i == 0
+            if t0:
+                _trace("llm0.h_in", h)
+            qkv = lin(h, Lw["n1"], Lw["wqkv"], tag="llm0.n1" if t0 else None, out=ws.get("llm_qkv", (M, 3 * T), BF16))
             ops.qkv_split(qkv, None if Q_IN_PLACE else q, cache.k[i], cache.vt[i], B=bs, H=H, L=L, hd=hd, pos0=past,
                           cos=w["cos"], sin=w["sin"], pos_dev=pos_dev, pos_stride=pos_stride)
             att_kw = dict(Skv=cache.smax if dyn else past + L, causal=True, q_pos0=past, kv_len=kv_len,
@@ -376,11 +408,17 @@ class LlamaEngine:
             else:
                 ctx = ops.attention(q, cache.k[i], cache.vt[i], **att_kw)
             lin_bf16(ctx, Lw["wo"], resid=h, out=h, out_f32=True)
-            y = lin(h, Lw["n2"], Lw["wgu"], act=3, out=ws.get("llm_y", (M, self.I), BF16))
+            if t0:
+                _trace("llm0.qkv", qkv), _trace("llm0.ctx", ctx), _trace("llm0.h_attn", h)
+            y = lin(h, Lw["n2"], Lw["wgu"], tag="llm0.n2" if t0 else None, act=3, out=ws.get("llm_y", (M, self.I), BF16))
             lin_bf16(y, Lw["wd"], resid=h, out=h, out_f32=True)
+            if t0:
+                _trace("llm0.act", y), _trace("llm0.h_out", h)
         if not dyn:
             cache.seq_len = past + L
         hn = ops.rmsnorm(h, w["norm"], self.eps, out=ws.get("llm_x", (M, T), BF16))
+        if len(w["layers"]) == 1:
+            _trace("llm.final_norm", hn)
         if not all_logits and L > 1:
             hn = hn.view(bs, L, T)[:, -1].contiguous()
             logits = ops.gemm(hn, w["head"], out_f32=True)

@@ -294,8 +294,8 @@ class GromaModel:
                 with torch.cuda.stream(side):
                     feats, S = self.region.fuse(hidden4[-3:])
                     last = hidden4[self.config.perceiver_cfg.vis_output_layer]
-                    s2d = ops.s2d_pack(last, self.vit.G)
-                    mid = ops.gemm(s2d, self.bridge["w0"], bias=self.bridge["b0"], act=1)
+                    s2d = engine._trace("bridge.s2d", ops.s2d_pack(last, self.vit.G))
+                    mid = engine._trace("bridge.mid", ops.gemm(s2d, self.bridge["w0"], bias=self.bridge["b0"], act=1))
                     image_features = ops.gemm(mid, self.bridge["w2"], bias=self.bridge["b2"], out_f32=True)
                     image_features.record_stream(main)
                 selected_boxes, aux = self.propose(hidden4, refer_boxes, ground_boxes, seeds=_seeds)
@@ -370,6 +370,8 @@ class GromaModel:
                 aux["lengths"] = mask_h.sum(-1).tolist()  # expanded length of every row (right padding excluded)
                 aux["hidden4"] = hidden4  # the four ViT states the path consumed (arena views: valid until the next forward)
                 aux["input_ids"] = new_ids_h
+                if getattr(self, "capture_embeds", False):  # parity tests: the LLM stage's exact input (emb is consumed in place)
+                    aux["inputs_embeds"] = emb.view(bs, L, -1).clone()
                 self._last_aux = aux
             else:
                 cache = past_key_values

@@ -417,6 +417,21 @@ def topk_desc(x, K):
     return out
 
 
+_NMS_WS = {}
+
+
+def _nms_ws(B, n, device):
+    """caller-owned workspace of the general NMS path (n > 512); None on the one-workgroup fast path"""
+    nbytes = _lib.load().gr_nms_workspace_bytes(B, n)
+    if nbytes == 0:
+        return None
+    key = (str(device), nbytes)
+    if key not in _NMS_WS:
+        _NMS_WS.clear()
+        _NMS_WS[key] = torch.empty((nbytes,), dtype=torch.uint8, device=device)
+    return _NMS_WS[key]
+
+
 def nms(boxes_cxcywh, scores, iou_thr, score_thr, max_num, n_valid=None):
     """boxes [B,n,4] (cx,cy,w,h), scores [B,n] -> keep int64 [B,max_num] (-1 padded), n_keep int32 [B]"""
     lib = _lib.load()
@@ -425,8 +440,44 @@ def nms(boxes_cxcywh, scores, iou_thr, score_thr, max_num, n_valid=None):
     keep = torch.empty((B, max_num), dtype=I64, device=scores.device)
     n_keep = torch.empty((B,), dtype=I32, device=scores.device)
     _lib.check(lib.gr_nms_f32(_p(boxes_cxcywh), _p(scores), B, n, iou_thr, score_thr, max_num, _p(n_valid), _p(keep),
-                              _p(n_keep), _stream()), "gr_nms_f32")
+                              _p(n_keep), _p(_nms_ws(B, n, scores.device)), _stream()), "gr_nms_f32")
     return keep, n_keep
+
+
+def nms_xyxy(boxes_xyxy, scores, iou_threshold, offset):
+    """mmcv `_ext.nms` contract (pybind.cpp:175): boxes f32 [n,4] corners, scores [n] -> (keep int64 [n] with -1 tail,
+    n_keep int32 [1]) on the device; no host sync here (groma_amd.mmcv_ext.nms slices the result like the reference)."""
+    lib = _lib.load()
+    _chk(boxes_xyxy, F32, "boxes"); _chk(scores, F32, "scores")
+    n = scores.shape[0]
+    if boxes_xyxy.shape != (n, 4):
+        raise ValueError(f"boxes must be [{n},4], got {tuple(boxes_xyxy.shape)}")
+    keep = torch.empty((max(n, 1),), dtype=I64, device=scores.device)
+    n_keep = torch.empty((1,), dtype=I32, device=scores.device)
+    _lib.check(lib.gr_nms(_p(boxes_xyxy), _p(scores), n, float(iou_threshold), int(offset), _p(keep), _p(n_keep),
+                          _p(_nms_ws(1, n, scores.device)), _stream()), "gr_nms")
+    return keep, n_keep
+
+
+def roi_align_forward(input, rois, output, argmax_y, argmax_x, aligned_height, aligned_width, spatial_scale,
+                      sampling_ratio, pool_mode, aligned):
+    """mmcv `_ext.roi_align_forward` contract (pybind.cpp:596): NCHW f32 input, [K,5] rois, writes `output`
+    (and argmax_y / argmax_x for max pooling) in place on the current stream."""
+    lib = _lib.load()
+    _chk(input, F32, "input"); _chk(rois, F32, "rois"); _chk(output, F32, "output")
+    N, C, H, W = input.shape
+    K = rois.shape[0]
+    if rois.dim() != 2 or rois.shape[1] != 5:
+        raise ValueError("rois must be [K,5]")
+    if tuple(output.shape) != (K, C, aligned_height, aligned_width):
+        raise ValueError("output must be [K,C,aligned_height,aligned_width]")
+    if pool_mode == 0:
+        _chk(argmax_y, F32, "argmax_y"); _chk(argmax_x, F32, "argmax_x")
+    _lib.check(lib.gr_roi_align_forward(_p(input), _p(rois), _p(output), _p(argmax_y) if pool_mode == 0 else None,
+                                        _p(argmax_x) if pool_mode == 0 else None, K, C, H, W, aligned_height,
+                                        aligned_width, float(spatial_scale), int(sampling_ratio), int(pool_mode),
+                                        int(bool(aligned)), _stream()), "gr_roi_align_forward")
+    return output
 
 
 def roi_align_pack(feat_nhwc, rois, out, *, C, H, W, ph, pw, spatial_scale, sampling_ratio, aligned=True, pad=1,

@@ -157,9 +157,16 @@ def materialize(shape, kind, gen, device="cpu"):
     raise ValueError(kind)
 
 
-def make_state_dict(cfg, seed=0):
+def make_state_dict(cfg, seed=0, only=None):
+    """only=(prefix, ...): keep just those parameters (all are still drawn, from the one seeded stream, so a subset
+    equals the same entries of the full dict)."""
     gen = torch.Generator().manual_seed(seed)
-    return {name: materialize(shape, kind, gen) for name, shape, kind in param_spec(cfg)}
+    out = {}
+    for name, shape, kind in param_spec(cfg):
+        t = materialize(shape, kind, gen)
+        if only is None or name.startswith(tuple(only)):
+            out[name] = t
+    return out
 
 
 def make_inputs(cfg, tok, bs, seed=1234, prompt_len=128, k1=20, k2=6):

@@ -26,7 +26,7 @@ extern "C" {
 typedef struct ihipStream_t* hipStream_t;
 #endif
 
-#define GROMA_HIP_ABI_VERSION 4
+#define GROMA_HIP_ABI_VERSION 5
 int gr_abi_version(void);
 /* kernel timing hook used by bench.py: when enabled, every gr_gemm_bf16 launch is bracketed by HIP
  * events on its own stream; gr_prof_read drains them (sync) and returns total ms + launch count. */
@@ -180,12 +180,25 @@ int gr_box_refine(const float* tmp, const float* ref, float* out, long n, hipStr
 int gr_score_fuse(const float* coco, const float* sa1b, float* out, long n, long ld, hipStream_t stream);
 
 /* ------------------------------------------------------------------- selection (index-exact) -- */
-/* replaces torch.topk at groma/model/ddetr_transformer.py:556; order (value desc, index asc); S <= 1024 */
+/* replaces torch.topk at groma/model/ddetr_transformer.py:556; order (value desc, index asc); S <= 4096
+ * (one workgroup per image: LDS bitonic sort, 1024- or 4096-entry capacity) */
 int gr_topk_desc(const float* x, int* out_idx, int B, int S, int K, long ldx, hipStream_t stream);
-/* replaces mmcv `_ext.nms` + NMSop glue (mmcv/ops/nms.py:14-33, csrc/pytorch/cpu/nms.cpp:5-54) for the call at
- * groma/model/groma.py:266-272; boxes are (cx,cy,w,h); n <= 512; keep is int64 [B,max_num], -1 padded. */
+/* replaces mmcv `_ext.nms` + NMSop glue (mmcv/ops/nms.py:14-33, csrc/pytorch/cpu/nms.cpp:5-54) for the BATCHED call at
+ * groma/model/groma.py:266-272: boxes are (cx,cy,w,h) (converted with HF center_to_corners_format inside), score
+ * threshold applied only when > 0 (nms.py:21), first max_num kept; keep is int64 [B,max_num], -1 padded.
+ * n <= 512: one workgroup per image, no workspace (ws may be NULL).  512 < n <= 4096: three launches over a caller-owned
+ * workspace of gr_nms_workspace_bytes(B, n) bytes. */
+long gr_nms_workspace_bytes(int B, int n);
 int gr_nms_f32(const float* boxes_cxcywh, const float* scores, int B, int n, float iou_thr, float score_thr, int max_num,
-               const int* n_valid, long* keep, int* n_keep, hipStream_t stream);
+               const int* n_valid, long* keep, int* n_keep, void* ws, hipStream_t stream);
+/* The reference op itself, argument for argument: `Tensor nms(Tensor boxes, Tensor scores, float iou_threshold,
+ * int offset)` (mmcv/ops/csrc/pytorch/pybind.cpp:175; CPU semantics csrc/pytorch/cpu/nms.cpp:5-54; called from
+ * NMSop.forward, mmcv/ops/nms.py:26-27).  boxes f32 [n,4] = (x1,y1,x2,y2), scores f32 [n], offset in {0,1}.
+ * The returned Tensor becomes two caller-owned outputs: keep int64 [n] receives the kept indices (into the input, by
+ * descending score, ties by ascending index; entries past *n_keep are -1) and n_keep (device int32) their count.
+ * n == 0 is legal (count 0).  ws as for gr_nms_f32 with B = 1. */
+int gr_nms(const float* boxes_xyxy, const float* scores, int n, float iou_threshold, int offset, long* keep, int* n_keep,
+           void* ws, hipStream_t stream);
 
 /* ---------------------------------------------------------------------- fused RoIAlign + pack -- */
 /* replaces mmcv `_ext.roi_align_forward` (mmcv/ops/roi_align.py:93-104; kernel
@@ -195,6 +208,18 @@ int gr_nms_f32(const float* boxes_cxcywh, const float* scores, int B, int n, flo
 int gr_roi_align_pack(const void* feat_nhwc, const float* rois, void* out, int R, int C, int H, int W, int pooled_h,
                       int pooled_w, float spatial_scale, int sampling_ratio, int aligned, int pad, int out_f32,
                       hipStream_t stream);
+
+/* The reference op itself, argument for argument: `void roi_align_forward(Tensor input, Tensor rois, Tensor output,
+ * Tensor argmax_y, Tensor argmax_x, int aligned_height, int aligned_width, float spatial_scale, int sampling_ratio,
+ * int pool_mode, bool aligned)` (mmcv/ops/csrc/pytorch/pybind.cpp:596; caller mmcv/ops/roi_align.py:93-104; arithmetic
+ * of csrc/common/cuda/roi_align_cuda_kernel.cuh:17-108).  Tensors become pointers + the sizes ATen would carry:
+ * input f32 NCHW [N,C,H,W], rois f32 [K,5] = (batch, x1,y1,x2,y2), output f32 [K,C,aligned_height,aligned_width]
+ * (caller-allocated; every element is written), argmax_y/argmax_x f32 like output -- written when pool_mode == 0 (max),
+ * ignored (may be NULL) when pool_mode == 1 (avg).  Same numbers as gr_roi_align_pack; this entry keeps the reference's
+ * NCHW fp32 layout for an mmcv-side binding, the packed NHWC bf16 entry above is the one the hot path uses. */
+int gr_roi_align_forward(const float* input, const float* rois, float* output, float* argmax_y, float* argmax_x, int K,
+                         int C, int H, int W, int aligned_height, int aligned_width, float spatial_scale,
+                         int sampling_ratio, int pool_mode, int aligned, hipStream_t stream);
 
 #ifdef __cplusplus
 }

@@ -28,6 +28,8 @@ def _load():
         _lib.oracle_roi_align_avg.restype = None
         _lib.oracle_roi_align_avg.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p] + [ctypes.c_int] * 6 + \
             [ctypes.c_float, ctypes.c_int, ctypes.c_int]
+        _lib.oracle_roi_align_max.restype = None
+        _lib.oracle_roi_align_max.argtypes = [ctypes.c_void_p] * 5 + [ctypes.c_int] * 6 + [ctypes.c_float, ctypes.c_int, ctypes.c_int]
     return _lib
 
 
@@ -51,6 +53,20 @@ def roi_align_avg(inp_nchw, rois, pooled, spatial_scale, sampling_ratio, aligned
         _load().oracle_roi_align_avg(x.ctypes.data, r.ctypes.data, out.ctypes.data, r.shape[0], C, H, W, ph, pw,
                                      float(spatial_scale), int(sampling_ratio), int(bool(aligned)))
     return out
+
+
+def roi_align_max(inp_nchw, rois, pooled, spatial_scale, sampling_ratio, aligned=True):
+    """-> (output, argmax_y, argmax_x), the max-pooling branch (pool_mode 0)"""
+    x = np.ascontiguousarray(inp_nchw, dtype=np.float32)
+    r = np.ascontiguousarray(rois, dtype=np.float32).reshape(-1, 5)
+    N, C, H, W = x.shape
+    ph, pw = pooled
+    out, ay, ax = (np.zeros((r.shape[0], C, ph, pw), dtype=np.float32) for _ in range(3))
+    if r.shape[0]:
+        _load().oracle_roi_align_max(x.ctypes.data, r.ctypes.data, out.ctypes.data, ay.ctypes.data, ax.ctypes.data,
+                                     r.shape[0], C, H, W, ph, pw, float(spatial_scale), int(sampling_ratio),
+                                     int(bool(aligned)))
+    return out, ay, ax
 
 
 # ---- the reference's own CPU ops (oracle/_ref/libmmcv_ref.so, built by oracle/build_ref.py from /root/reference) ----

@@ -117,13 +117,29 @@ def vit_pos_embed(sd, vc, grid, prefix="perceiver.vis_encoder."):
     return torch.cat((cls_pos.unsqueeze(0), patch_pos), dim=1)
 
 
+ATT_KEY_TILE = 64  # keys per online-softmax step of the device's prefill attention kernel (csrc/attention.hip, KV)
+
+
 def _softmax_pv(scores, v):
-    """softmax(scores) @ v.  Rounded mode mirrors the flash kernel: un-normalised exp() rounded to bf16 for the P.V
-    product, the row sum kept in fp32 from the un-rounded values, context rounded to bf16 after the division."""
+    """softmax(scores) @ v.  Rounded mode mirrors the flash kernel's number formats: keys are consumed in tiles of 64,
+    the un-normalised exp(s - running_max) of a tile is rounded to bf16 for the P.V product (the running max being the
+    maximum over the tiles seen SO FAR, so which value gets rounded depends on the tile order), earlier tiles are rescaled
+    in fp32, the row sum is kept in fp32 from the un-rounded values, and the context is rounded to bf16 after the division.
+    (With zero-mean V a different-but-equivalent rounding point -- e.g. exp(s - final_max) -- changes the context by
+    ~1e-3 relative: the rounding errors of P do not average out, they random-walk like the signal.)"""
     if _ROUND[0] is None:
         return torch.softmax(scores, dim=-1, dtype=torch.float32) @ v
-    e = torch.exp(scores - scores.amax(dim=-1, keepdim=True))
-    return _r((_r(e) @ v) / e.sum(dim=-1, keepdim=True))
+    S = scores.shape[-1]
+    nt = (S + ATT_KEY_TILE - 1) // ATT_KEY_TILE
+    pad = nt * ATT_KEY_TILE - S
+    sp = F.pad(scores, (0, pad), value=torch.finfo(torch.float32).min) if pad else scores
+    tile_max = sp.view(*sp.shape[:-1], nt, ATT_KEY_TILE).amax(dim=-1)
+    m_run = torch.cummax(tile_max, dim=-1).values                      # running max after each tile
+    m_key = m_run.repeat_interleave(ATT_KEY_TILE, dim=-1)[..., :S]     # the max each key's exp() was taken against
+    m_fin = m_run[..., -1:]
+    e = torch.exp(scores - m_key)
+    w = torch.exp(m_key - m_fin)                                       # fp32 rescale of earlier tiles (product of alphas)
+    return _r(((_r(e) * w) @ v) / (e * w).sum(dim=-1, keepdim=True))
 
 
 def vit_forward(sd, cfg, images, prefix="perceiver.vis_encoder."):
@@ -638,7 +654,7 @@ def groma_forward(sd, cfg, tok, input_ids, images, refer_boxes=None, ground_boxe
         embeds.masked_scatter_((new_ids == tok["refer_feat_token_id"])[:, :, None], torch.cat(refer_region))
     hidden, past = llama_forward(sd, cfg, embeds, attention_mask)
     logits = lm_logits(sd, hidden)
-    out = dict(logits=logits, past=past, input_ids=new_ids, attention_mask=attention_mask, inputs_embeds=embeds,
+    out = dict(logits=logits, past=past, input_ids=new_ids, rewritten_ids=input_ids, attention_mask=attention_mask, inputs_embeds=embeds,
                pred_boxes=selected_boxes, image_features=img, region_features=reg, llm_hidden=hidden)
     out.update({k: v for k, v in per.items() if k not in out})
     return out
@@ -661,7 +677,10 @@ def greedy_generate(sd, cfg, tok, input_ids, images, max_new_tokens, eos_token_i
     past = out["past"]
     logits = out["logits"]
     unfinished = torch.ones(input_ids.shape[0], dtype=torch.long)
+    margins = []  # per step: top-1 minus top-2 logit of every row (how resolvable the greedy choice is)
     for step in range(max_new_tokens):
+        top2 = logits[:, -1, :].topk(2, dim=-1).values
+        margins.append(top2[:, 0] - top2[:, 1])
         nxt = torch.argmax(logits[:, -1, :], dim=-1)
         nxt = nxt * unfinished + tok["pad_token_id"] * (1 - unfinished)
         seqs = torch.cat([seqs, nxt[:, None]], dim=-1)
@@ -669,4 +688,4 @@ def greedy_generate(sd, cfg, tok, input_ids, images, max_new_tokens, eos_token_i
         if unfinished.max() == 0 or step == max_new_tokens - 1:
             break
         logits, past = groma_decode_step(sd, cfg, nxt, past)
-    return dict(sequences=seqs, pred_boxes=out["pred_boxes"], prefill=out)
+    return dict(sequences=seqs, pred_boxes=out["pred_boxes"], prefill=out, margins=torch.stack(margins, dim=1))

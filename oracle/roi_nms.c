@@ -139,3 +139,47 @@ void oracle_roi_align_avg(const float* input, const float* rois, float* output, 
     output[index] = output_val / count;
   }
 }
+
+/* max pooling branch of the same kernel (roi_align_cuda_kernel.cuh:66-87): output = max over the bin's samples,
+ * argmax_y / argmax_x = the sampling coordinates of the first maximum (-1 when the bin has no sample above -FLT_MAX) */
+void oracle_roi_align_max(const float* input, const float* rois, float* output, float* argmax_y, float* argmax_x, int R,
+                          int channels, int height, int width, int pooled_height, int pooled_width, float spatial_scale,
+                          int sampling_ratio, int aligned) {
+  const long nthreads = (long)R * channels * pooled_height * pooled_width;
+  for (long index = 0; index < nthreads; ++index) {
+    const int pw = index % pooled_width;
+    const int ph = (index / pooled_width) % pooled_height;
+    const int c = (index / pooled_width / pooled_height) % channels;
+    const int n = index / pooled_width / pooled_height / channels;
+    const float* offset_rois = rois + n * 5;
+    const int roi_batch_ind = (int)offset_rois[0];
+    const float offset = aligned ? 0.5f : 0.0f;
+    const float roi_start_w = offset_rois[1] * spatial_scale - offset;
+    const float roi_start_h = offset_rois[2] * spatial_scale - offset;
+    const float roi_end_w = offset_rois[3] * spatial_scale - offset;
+    const float roi_end_h = offset_rois[4] * spatial_scale - offset;
+    float roi_width = roi_end_w - roi_start_w;
+    float roi_height = roi_end_h - roi_start_h;
+    if (!aligned) {
+      roi_width = fmaxf(roi_width, 1.f);
+      roi_height = fmaxf(roi_height, 1.f);
+    }
+    const float bin_size_h = roi_height / (float)pooled_height;
+    const float bin_size_w = roi_width / (float)pooled_width;
+    const float* offset_input = input + ((long)roi_batch_ind * channels + c) * height * width;
+    const int roi_bin_grid_h = (sampling_ratio > 0) ? sampling_ratio : (int)ceilf(roi_height / pooled_height);
+    const int roi_bin_grid_w = (sampling_ratio > 0) ? sampling_ratio : (int)ceilf(roi_width / pooled_width);
+    float maxval = -3.402823466e+38f, maxidx_y = -1.f, maxidx_x = -1.f;
+    for (int iy = 0; iy < roi_bin_grid_h; iy++) {
+      const float y = roi_start_h + ph * bin_size_h + ((float)iy + .5f) * bin_size_h / (float)roi_bin_grid_h;
+      for (int ix = 0; ix < roi_bin_grid_w; ix++) {
+        const float x = roi_start_w + pw * bin_size_w + ((float)ix + .5f) * bin_size_w / (float)roi_bin_grid_w;
+        const float val = bilinear_interpolate(offset_input, height, width, y, x);
+        if (val > maxval) { maxval = val; maxidx_y = y; maxidx_x = x; }
+      }
+    }
+    output[index] = maxval;
+    argmax_y[index] = maxidx_y;
+    argmax_x[index] = maxidx_x;
+  }
+}

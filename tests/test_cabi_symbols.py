@@ -9,7 +9,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def _declared():
     src = open(os.path.join(ROOT, "include", "groma_hip.h")).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-    return sorted(set(re.findall(r"\bint\s+(gr_[a-z0-9_]+)\s*\(", src)))
+    return sorted(set(re.findall(r"\b(?:int|long)\s+(gr_[a-z0-9_]+)\s*\(", src)))
 
 
 def test_header_symbols_are_exported_and_typed():
@@ -22,7 +22,7 @@ def test_header_symbols_are_exported_and_typed():
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/groma_hip.h but not exported"
     assert set(names) == set(_lib.SIGNATURES), "ctypes signature table out of sync with the header"
-    assert _lib.load().gr_abi_version() == 4
+    assert _lib.load().gr_abi_version() == 5
 
 
 def test_bad_arguments_are_rejected_without_a_gpu():
@@ -33,7 +33,13 @@ def test_bad_arguments_are_rejected_without_a_gpu():
     d = _lib.GemmDesc()
     assert lib.gr_gemm_bf16(ctypes.byref(d), None) == 22
     assert lib.gr_topk_desc(None, None, 1, 10, 5, 10, None) == 22
-    assert lib.gr_nms_f32(None, None, 1, 10, 0.5, 0.0, 10, None, None, None, None) == 22
+    assert lib.gr_nms_f32(None, None, 1, 10, 0.5, 0.0, 10, None, None, None, None, None) == 22
+    assert lib.gr_nms_workspace_bytes(2, 300) == 0 and lib.gr_nms_workspace_bytes(2, 513) > 2 * 4096 * 64 * 8
+    assert lib.gr_nms(None, None, 10, 0.5, 0, None, None, None, None) == 22
+    assert lib.gr_nms(None, None, 10, 0.5, 2, None, None, None, None) == 22  # offset must be 0 or 1
+    assert lib.gr_roi_align_forward(None, None, None, None, None, 0, 8, 4, 4, 2, 2, 1.0, 2, 1, 1, None) == 0  # K = 0
+    assert lib.gr_roi_align_forward(None, None, None, None, None, 3, 8, 4, 4, 2, 2, 1.0, 2, 1, 1, None) == 22
+    assert lib.gr_roi_align_forward(None, None, None, None, None, 3, 8, 4, 4, 2, 2, 1.0, 2, 7, 1, None) == 22  # pool_mode
     assert lib.gr_roi_align_pack(None, None, None, 0, 8, 4, 4, 14, 14, 1.0, 2, 1, 1, 0, None) == 0  # empty ROI set is fine
     assert lib.gr_roi_align_pack(None, None, None, 3, 8, 4, 4, 14, 14, 1.0, 2, 1, 1, 0, None) == 22
     assert lib.gr_attention_bf16(None, None, None, None, None, 1, 1, 1, 1, 64, 64, 0, 0, 1.0, None, 0, 0, None, None, None) == 22

@@ -44,24 +44,29 @@ def test_proposer_chained_exact_indices(setup):
     assert util.relerr(dbg["src"], det["src"]) < 2e-4
     assert util.relerr(dbg["memory"], det["memory"]) < 2e-4
     assert util.relerr(dbg["enc_class"], det["enc_class"]) < 2e-4
-    # guard: exact index equality is only meaningful if the oracle's ranking has no near-ties
-    srt = torch.sort(det["enc_class"], dim=1, descending=True)[0][:, : idx.shape[1] + 1]
-    gap = (srt[:, :-1] - srt[:, 1:]).min().item()
+    # Ranking check that never skips: every device top-k slot must hold an element whose ORACLE logit equals the oracle's
+    # value at that rank within 2x the measured fp32 evaluation error (a valid ranking), and the ids must be torch.equal
+    # on every slot whose oracle neighbours are further apart than 4x that error.  (Bit-exact equality of ALL 300 ids on
+    # committed near-tie-free seeds at the reference depth 6+6: tests/test_fullwidth_parity_gpu.py.)
+    Q = idx.shape[1]
+    srt = torch.sort(det["enc_class"], dim=1, descending=True, stable=True)[0]
     err = (dbg["enc_class"].cpu() - det["enc_class"]).abs().max().item()
-    print("topk min gap", gap, "max abs err", err)
-    if gap > 4 * err:
-        assert torch.equal(idx.cpu().long(), det["topk_idx"])
+    got = det["enc_class"].gather(1, idx.cpu().long())
+    assert (got - srt[:, :Q]).abs().max().item() <= 2 * err + 1e-7
+    gaps = srt[:, :Q] - srt[:, 1:Q + 1]
+    clear = (gaps > 4 * err) & (torch.cat([torch.ones_like(gaps[:, :1]), gaps[:, :-1]], 1) > 4 * err)
+    print("topk min gap", gaps.min().item(), "max abs err", err, "clear slots", int(clear.sum()), "/", clear.numel())
+    assert clear.float().mean() > 0.8
+    assert torch.equal(idx.cpu().long()[clear], det["topk_idx"][clear])
+    if bool(clear.all()):
         assert util.relerr(pred, det["pred_boxes"]) < 2e-4
-        ref_scores = O.fuse_scores(det["logits_coco"], det["logits_sa1b"])
-        assert util.relerr(scores, ref_scores) < 2e-4
-    else:
-        pytest.skip("seed has a near-tie in the two-stage ranking; exact-index check not meaningful")
+        assert util.relerr(scores, O.fuse_scores(det["logits_coco"], det["logits_sa1b"])) < 2e-4
 
 
 def test_full_forward_chained(setup):
     cfg, sd, tk, model, images, ids = setup
     torch.manual_seed(77)
-    out = model.forward(input_ids=ids.clone(), images=images, return_dict=True, output_hidden_states=True)
+    out = model.forward(input_ids=ids.clone(), images=images, return_dict=True, output_hidden_states=True, use_cache=True)
     aux = model._last_aux
     dev_h = [model._ws.get(f"vit_h{i}", (2, model.vit.T, model.vit.D), torch.float32).cpu() for i in range(4)]
     torch.manual_seed(77)
@@ -114,33 +119,100 @@ def test_forward_with_refer_and_ground_boxes(setup):
     finally:
         (model.config.max_region_num,) = old
     assert torch.equal(model._last_aux["nms_keep"][0], ref["nms_inds"][0])
+    # the caller's input_ids are rewritten in place exactly as the reference does (groma.py:295,307): same <r_k> ids
+    assert torch.equal(ids_d.cpu(), ref["rewritten_ids"])
     assert ids_d[0, 40].item() in tk.box_idx_token_ids and ids_d[0, 42].item() in tk.box_idx_token_ids
+    assert torch.equal(model._last_aux["input_ids"], ref["input_ids"])  # spliced ids incl. ragged N_i and right padding
     assert util.relerr(out.logits, ref["logits"]) < 2e-2
     assert out.logits.shape == ref["logits"].shape
 
 
-def test_generate_matches_oracle_greedy(setup):
+MIN_MARGIN = 0.05  # abs logit error of the bf16 path on these weights is ~1e-2 (test_full_forward_chained)
+
+
+def _oracle_generate(setup, ids, images, n, seed, eos):
+    cfg, sd, tk, model = setup[:4]
+    bs = ids.shape[0]
+    dev_h = [model._ws.get(f"vit_h{i}", (bs, model.vit.T, model.vit.D), torch.float32).cpu() for i in range(4)]
+    torch.manual_seed(seed)
+    return O.greedy_generate(sd, cfg.to_dict(), util.tok_dict(tk), ids.clone(), images, n, eos_token_id=eos,
+                             hidden_states=tuple(dev_h))
+
+
+@pytest.mark.parametrize("graph", [True, False])
+def test_generate_matches_oracle_greedy(setup, graph):
+    """EVERY generated token against HF-greedy over the oracle (R: groma/eval/eval_rec.py:93-104), not just the first."""
     cfg, sd, tk, model, images, ids = setup
-    torch.manual_seed(9)
-    g = model.generate(ids.clone(), images=images, use_cache=True, do_sample=False, max_new_tokens=3,
-                       return_dict_in_generate=True, output_hidden_states=True, generation_config=model.generation_config)
-    assert g.sequences.shape == (2, ids.shape[1] + 3)
+    n = 6
+    gc = model.generation_config
+    old = (gc.eos_token_id, model.decode_graph)
+    try:
+        gc.eos_token_id, model.decode_graph = None, graph
+        torch.manual_seed(9)
+        g = model.generate(ids.clone(), images=images, use_cache=True, do_sample=False, max_new_tokens=n,
+                           return_dict_in_generate=True, output_hidden_states=True, generation_config=gc)
+    finally:
+        gc.eos_token_id, model.decode_graph = old
+    assert g.sequences.shape == (2, ids.shape[1] + n)
     assert torch.equal(g.sequences[:, : ids.shape[1]].cpu(), ids)
     boxes = g.hidden_states[0][-1]['pred_boxes']
     assert len(boxes) == 2 and boxes[0].shape == (100, 4)
-    dev_h = [model._ws.get(f"vit_h{i}", (2, model.vit.T, model.vit.D), torch.float32).cpu() for i in range(4)]
-    torch.manual_seed(9)
-    ref = O.greedy_generate(sd, cfg.to_dict(), util.tok_dict(tk), ids.clone(), images, 3, eos_token_id=2,
-                            hidden_states=tuple(dev_h))
-    # token ids: exact unless the oracle's own top-2 margin at that step is inside the bf16 error band
-    same = (g.sequences.cpu() == ref["sequences"])
-    print("generated", g.sequences[:, -3:].tolist(), "oracle", ref["sequences"][:, -3:].tolist())
-    assert same[:, : ids.shape[1]].all()
-    # first generated token: must equal the oracle's wherever the oracle's own top-2 margin at the last prefill position
-    # is resolvable under bf16 compute (abs logit error is ~1e-2 on these weights; see test_full_forward_chained)
-    top2 = ref["prefill"]["logits"][:, -1].topk(2, dim=-1).values
-    clear = (top2[:, 0] - top2[:, 1]) > 0.05
-    assert same[:, ids.shape[1]][clear].all(), "first generated token differs from the oracle on a clear-margin row"
+    ref = _oracle_generate(setup, ids, images, n, 9, eos=-1)
+    for i in range(2):
+        assert torch.allclose(boxes[i].cpu(), ref["pred_boxes"][i], atol=1e-5)  # the order <r_j> indexes
+    P = ids.shape[1]
+    ncmp = util.assert_greedy_tokens_match(g.sequences[:, P:].cpu(), ref["sequences"][:, P:], ref["margins"], MIN_MARGIN, "generate")
+    print("generated", g.sequences[:, P:].tolist(), "oracle", ref["sequences"][:, P:].tolist(), "compared", ncmp,
+          "margins", ref["margins"].tolist())
+    assert ncmp >= n  # at least one full row's worth of tokens was resolvable
+
+
+def test_generate_ragged_right_padded_batch_matches_oracle(setup):
+    """HF greedy over a RIGHT-padded batch takes the arg-max of the last (pad) position of the shorter row and
+    decodes every row at the same position with an all-ones mask (R: groma/model/groma.py:376-379).  Reproduced, not
+    fixed: the device tokens must equal the oracle's on the padded row too."""
+    cfg, sd, tk, model, images, ids = setup
+    ids = ids.clone()
+    ids[1, -9:] = tk.pad_token_id
+    n = 4
+    gc = model.generation_config
+    old = gc.eos_token_id
+    try:
+        gc.eos_token_id = None
+        torch.manual_seed(21)
+        g = model.generate(ids.clone(), images=images, max_new_tokens=n, return_dict_in_generate=True)
+    finally:
+        gc.eos_token_id = old
+    ref = _oracle_generate(setup, ids, images, n, 21, eos=-1)
+    assert ref["prefill"]["attention_mask"][1].sum() < ref["prefill"]["attention_mask"][0].sum()  # really ragged
+    P = ids.shape[1]
+    ncmp = util.assert_greedy_tokens_match(g.sequences[:, P:].cpu(), ref["sequences"][:, P:], ref["margins"], MIN_MARGIN, "ragged")
+    print("ragged generated", g.sequences[:, P:].tolist(), "oracle", ref["sequences"][:, P:].tolist(), "compared", ncmp)
+    assert ncmp >= 2
+
+
+def test_generate_eos_padding_matches_oracle(setup):
+    """finished rows emit pad, the loop stops when every row is finished (HF greedy_search bookkeeping)"""
+    cfg, sd, tk, model, images, ids = setup
+    gc = model.generation_config
+    old = (gc.eos_token_id, getattr(gc, "pad_token_id", None))
+    try:
+        gc.eos_token_id = None
+        torch.manual_seed(9)
+        free = model.generate(ids.clone(), images=images, max_new_tokens=6).cpu()
+        eos = int(free[0, ids.shape[1] + 1])  # row 0's second token becomes EOS
+        gc.eos_token_id, gc.pad_token_id = eos, tk.pad_token_id
+        torch.manual_seed(9)
+        got = model.generate(ids.clone(), images=images, max_new_tokens=6).cpu()
+    finally:
+        gc.eos_token_id, gc.pad_token_id = old
+    ref = _oracle_generate(setup, ids, images, 6, 9, eos=eos)
+    P = ids.shape[1]
+    if bool((ref["margins"] >= MIN_MARGIN).all()):
+        assert torch.equal(got, ref["sequences"])
+    else:
+        util.assert_greedy_tokens_match(got[:, P:], ref["sequences"][:, P:], ref["margins"], MIN_MARGIN, "eos")
+    assert (got[0, P + 2:] == tk.pad_token_id).all()
 
 
 @pytest.mark.parametrize("eos", [None, "from_eager"])
@@ -166,7 +238,8 @@ def test_generate_graph_equals_eager(setup, eos):
             torch.manual_seed(9)
             out = model.generate(ids.clone(), images=images, max_new_tokens=12, return_dict_in_generate=True)
             assert torch.equal(out.sequences.cpu(), eager), (out.sequences[:, ids.shape[1]:].tolist(), eager[:, ids.shape[1]:].tolist())
-            assert out.past_key_values.seq_len == out.past_key_values.seq_len  # arena stays readable
+            # arena stays readable: expanded prompt + every new token but the last one
+            assert out.past_key_values.seq_len == model._last_aux["input_ids"].shape[1] + eager.shape[1] - ids.shape[1] - 1
         if eos == "from_eager":
             assert eager.shape[1] <= ids.shape[1] + 12
             assert (eager[0, ids.shape[1] + 3:] == 0).all()  # finished row pads

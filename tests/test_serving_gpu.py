@@ -33,6 +33,38 @@ def _solo_generate(model, ids, image, n, seed):
     return out[0, ids.shape[0]:].tolist()
 
 
+def test_batcher_rows_match_oracle_greedy(setup):
+    """ContinuousBatcher against the ORACLE (not against generate()): each request's tokens must equal HF greedy over the
+    CPU restatement run at batch 1 on that request (R: groma/serve/model_worker.py:287-338), under the margin rule of
+    tests/util.assert_greedy_tokens_match.  Requests are served two at a time, so rows share decode steps."""
+    from groma_amd.serving import ContinuousBatcher
+    from groma_amd import synth
+    from oracle import groma_oracle as O
+    cfg, model, reqs = setup
+    cfg0, sd, tk = util.tiny_setup(seed=0)  # the same seeded state dict the device model was built from
+    b = ContinuousBatcher(model, max_rows=2, max_len=1024)
+    total = 0
+    for ids, image, n, seed in reqs[:3]:
+        n = min(n, 8)
+        other = b.submit(*reqs[4][:2], max_new_tokens=20, seed=reqs[4][3])  # a neighbour decoding alongside
+        rid = b.submit(ids, image, max_new_tokens=n, seed=seed)
+        b.run_until_done()
+        r = b.result(rid)
+        assert r.error is None and r.done and len(r.tokens) == n
+        # the oracle consumes the device ViT states of THIS request (stage chaining, as in test_parity_gpu)
+        torch.manual_seed(seed)
+        dev_h = tuple(h.cpu() for h in model.vit.forward(image[None].cuda().float()))
+        torch.manual_seed(seed)
+        ref = O.greedy_generate(sd, cfg0.to_dict(), util.tok_dict(tk), ids[None].clone(), image[None], n, eos_token_id=-1,
+                                hidden_states=dev_h)
+        assert torch.allclose(r.pred_boxes.cpu(), ref["pred_boxes"][0], atol=1e-5)
+        P = ids.shape[0]
+        total += util.assert_greedy_tokens_match(torch.tensor([r.tokens]), ref["sequences"][:, P:], ref["margins"], 0.05,
+                                                 f"serving rid {rid}")
+        b.result(other)
+    assert total >= 8
+
+
 def test_single_row_batcher_equals_generate(setup):
     from groma_amd.serving import ContinuousBatcher
     cfg, model, reqs = setup
