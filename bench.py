@@ -45,42 +45,63 @@ def flops_per_image(cfg, N, P):
     return dict(vit=vit, bridge=bridge, ddetr=ddetr, region=region, llm=llm, total=vit + bridge + ddetr + region + llm, L=L)
 
 
-def cpu_baseline(cfg_name, threads=None):
-    """Oracle (plain PyTorch fp32 restatement, oracle/groma_oracle.py) timed on this box's host cores on a bounded
-    sample: ONE image through full-width but reduced-depth stages (2 of 24 ViT layers, 1 of 5 fusion rounds, 1 of
-    32 LLaMA layers), per-layer times scaled to the full depth."""
+class _AliasedLayers(dict):
+    """state dict whose per-layer entries of the three deep stacks all resolve to layer 0: a FULL-DEPTH oracle forward then
+    needs one materialised layer per stack (3 GB instead of 30 GB of host RAM, seconds instead of minutes of randn) while
+    executing every layer's arithmetic and memory traffic -- the weights of a 0.8 GB layer never stay in cache anyway."""
+    import re as _re
+    _pat = _re.compile(r"(vis_encoder\.encoder\.layer|mlvl_fuse\.fuse_convs|llm\.model\.layers)\.\d+\.")
+
+    def _k(self, k):
+        return self._pat.sub(lambda m: m.group(1) + ".0.", k)
+
+    def __getitem__(self, k):
+        return dict.__getitem__(self, self._k(k))
+
+    def get(self, k, default=None):
+        return dict.get(self, self._k(k), default)
+
+    def __contains__(self, k):
+        return dict.__contains__(self, self._k(k))
+
+
+def cpu_baseline(cfg_name, threads=None, full_reps=1):
+    """The oracle (plain PyTorch fp32 restatement, oracle/groma_oracle.py) on this box's host cores, ONE image.
+      value  = a MEASURED full-depth forward (24 ViT layers, 6+6 DDETR, NMS, 5 fusion rounds, RoI extraction, 32 LLaMA
+               layers, 32 114-wide head over all 582 positions), median of `full_reps` runs (default 1: ~40 s of CPU work;
+               the reduced-depth pass just before it is the warm-up).  Layer weights of the three deep stacks are aliased
+               to one materialised layer each (_AliasedLayers) -- same arithmetic, bounded host RAM.
+      sample = also carries the round-1 style extrapolation (reduced depth x layer counts) for comparison."""
     from groma_amd import config as gconfig, synth
     from oracle import groma_oracle as O
     if threads:
         torch.set_num_threads(threads)
     full = gconfig.groma_7b(box_score_thres=0.0) if cfg_name == "7b" else gconfig.groma_tiny(box_score_thres=0.0)
     nv, nf, nl = full.perceiver_cfg.vis_encoder_cfg.num_hidden_layers, full.region_cfg.num_fuse, full.llm_cfg.num_hidden_layers
-    small = gconfig.GromaConfig(**{**full.to_dict(), "vocab_size": None}) if False else None
     d = full.to_dict()
     d.pop("vocab_size")
-    d["perceiver_cfg"]["vis_encoder_cfg"]["num_hidden_layers"] = min(2, nv)
+    d["perceiver_cfg"]["vis_encoder_cfg"]["num_hidden_layers"] = 1
     d["region_cfg"]["num_fuse"] = 1
     d["llm_cfg"]["num_hidden_layers"] = 1
     small = gconfig.GromaConfig(**d)
-    sd = synth.make_state_dict(small, 0)
+    sd = _AliasedLayers(synth.make_state_dict(small, 0))
     cd = small.to_dict()
-
-    class Tok:
-        pass
     from tests.util import TokenIds, tok_dict
     tk = TokenIds()
     images, ids = synth.make_inputs(small, tk, 1, seed=1234)
 
     def timed(fn):
-        fn()  # warm-up
         t = time.perf_counter()
         r = fn()
         return time.perf_counter() - t, r
 
     with torch.no_grad():
-        nvs = small.perceiver_cfg.vis_encoder_cfg.num_hidden_layers
-        t_vit, hs = timed(lambda: O.vit_forward(sd, cd, images))
-        t_vit_full = t_vit / nvs * nv
+        # reduced depth (one layer of each deep stack), per-stage -> extrapolation + warm-up of the thread pool
+        O.vit_forward(sd, cd, images)
+        t_vit, hs4 = timed(lambda: O.vit_forward(sd, cd, images))
+        cd2 = full.to_dict()
+        cd2["perceiver_cfg"]["vis_encoder_cfg"]["num_hidden_layers"] = 3  # 4 states for the proposer (aliased weights)
+        hs = O.vit_forward(sd, cd2, images)
         t_det, det = timed(lambda: O.ddetr_forward(sd, cd, O.ddetr_inputs_from_hidden(hs)))
         scores = O.fuse_scores(det["logits_coco"], det["logits_sa1b"])
         torch.manual_seed(0)
@@ -88,18 +109,28 @@ def cpu_baseline(cfg_name, threads=None):
         mlvl = [h[:, 1:] for h in hs[-3:]]
         t_fuse, feats = timed(lambda: O.region_fuse(sd, cd, mlvl))
         t_roi, reg = timed(lambda: O.roi_extract(sd, cd, feats, sel))
-        # one fusion round ~ t_fuse minus the input conv share; scale the 3x3 rounds to full depth
-        t_region_full = t_fuse * nf + t_roi
         L = ids.shape[1] - 2 + 256 + 2 * len(sel[0])
         emb = torch.randn((1, L, small.llm_cfg.hidden_size)) * 0.02
         t_llm, (hid, _) = timed(lambda: O.llama_forward(sd, cd, emb, torch.ones((1, L))))
         t_head, _ = timed(lambda: O.lm_logits(sd, hid))
-        t_llm_full = t_llm * nl + t_head
-    total = t_vit_full + t_det + t_region_full + t_llm_full
-    return {"value": 1.0 / total, "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"1 image, full width, timed depth: {nvs}/{nv} ViT layers, 1/{nf} fusion rounds, 1/{nl} LLaMA layers "
-                      f"(scaled to full depth); stage seconds/image: vit {t_vit_full:.2f}, ddetr {t_det:.2f}, "
-                      f"region {t_region_full:.2f}, llm {t_llm_full:.2f}"}
+        extrap = t_vit * nv + t_det + t_fuse * nf + t_roi + t_llm * nl + t_head
+        # the measurement: a full-depth forward through the oracle's own entry point
+        fd = full.to_dict()
+        runs = []
+        for _ in range(max(1, full_reps)):
+            torch.manual_seed(0)
+            t, ref = timed(lambda: O.groma_forward(sd, fd, tok_dict(tk), ids.clone(), images))
+            runs.append(t)
+        runs.sort()
+        t_full = runs[len(runs) // 2]
+        assert ref["logits"].shape[1] == L
+    return {"value": 1.0 / t_full, "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
+            "seconds_per_image": t_full,
+            "sample": f"1 image, MEASURED full-depth fp32 oracle forward ({nv} ViT layers, {full.perceiver_cfg.ddetr_cfg.encoder_layers}+{full.perceiver_cfg.ddetr_cfg.decoder_layers} DDETR, NMS, {nf} fusion rounds, "
+                      f"{len(sel[0])} regions, {nl} LLaMA layers, logits for all {L} positions), median of {len(runs)} run(s) "
+                      f"after a reduced-depth warm-up; per-layer weights of the deep stacks aliased to one layer each. "
+                      f"For comparison, reduced-depth extrapolation: {extrap:.1f} s/image "
+                      f"(vit {t_vit * nv:.2f}, ddetr {t_det:.2f}, region {t_fuse * nf + t_roi:.2f}, llm {t_llm * nl + t_head:.2f})"}
 
 
 def main():
@@ -119,7 +150,12 @@ def main():
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise the RCCL process group and run the per-step all-gather even with one rank (smoke test of "
                          "the N>1 path on a 1-GPU box; launch under torch.distributed.run --nproc-per-node 1)")
+    ap.add_argument("--global-batch", type=int, default=0,
+                    help="STRONG scaling: a fixed number of images per step, sharded over the ranks (groma_amd.dist.shard_range) and "
+                         "processed in micro-batches of --batch.  BASELINE configs[3] = --mode generate --global-batch 32 --batch 4 "
+                         "(4 images per GPU at 8 ranks).  0 (default) = weak scaling, --batch images on every rank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-reps", type=int, default=1, help="timed full-depth oracle forwards (median is reported)")
     ap.add_argument("--gemm-breakdown", default=None, help="write a per-shape GEMM table (from the HIP-event hook) here")
     args = ap.parse_args()
 
@@ -130,62 +166,49 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    dist = None
     use_dist = world > 1 or args.force_dist
-    if use_dist:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
 
-    from groma_amd import config as gconfig, constants, ops, synth
+    from groma_amd import config as gconfig, constants, dist as gdist, ops, synth
     from groma_amd.groma import GromaModel
+    if use_dist:
+        gdist.init("nccl", dev)  # RCCL over xGMI; rendezvous on 127.0.0.1 unless the launcher says otherwise
 
     cfg = gconfig.groma_7b(box_score_thres=0.0) if args.config == "7b" else gconfig.groma_tiny(box_score_thres=0.0)
     fp8 = args.dtype == "fp8"
     model = GromaModel.from_synthetic(cfg, seed=0, device=dev, fp8=fp8)
     model.init_special_token_id(constants.SyntheticTokenizer())
     P = 128
-    images, ids = synth.make_inputs(cfg, model, args.batch, seed=1234 + rank, prompt_len=P)
+    gen = args.mode == "generate"
+    strong = args.global_batch > 0
+    # the per-rank driver (shard bookkeeping, ONE all-gather of the per-image rows per step, barrier + max-over-ranks
+    # timing) is groma_amd.dist.ShardedJob -- the same code tests/test_dist_gloo.py runs with 2 gloo ranks
+    row = (P + args.new_tokens,) if gen else (100,)
+    job = gdist.ShardedJob(dev, row, torch.int64 if gen else torch.float32,
+                           **(dict(global_batch=args.global_batch) if strong else dict(rows_per_rank=args.batch)))
+    if strong:   # the same global images whatever the world size; this rank keeps its shard
+        images, ids = synth.make_inputs(cfg, model, job.global_batch, seed=1234, prompt_len=P)
+        images, ids = images[job.lo:job.hi], ids[job.lo:job.hi]
+    else:
+        images, ids = synth.make_inputs(cfg, model, args.batch, seed=1234 + rank, prompt_len=P)
     images, ids = images.to(dev), ids.to(dev)
     r0 = model.box_idx_token_ids[0]
-    gathered = torch.empty((world * args.batch, 100), dtype=torch.float32, device=dev) if use_dist else None
-
-    gen = args.mode == "generate"
+    chunks = [(lo, min(lo + args.batch, job.rows)) for lo in range(0, job.rows, args.batch)]
     if gen:
         model.generation_config.eos_token_id = None  # random-init weights: fixed-length decode, never an early stop
-        gathered_ids = torch.empty((world * args.batch, P + args.new_tokens), dtype=torch.int64, device=dev) if use_dist else None
 
     def step(i):
         torch.manual_seed(1000 + i)  # the path draws torch.randperm (T4)
-        if gen:
-            seq = model.generate(ids, images=images, max_new_tokens=args.new_tokens)
-            if use_dist:
-                dist.all_gather_into_tensor(gathered_ids, seq.contiguous())
-            return seq
-        logits, _ = model.forward(input_ids=ids, images=images, use_cache=False)
-        region_logits = logits[:, -1, r0:r0 + 100].contiguous()
-        if use_dist:
-            dist.all_gather_into_tensor(gathered, region_logits)
-        return region_logits
+        rows = []
+        for lo, hi in chunks:
+            if gen:
+                rows.append(model.generate(ids[lo:hi], images=images[lo:hi], max_new_tokens=args.new_tokens))
+            else:
+                logits, _ = model.forward(input_ids=ids[lo:hi], images=images[lo:hi], use_cache=False)
+                rows.append(logits[:, -1, r0:r0 + 100])
+        local = rows[0] if len(rows) == 1 else torch.cat(rows)
+        return job.exchange(local.contiguous())
 
-    def barrier():
-        torch.cuda.synchronize()
-        if use_dist:
-            dist.barrier()
-            torch.cuda.synchronize()
-
-    for i in range(args.warmup):
-        step(i)
-    barrier()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(args.warmup + i)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if use_dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = job.timed(step, args.warmup, args.steps)
 
     # ---- roofline leg: the same steps again with HIP events around every GEMM launch (on the launch stream) ----
     n_reg = [b.shape[0] for b in model._last_aux["sel_idx"]]
@@ -217,15 +240,17 @@ def main():
     gemm_flops = sum(2.0 * r[0] * r[1] * r[2] for r in dom)
     # HBM-side traffic of the dominant kernel: rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE, separate runs, gfx950
     # correction applied) of THIS command, summarised under profiles/ -- bench.py cannot drive the profiler itself
-    traffic = None
+    traffic, traffic_file = None, None
     try:
-        with open(os.path.join(ROOT, "profiles", f"r01_pmc_traffic_b{args.batch}.json")) as f:
-            pm = json.load(f)["kernels"]
-        if args.config == "7b" and not fp8:
-            traffic = pm["gemm_bf16_256_kernel(GemmArgs)"]["traffic_bytes_per_launch"]
+        import glob
+        cands = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_pmc_traffic_b{args.batch}.json")))
+        if cands and args.config == "7b" and not fp8 and not gen:
+            traffic_file = os.path.basename(cands[-1])  # the newest round's counters
+            with open(cands[-1]) as f:
+                traffic = json.load(f)["kernels"]["gemm_bf16_256_kernel(GemmArgs)"]["traffic_bytes_per_launch"]
     except Exception:
         traffic = None
-    ips = world * args.batch * args.steps / elapsed
+    ips = job.global_batch * args.steps / elapsed
     peak = 5000.0 if fp8 else 2500.0  # dense MFMA peak of the operand type (MI355X_MICROARCH.md)
     kname = "gemm_fp8_256_kernel(GemmArgs) -- 256x256 ping-pong e4m3 MFMA GEMM" if fp8 else \
         "gemm_bf16_256_kernel(GemmArgs) -- 256x256 ping-pong MFMA GEMM incl. implicit-GEMM 3x3 convs"
@@ -233,18 +258,20 @@ def main():
     out = {
         "metric": "images/sec end-to-end forward (448px, 300 proposals, 128 tok)",
         "value": ips, "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong" if strong else "weak",
+        "vs_baseline": None,
         "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": "configs[2]: full Groma-7B forward (DINOv2-L + DDETR 300 proposals -> NMS 100 regions + "
                                "region encoder + Vicuna-7B prefill, logits for all positions), random-init weights"
                                if args.config == "7b" else "tiny parity architecture (NOT the headline workload)",
-                   "images_per_gpu": args.batch, "global_batch": world * args.batch, "prompt_tokens": P,
+                   "images_per_gpu": job.rows, "images_per_forward_call": min(args.batch, job.rows),
+                   "global_batch": job.global_batch, "prompt_tokens": P,
                    "llm_seq_len": fl["L"], "regions_per_image": sum(n_reg) / len(n_reg),
                    "parallelism": f"dp{world} (image batch sharded, full replica per GPU)"},
         "roofline": {"bound": "mfma", "kernel": kname,
                      "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
                      "traffic_note": "bytes/launch of gemm_bf16_256_kernel at the L2<->fabric boundary (Infinity-Cache hits "
-                                     "included), rocprofv3 PMC, profiles/r01_pmc_traffic_b%d.json" % args.batch if traffic else None,
+                                     "included), rocprofv3 PMC passes of this command committed as profiles/%s" % traffic_file if traffic else None,
                      "launches_per_step": gemm_launches / max(args.steps, 1),
                      "avg_launch_us": gemm_ms * 1e3 / max(gemm_launches, 1),
                      "flops_per_launch": gemm_flops / max(gemm_launches, 1),
@@ -252,8 +279,8 @@ def main():
                      "all_gemm_kernels": {"achieved": all_flops / (all_ms * 1e-3) / 1e12 if all_ms > 0 else 0.0,
                                           "launches_per_step": len(recs) / max(args.steps, 1),
                                           "time_share_of_step": (all_ms / args.steps) / (elapsed / args.steps * 1e3)},
-                     "e2e_algorithmic_tflops_per_gpu": fl["total"] * args.batch * args.steps / elapsed / 1e12,
-                     "e2e_frac_of_peak": fl["total"] * args.batch * args.steps / elapsed / 1e12 / peak},
+                     "e2e_algorithmic_tflops_per_gpu": fl["total"] * job.rows * args.steps / elapsed / 1e12,
+                     "e2e_frac_of_peak": fl["total"] * job.rows * args.steps / elapsed / 1e12 / peak},
     }
     if gen:  # configs[3]: the decode steps stream the bf16 weights once per token -> HBM roofline of the GEMV kernel
         gv = [r for r in recs if r[3] & 8]
@@ -273,12 +300,13 @@ def main():
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline and not gen:
             try:
-                out["cpu_baseline"] = cpu_baseline(args.config)
+                out["cpu_baseline"] = cpu_baseline(args.config, full_reps=args.cpu_baseline_reps)
             except Exception as e:  # never lose the GPU measurement to a host-side failure
                 out["cpu_baseline"] = {"value": None, "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
                                        "sample": f"failed: {type(e).__name__}: {e}"}
         print(json.dumps(out), flush=True)
     if use_dist:
+        import torch.distributed as dist
         dist.destroy_process_group()
 
 

@@ -22,6 +22,8 @@ def init(backend=None, device=None):
         return dist
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29511")
+    os.environ.setdefault("RANK", "0")
+    os.environ.setdefault("WORLD_SIZE", "1")
     backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")
     kw = {"device_id": device} if (backend == "nccl" and device is not None) else {}
     dist.init_process_group(backend, **kw)
@@ -51,3 +53,68 @@ def region_logits(logits, box_idx_token_ids):
     """last-position logits restricted to the <r_i> vocabulary slice (SURVEY §8 'Region logits')."""
     r0 = box_idx_token_ids[0]
     return logits[:, -1, r0:r0 + len(box_idx_token_ids)].float().contiguous()
+
+
+class ShardedJob:
+    """The per-rank driver of an image-sharded job -- what bench.py runs, and what tests/test_dist_gloo.py runs under gloo.
+
+    One process per GPU, a full replica each; `rows` images of the global batch live on this rank (weak scaling: the same
+    count everywhere; strong scaling: shard_range of a fixed global batch, possibly ragged).  A step = local forward of the
+    shard + ONE all-gather of the per-image result rows into a preallocated buffer (no allocation, no host sync inside the
+    timed region).  Timing follows the driver's contract: barrier + device sync on both sides, MAX over ranks."""
+
+    def __init__(self, device, row_shape, dtype, global_batch=None, rows_per_rank=None):
+        import torch.distributed as dist
+        self.dist = dist if dist.is_initialized() else None
+        self.world = dist.get_world_size() if self.dist else 1
+        self.rank = dist.get_rank() if self.dist else 0
+        self.device = torch.device(device)
+        if global_batch is not None:   # strong scaling: a fixed global batch split over the ranks
+            self.counts = [shard_range(global_batch, self.world, r)[1] - shard_range(global_batch, self.world, r)[0]
+                           for r in range(self.world)]
+            self.lo, self.hi = shard_range(global_batch, self.world, self.rank)
+        else:                          # weak scaling: rows_per_rank images on every rank
+            self.counts = [int(rows_per_rank)] * self.world
+            self.lo, self.hi = self.rank * rows_per_rank, (self.rank + 1) * rows_per_rank
+        self.rows = self.counts[self.rank]
+        self.global_batch = sum(self.counts)
+        self.max_rows = max(self.counts)
+        self.row_shape = tuple(row_shape)
+        self._send = torch.zeros((self.max_rows,) + self.row_shape, dtype=dtype, device=self.device)
+        self._recv = torch.zeros((self.world * self.max_rows,) + self.row_shape, dtype=dtype, device=self.device)
+
+    def exchange(self, local_rows):
+        """local_rows [rows, *row_shape] -> view [global_batch, *row_shape] of every rank's rows, in image order."""
+        if self.dist is None:
+            return local_rows
+        if local_rows.shape[0] == self.max_rows and len(set(self.counts)) == 1:
+            self.dist.all_gather_into_tensor(self._recv, local_rows.contiguous())
+            return self._recv
+        self._send[: local_rows.shape[0]].copy_(local_rows)
+        self.dist.all_gather_into_tensor(self._recv, self._send)
+        return torch.cat([self._recv[r * self.max_rows: r * self.max_rows + c] for r, c in enumerate(self.counts)])
+
+    def barrier(self):
+        if self.device.type == "cuda":
+            torch.cuda.synchronize(self.device)
+        if self.dist is not None:
+            self.dist.barrier()
+            if self.device.type == "cuda":
+                torch.cuda.synchronize(self.device)
+
+    def timed(self, step_fn, warmup, steps):
+        """W untimed + exactly K timed calls of step_fn(i); returns seconds, MAX over ranks."""
+        import time
+        for i in range(warmup):
+            step_fn(i)
+        self.barrier()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            step_fn(warmup + i)
+        self.barrier()
+        elapsed = time.perf_counter() - t0
+        if self.dist is not None:
+            t = torch.tensor([elapsed], dtype=torch.float64, device=self.device)
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        return elapsed

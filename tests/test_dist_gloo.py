@@ -27,7 +27,20 @@ def _worker(rank, world, port, q):
     gt = [torch.tensor([[0.5, 0.5, 0.2, 0.2]])] * seq.shape[0]
     m.update(seq, 2, box, gt, tok)
     summ = m.summary()
-    q.put((rank, torch.equal(got, full * 2.0) and summ["count"] == 3 and abs(summ["iou@0.5 accu"] - 1 / 3) < 1e-12
+    # bench.py's own per-step driver (groma_amd.dist.ShardedJob): weak shard (even) and strong shard (ragged 5 over 2)
+    ok_job = True
+    for kw in (dict(rows_per_rank=3), dict(global_batch=5)):
+        job = gdist.ShardedJob("cpu", (100,), torch.float32, **kw)
+        ref = torch.arange(job.global_batch * 100, dtype=torch.float32).view(job.global_batch, 100)
+        calls = []
+
+        def step(i, job=job, ref=ref, calls=calls):
+            calls.append(i)
+            return job.exchange(ref[job.lo:job.hi] * (i + 1.0))
+        elapsed = job.timed(step, warmup=1, steps=3)
+        ok_job = ok_job and calls == [0, 1, 2, 3] and elapsed > 0 and job.rows == job.hi - job.lo
+        ok_job = ok_job and torch.equal(step(4), ref * 5.0) and sum(job.counts) == job.global_batch
+    q.put((rank, ok_job and torch.equal(got, full * 2.0) and summ["count"] == 3 and abs(summ["iou@0.5 accu"] - 1 / 3) < 1e-12
            and abs(summ["missing percentage"] - 1 / 3) < 1e-12, even[:, 0].tolist()))
     dist.barrier()
     dist.destroy_process_group()
