@@ -66,6 +66,9 @@ class GromaModel:
     def __init__(self, config: GromaConfig, source=None, device="cuda", fp8=False):
         self.config = config
         self.decode_graph = True  # generate(): replay one captured hipGraph per token (False = eager per-kernel launches)
+        # proposer chain (input_proj -> DDETR encoder x6 -> two-stage top-300 -> decoder x6 -> heads -> score fusion -> NMS,
+        # ~330 launches of fp32 kernels that are launch-latency-bound) captured once per batch size and replayed
+        self.proposer_graph = True
         self.fp8 = bool(fp8)  # BASELINE configs[4]: OCP e4m3 operands for the DINOv2 and LLaMA GEMMs (extension)
         self.device = torch.device(device)
         self.training = False
@@ -208,29 +211,36 @@ class GromaModel:
         """Steps C-E: DDETR proposer -> fused scores -> on-device NMS -> host randperm (one D2H of <1 KB/image)."""
         cfg = self.config
         bs = hidden4[0].shape[0]
-        pred_boxes, scores, topk_idx = self.proposer.forward(hidden4, debug=debug)
-        Q = pred_boxes.shape[1]
         dev = self.device
-        if refer_boxes is None:
-            refer_boxes = [torch.empty((0, 4), device=dev) for _ in range(bs)]
-        if ground_boxes is None:
-            ground_boxes = [torch.empty((0, 4), device=dev) for _ in range(bs)]
-        n_extra = [refer_boxes[i].shape[0] + ground_boxes[i].shape[0] for i in range(bs)]
-        nmax = Q + max(n_extra)
-        if max(n_extra) == 0:
-            boxes_all, scores_all, n_valid = pred_boxes.contiguous(), scores.contiguous(), None
+        n_extra = [(refer_boxes[i].shape[0] if refer_boxes is not None else 0) +
+                   (ground_boxes[i].shape[0] if ground_boxes is not None else 0) for i in range(bs)]
+        if self.proposer_graph and debug is None and max(n_extra) == 0:
+            # fixed shapes, no host value in any kernel argument: replay the captured chain (SURVEY 7 item 7)
+            pred_boxes, scores, topk_idx, keep, n_keep = self._propose_graph(hidden4)
+            Q = pred_boxes.shape[1]
+            boxes_all, scores_all = pred_boxes, scores
         else:
-            boxes_all = torch.zeros((bs, nmax, 4), dtype=F32, device=dev)
-            scores_all = torch.zeros((bs, nmax), dtype=F32, device=dev)
-            boxes_all[:, :Q], scores_all[:, :Q] = pred_boxes, scores
-            for i in range(bs):  # groma.py:259-264: refer boxes score 1.0, ground boxes 0.2
-                r, g = refer_boxes[i].to(dev, F32), ground_boxes[i].to(dev, F32)
-                boxes_all[i, Q:Q + len(r)], scores_all[i, Q:Q + len(r)] = r, 1.0
-                boxes_all[i, Q + len(r):Q + len(r) + len(g)] = g
-                scores_all[i, Q + len(r):Q + len(r) + len(g)] = 0.2
-            n_valid = torch.tensor([Q + e for e in n_extra], dtype=I32, device=dev)
-        keep, n_keep = ops.nms(boxes_all, scores_all, float(cfg.nms_thres), float(cfg.box_score_thres),
-                               int(cfg.max_region_num), n_valid=n_valid)
+            pred_boxes, scores, topk_idx = self.proposer.forward(hidden4, debug=debug)
+            Q = pred_boxes.shape[1]
+            if refer_boxes is None:
+                refer_boxes = [torch.empty((0, 4), device=dev) for _ in range(bs)]
+            if ground_boxes is None:
+                ground_boxes = [torch.empty((0, 4), device=dev) for _ in range(bs)]
+            nmax = Q + max(n_extra)
+            if max(n_extra) == 0:
+                boxes_all, scores_all, n_valid = pred_boxes.contiguous(), scores.contiguous(), None
+            else:
+                boxes_all = torch.zeros((bs, nmax, 4), dtype=F32, device=dev)
+                scores_all = torch.zeros((bs, nmax), dtype=F32, device=dev)
+                boxes_all[:, :Q], scores_all[:, :Q] = pred_boxes, scores
+                for i in range(bs):  # groma.py:259-264: refer boxes score 1.0, ground boxes 0.2
+                    r, g = refer_boxes[i].to(dev, F32), ground_boxes[i].to(dev, F32)
+                    boxes_all[i, Q:Q + len(r)], scores_all[i, Q:Q + len(r)] = r, 1.0
+                    boxes_all[i, Q + len(r):Q + len(r) + len(g)] = g
+                    scores_all[i, Q + len(r):Q + len(r) + len(g)] = 0.2
+                n_valid = torch.tensor([Q + e for e in n_extra], dtype=I32, device=dev)
+            keep, n_keep = ops.nms(boxes_all, scores_all, float(cfg.nms_thres), float(cfg.box_score_thres),
+                                   int(cfg.max_region_num), n_valid=n_valid)
         # one host round trip: kept indices + scores arg-max fallback (the reference syncs at nms / len / randperm too)
         keep_h, n_keep_h = keep.cpu(), n_keep.cpu()
         selected, sel_idx = [], []
@@ -252,6 +262,32 @@ class GromaModel:
         aux = dict(pred_boxes=pred_boxes, scores=scores, topk_idx=topk_idx, nms_keep=[keep_h[i, :int(n_keep_h[i])] for i in range(bs)],
                    sel_idx=sel_idx)
         return selected, aux
+
+    def _propose_graph(self, hidden4):
+        """Replay (capturing on first use) the hipGraph of the proposer chain + NMS for these input buffers.  The graph
+        reads the ViT states in place (workspace arenas: stable addresses) and owns its outputs; thresholds are baked in, so
+        the key carries them.  At most 4 graphs are kept (batch sizes seen most recently)."""
+        cfg = self.config
+        key = (tuple(h.data_ptr() for h in hidden4), tuple(hidden4[0].shape), float(cfg.nms_thres), float(cfg.box_score_thres),
+               int(cfg.max_region_num))
+        pool = self.__dict__.setdefault("_pgraphs", {})
+        ent = pool.get(key)
+        if ent is None:
+            def chain():
+                pred, scores, idx = self.proposer.forward(hidden4)
+                keep, n_keep = ops.nms(pred.contiguous(), scores.contiguous(), float(cfg.nms_thres), float(cfg.box_score_thres),
+                                       int(cfg.max_region_num))
+                return pred, scores, idx, keep, n_keep
+            chain()  # warm-up: lazy per-kernel attributes, workspaces
+            torch.cuda.synchronize(self.device)  # nothing else of this forward (side stream) may overlap the capture
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                outs = chain()
+            if len(pool) >= 4:
+                pool.pop(next(iter(pool)))
+            ent = pool[key] = (g, outs)
+        ent[0].replay()
+        return ent[1]
 
     def _splice(self, input_ids_h, n_img_tok, n_reg):
         """groma.py:317-357 on the host (index bookkeeping only)."""

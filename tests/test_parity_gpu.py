@@ -245,3 +245,26 @@ def test_generate_graph_equals_eager(setup, eos):
             assert (eager[0, ids.shape[1] + 3:] == 0).all()  # finished row pads
     finally:
         gc.eos_token_id, gc.pad_token_id, model.decode_graph = old
+
+
+def test_proposer_graph_equals_eager(setup):
+    """the hipGraph-replayed proposer chain + NMS (GromaModel.proposer_graph) is the same kernels in the same order as the
+    eager launches: bit-identical boxes, scores, top-k ids, NMS keep ids and logits, also on replay and at another batch"""
+    cfg, sd, tk, model, images, ids = setup
+    res = {}
+    for mode in (False, True, True):
+        model.proposer_graph = mode
+        for bs in (2, 1):
+            torch.manual_seed(31)
+            out = model.forward(input_ids=ids[:bs].clone(), images=images[:bs], return_dict=True)
+            aux = model._last_aux
+            cur = (aux["pred_boxes"].clone(), aux["scores"].clone(), aux["topk_idx"].clone(), [k.clone() for k in aux["nms_keep"]],
+                   out.logits.clone())
+            if (bs,) not in res:
+                res[(bs,)] = cur
+            else:
+                ref = res[(bs,)]
+                assert torch.equal(cur[0], ref[0]) and torch.equal(cur[1], ref[1]) and torch.equal(cur[2], ref[2])
+                assert all(torch.equal(a, b) for a, b in zip(cur[3], ref[3]))
+                assert torch.equal(cur[4], ref[4])
+    model.proposer_graph = True
