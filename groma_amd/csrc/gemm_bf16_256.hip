@@ -22,6 +22,7 @@
 //  * LDS image: 128-B rows, 16-B chunk position = k-chunk ^ (row & 7): written lane-linearly by the DMA with the
 //    XOR applied to the per-lane SOURCE address, mirrored on the ds_read_b128 side (conflict-free).
 #include "gemm_common.h"
+#include <cstdlib>
 
 #define T256 256
 #define NT 512
@@ -78,14 +79,29 @@ extern "C" int gr_diag_clk(unsigned long long* out) {
 
 __global__ __launch_bounds__(NT) void G256_KERNEL(GemmArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x;
   CLK_MARK(0)
+
+  // Persistent tile loop: the grid is min(tiles, CUs) blocks and block b runs virtual blocks b, b + grid, b + 2*grid ...
+  // (grid is a multiple of 8, so a virtual block keeps its XCD and the XCD-aware tile order is unchanged).  A CU goes from
+  // one tile's last store to the next tile's first DMA without a workgroup retire / dispatch in between: measured
+  // 1093 -> 1079 us on the LLaMA gate-up shape, 610 -> 604 us on QKV (tests/diag/persist_ab.py), neutral on the ViT shapes.
+  const int total_tiles = p.tiles_m * p.tiles_n;
+#if G256_FP8  // the e4m3 build has no register headroom for the tile loop (it spilled inside the K loop): one tile per block
+  {
+  const int vb = blockIdx.x;
+#else
+  for (int vb = blockIdx.x; vb < total_tiles; vb += gridDim.x) {
+#endif
+  // everything derived from the thread id is RE-derived per tile (opaque copy): hoisted out of the tile loop those values
+  // would have to survive the register-hungry epilogue, and the kernel already sits at 246 of 256 VGPRs
+  int tid = threadIdx.x;
+  asm volatile("" : "+v"(tid));
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 2, wn = wave & 3;
-
+  if (vb != (int)blockIdx.x) __syncthreads();  // the previous tile's epilogue has finished reading the stage buffers
   int tm, tn;
-  tile_of_block(blockIdx.x, gridDim.x, p.tiles_m, p.tiles_n, tm, tn);
+  tile_of_block(vb, total_tiles, p.tiles_m, p.tiles_n, tm, tn);
   const int m0 = tm * T256, n0 = tn * T256;
 
   const int ksteps_total = p.K / KT;
@@ -283,6 +299,7 @@ __global__ __launch_bounds__(NT) void G256_KERNEL(GemmArgs p) {
                                [&](int sr) { return m0 + (sr >> 5) * 128 + q * 32 + (sr & 31); });
     CLK_MARK(4 + 2 * q)
   }
+  }  // persistent tile loop
   CLK_MARK(2)
 }
 
@@ -294,7 +311,17 @@ int G256_LAUNCH(const GemmArgs& p, hipStream_t stream) {
     if (e != hipSuccess) return (int)e;
     attr_set = true;
   }
-  dim3 grid(p.tiles_m * p.tiles_n, p.splits);
+  // persistent launch: one block per CU (the 128 KB of LDS allow one block per CU anyway), fewer when there are fewer tiles
+  static int n_cu = 0;
+  if (n_cu == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return GR_EINVAL;
+    n_cu = prop.multiProcessorCount > 8 ? (prop.multiProcessorCount & ~7) : 8;
+  }
+  static const bool persist_off = G256_FP8 || getenv("GROMA_G256_NO_PERSIST") != nullptr;  // env: A/B switch for measurements
+  const int tiles = p.tiles_m * p.tiles_n;
+  dim3 grid(persist_off ? tiles : (tiles < n_cu ? tiles : n_cu), p.splits);
   hipLaunchKernelGGL(G256_KERNEL, grid, dim3(NT), 2 * STAGE_BYTES, stream, p);
   GR_CHECK_LAUNCH();
   return GR_OK;

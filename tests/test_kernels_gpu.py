@@ -45,6 +45,26 @@ def test_gemm_plain(dev, M, N, K, tile):
     assert torch.equal(out, ops.gemm(a, w, out_f32=True, tile=384 - tile))
 
 
+@pytest.mark.parametrize("M,N,K", [(8148, 4096, 4096), (582, 4096, 11008), (512, 256, 1280), (300, 512, 1216), (1000, 768, 2048)])
+def test_gemm_fp32_residual_large_shapes(dev, M, N, K):
+    """C(f32) = A.W^T + R(f32) at the LLaMA o-proj / down-proj shapes on the persistent 256x256 kernel (several tiles per
+    block, a partial last row tile, in-place update of the residual stream), with and without a bias term."""
+    ops = _ops()
+    a = rnd((M, K), dev, seed=1).bfloat16()
+    w = rnd((N, K), dev, 0.05, seed=2).bfloat16()
+    resid = rnd((M, N), dev, 3.0, seed=5)
+    ref = (a.double() @ w.double().t() + resid.double()).float()
+    out = ops.gemm(a, w, resid=resid, out_f32=True, tile=256)
+    assert relerr(out, ref) < 2e-6
+    epi = ops.gemm(a, w, resid=resid, bias=torch.zeros((N,), device=dev), out_f32=True, tile=256)  # epilogue-side residual
+    assert relerr(epi, ref) < 2e-6
+    assert (out - epi).abs().max().item() <= 4e-6 * ref.abs().max().item()
+    r2 = resid.clone()
+    ops.gemm(a, w, resid=r2, out=r2, out_f32=True, tile=256)  # in place, as the LLaMA residual stream is updated
+    assert torch.equal(r2, out)
+    assert torch.equal(out, ops.gemm(a, w, resid=resid, out_f32=True, tile=256))  # deterministic
+
+
 @pytest.mark.parametrize("tile", [128, 256])
 def test_gemm_epilogues(dev, tile):
     import functools
