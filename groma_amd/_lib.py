@@ -67,6 +67,7 @@ SIGNATURES = {
     "gr_embed_gather": [_P, _P, _P, _P, _L, _I, _I, _I, _P],
     "gr_scatter_rows_f32": [_P, _P, _P, _L, _I, _P],
     "gr_argmax_rows": [_P, _P, _I, _I, _L, _P],
+    "gr_sample_rows": [_P, _P, _I, _I, _L, _P, _P, _P, _I, _I, _P],
     "gr_greedy_advance": [_P, _P, _P, _P, _P, _P, _P, _I, _L, _L, _I, _I, _I, _P],
     "gr_msda_f32": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "gr_mha32_f32": [_P, _P, _P, _I, _I, _I, _I, _F, _P],

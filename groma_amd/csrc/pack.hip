@@ -625,6 +625,100 @@ extern "C" int gr_greedy_advance(const long* nxt, long* tok, long* unfinished, l
   return GR_OK;
 }
 
+// ---------------------------------------------------------------------------------------
+// Next-token sampling of the serving loop (groma/serve/model_worker.py:307-311): temperature < 1e-4 -> arg-max, else
+// probs = softmax(logits / temperature); token ~ multinomial(probs).  The draw is an inverse-CDF lookup with a COUNTER-BASED
+// uniform u = splitmix64(seed[row], position of the new token) -- a function of the request's seed and the token's absolute
+// position only, so a row's samples do not depend on batching, admission time or graph replay, and a CPU checker can
+// recompute u exactly.  One 1024-thread block per row; every thread owns a contiguous chunk of the vocabulary (fixed
+// summation order: bit-reproducible run to run).  inv_temp[row] == 0 selects the greedy branch (same tie rule as
+// argmax_kernel: first maximal index).
+__device__ __forceinline__ float sample_uniform(long seed, int counter) {
+  unsigned long long z = (unsigned long long)seed + 0x9E3779B97F4A7C15ull * (unsigned long long)(counter + 1);
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z ^= z >> 31;
+  return (float)(z >> 40) * (1.0f / 16777216.0f);  // 24 bits -> [0, 1)
+}
+__global__ __launch_bounds__(1024) void sample_rows_kernel(const float* __restrict__ x, long* __restrict__ out, int V, long ld,
+                                                           const float* __restrict__ inv_temp, const long* __restrict__ seed,
+                                                           const int* __restrict__ pos, int pos_stride, int pos_off) {
+  const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float* xr = x + (long)row * ld;
+  const float it = inv_temp ? inv_temp[row] : 0.f;
+  __shared__ float sv[16];
+  __shared__ int si[16];
+  __shared__ int s_last, s_win;
+  const int chunk = (V + 1023) / 1024;
+  const int lo = min(V, tid * chunk), hi = min(V, lo + chunk);
+  // ---- max (and its first index: the greedy answer)
+  float best = -INFINITY;
+  int bi = 0x7fffffff;
+  auto take = [&](float v, int i) {
+    if (v > best || (v == best && i < bi)) { best = v; bi = i; }
+  };
+  for (int i = lo; i < hi; ++i) take(xr[i], i);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ov = __shfl_xor(best, o, 64);
+    const int oi = __shfl_xor(bi, o, 64);
+    take(ov, oi);
+  }
+  if (lane == 0) { sv[wave] = best; si[wave] = bi; }
+  if (tid == 0) { s_last = -1; s_win = 0x7fffffff; }
+  __syncthreads();
+  for (int w = 0; w < 16; ++w) take(sv[w], si[w]);  // every thread now holds the row max
+  if (it == 0.f) {
+    if (tid == 0) out[row] = bi;
+    return;
+  }
+  const float m = best;
+  __syncthreads();  // sv is reused below
+  // ---- un-normalised probabilities: chunk sums, block exclusive scan (wave scan + sequential wave totals)
+  float local = 0.f;
+  for (int i = lo; i < hi; ++i) local += __expf((xr[i] - m) * it);
+  float incl = local;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const float v = __shfl_up(incl, o, 64);
+    if (lane >= o) incl += v;
+  }
+  if (lane == 63) sv[wave] = incl;
+  if (local > 0.f) atomicMax(&s_last, tid);
+  __syncthreads();
+  float base = 0.f, total = 0.f;
+  for (int w = 0; w < 16; ++w) {
+    if (w < wave) base += sv[w];
+    total += sv[w];
+  }
+  const float excl = base + incl - local;
+  const int counter = (pos ? pos[(long)row * pos_stride] : 0) + pos_off;
+  const float target = sample_uniform(seed ? seed[row] : 0, counter) * total;
+  // the owning chunk: excl <= target < excl + local; fp slack at the top end falls to the last chunk with mass
+  if (local > 0.f && excl <= target && (target < excl + local || tid == s_last)) {
+    float acc = excl;
+    int pick = -1;
+    for (int i = lo; i < hi; ++i) {
+      const float e = __expf((xr[i] - m) * it);
+      acc += e;
+      if (e > 0.f) {
+        pick = i;
+        if (target < acc) break;
+      }
+    }
+    if (pick >= 0) atomicMin(&s_win, pick);
+  }
+  __syncthreads();
+  if (tid == 0) out[row] = s_win != 0x7fffffff ? s_win : bi;
+}
+extern "C" int gr_sample_rows(const float* x, long* out, int rows, int V, long ld, const float* inv_temp, const long* seed,
+                              const int* pos, int pos_stride, int pos_off, hipStream_t stream) {
+  if (!x || !out || rows <= 0 || V <= 0 || pos_stride < 0) return GR_EINVAL;
+  hipLaunchKernelGGL(sample_rows_kernel, dim3(rows), dim3(1024), 0, stream, x, out, V, ld, inv_temp, seed, pos, pos_stride, pos_off);
+  GR_CHECK_LAUNCH();
+  return GR_OK;
+}
+
 extern "C" int gr_argmax_rows(const float* x, long* out, int rows, int V, long ld, hipStream_t stream) {
   if (!x || !out || rows <= 0 || V <= 0) return GR_EINVAL;
   hipLaunchKernelGGL(argmax_kernel, dim3(rows), dim3(1024), 0, stream, x, out, V, ld);

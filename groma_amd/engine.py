@@ -482,7 +482,16 @@ class GreedyDecoder:
         self.step = torch.zeros((1,), dtype=I32, device=device)
         self.n_unf = torch.zeros((1,), dtype=I32, device=device)
         self.h = torch.zeros((bs, llm.T), dtype=F32, device=device)
+        # sampling state (groma/serve/model_worker.py:307-311): 1/temperature per row (0 = greedy arg-max) and the seed of the
+        # counter-based draw; device tensors, so switching greedy <-> sampling never re-captures the graph
+        self.inv_temp = torch.zeros((bs,), dtype=F32, device=device)
+        self.seed = torch.zeros((bs,), dtype=I64, device=device)
         self.graph = None
+
+    def set_sampling(self, temperature=0.0, seeds=None):
+        self.inv_temp.fill_(0.0 if temperature is None or temperature < 1e-4 else 1.0 / float(temperature))
+        if seeds is not None:
+            self.seed.copy_(torch.as_tensor(seeds, dtype=I64).reshape(-1).to(self.seed.device))
 
     def _advance(self, inc_pos):
         ops.greedy_advance(self.nxt, self.tok, self.unfinished, self.seq, self.pos, self.step, self.n_unf,
@@ -492,7 +501,9 @@ class GreedyDecoder:
         llm = self.llm
         ops.embed_gather(self.tok, llm.w["embed"], llm.w["new_embed"], out=self.h)
         llm.forward(self.h, self.bs, 1, self.cache, pos_dev=self.pos, pos_stride=0)
-        ops.argmax_rows(llm.ws.get("dec_logits", (self.bs, llm.Vpad), F32, exact=True), llm.V, out=self.nxt)
+        # the token sampled from the logits at position `pos` sits at pos + 1 (pos_off = 1)
+        ops.sample_rows(llm.ws.get("dec_logits", (self.bs, llm.Vpad), F32, exact=True), llm.V, self.inv_temp, self.seed,
+                        pos=self.pos, pos_stride=0, pos_off=1, out=self.nxt)
         self._advance(1)
 
     def capture(self):
@@ -519,7 +530,8 @@ class GreedyDecoder:
         self.pos.fill_(L)
         self.step.zero_()
         self.unfinished.fill_(1)
-        ops.argmax_rows(first_logits.contiguous(), first_logits.shape[-1], out=self.nxt)
+        ops.sample_rows(first_logits.contiguous(), first_logits.shape[-1], self.inv_temp, self.seed, pos=self.pos,
+                        pos_stride=0, pos_off=0, out=self.nxt)  # first new token: position L
         self._advance(0)
         n = 1
         while n < max_new:

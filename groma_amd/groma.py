@@ -469,7 +469,7 @@ class GromaModel:
         return dec
 
     def _generate_graph(self, seqs, ids, images, refer_boxes, ground_boxes, max_new_tokens, eos, pad, return_dict,
-                        output_hidden_states):
+                        output_hidden_states, temperature=0.0, seeds=None):
         """generate() with the per-token step captured once in a hipGraph (engine.GreedyDecoder): the step position,
         the token fed back, the finished mask and the output ids all live on the device, so one replay = one token
         and the host only reads the unfinished-row count when an EOS id is configured."""
@@ -479,6 +479,7 @@ class GromaModel:
         bound = P + n_img_tok + 2 * self.config.max_region_num + (sum(len(b) for b in refer_boxes) if refer_boxes else 0)
         smax = engine._ru(bound + max_new_tokens + 1, 256)
         dec = self._decoder(bs, smax, engine._ru(max_new_tokens, 64), eos, pad)
+        dec.set_sampling(temperature, seeds)
         first = self.forward(input_ids=ids, images=images, refer_boxes=refer_boxes, ground_boxes=ground_boxes,
                              use_cache=True, output_hidden_states=output_hidden_states, return_dict=True,
                              _last_logits_only=True, _reserve=max_new_tokens, _cache=dec.cache)
@@ -499,10 +500,19 @@ class GromaModel:
         (groma/eval/eval_rec.py:93-104): the next token is the arg-max of the LAST position of the right-padded
         expanded sequence; finished rows emit pad; `sequences` = original prompt + new ids."""
         gc = generation_config if generation_config is not None else self.generation_config
-        if do_sample or getattr(gc, "do_sample", False) and do_sample is None:
-            raise NotImplementedError("only greedy decoding (do_sample=False) is implemented on the MI355X path")
+        if do_sample is None:
+            do_sample = bool(getattr(gc, "do_sample", False))
         if kw.get("num_beams", 1) != 1:
             raise NotImplementedError("beam search is not implemented")
+        temperature = 0.0
+        if do_sample:
+            # the sampler the reference serves with (groma/serve/model_worker.py:307-311): softmax(logits / T) + multinomial;
+            # HF's top-k / top-p warpers are not part of it
+            if kw.get("top_k") not in (None, 0) or kw.get("top_p") not in (None, 1.0):
+                raise NotImplementedError("top_k / top_p sampling is not implemented (temperature sampling only)")
+            temperature = float(kw.get("temperature", getattr(gc, "temperature", 1.0) or 1.0))
+        # one draw of the CPU global RNG seeds the rows' counter-based samplers (torch.manual_seed makes a run reproducible)
+        seeds = torch.randint(0, 2 ** 62, (input_ids.shape[0],), dtype=I64) if do_sample else None
         if max_new_tokens is None:
             max_new_tokens = getattr(gc, "max_new_tokens", 20) or 20
         eos = getattr(gc, "eos_token_id", None)
@@ -514,7 +524,7 @@ class GromaModel:
         ids_for_model = input_ids.to(dev)
         if self.decode_graph and max_new_tokens > 1:
             return self._generate_graph(seqs, ids_for_model, images, refer_boxes, ground_boxes, max_new_tokens, eos, pad,
-                                        return_dict_in_generate, output_hidden_states)
+                                        return_dict_in_generate, output_hidden_states, temperature, seeds)
         out = self.forward(input_ids=ids_for_model, images=images, refer_boxes=refer_boxes, ground_boxes=ground_boxes,
                            use_cache=True, output_hidden_states=output_hidden_states, return_dict=True,
                            _last_logits_only=True, _reserve=max_new_tokens)
@@ -522,11 +532,16 @@ class GromaModel:
         cache = out.past_key_values
         logits = out.logits
         unfinished = torch.ones(seqs.shape[0], dtype=I64, device=dev)
+        bs = seqs.shape[0]
+        inv_t = torch.full((bs,), 0.0 if temperature < 1e-4 else 1.0 / temperature, dtype=F32, device=dev)
+        seed_t = (seeds if seeds is not None else torch.zeros((bs,), dtype=I64)).to(dev)
+        pos_t = torch.zeros((1,), dtype=I32, device=dev)
+        L0 = cache.seq_len  # expanded prompt length: the first new token sits at position L0
         for step in range(max_new_tokens):
             V = logits.shape[-1]
             last = logits[:, -1, :]
-            # view into the padded logits buffer: pass its row stride to the arg-max kernel
-            nxt = ops.argmax_rows(last if last.is_contiguous() else last.contiguous(), V)
+            pos_t.fill_(L0 + step)
+            nxt = ops.sample_rows(last if last.is_contiguous() else last.contiguous(), V, inv_t, seed_t, pos=pos_t)
             if eos is not None:
                 nxt = nxt * unfinished + pad * (1 - unfinished)
             seqs = torch.cat([seqs, nxt[:, None]], dim=-1)

@@ -359,6 +359,31 @@ def argmax_rows(x, V, out=None):
     return out
 
 
+def sample_uniform(seed, counter):
+    """host twin of the device draw (splitmix64 of the request seed and the token position) -> float in [0, 1)"""
+    M = (1 << 64) - 1
+    z = (int(seed) + 0x9E3779B97F4A7C15 * (int(counter) + 1)) & M
+    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & M
+    z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & M
+    z ^= z >> 31
+    return (z >> 40) / 16777216.0
+
+
+def sample_rows(x, V, inv_temp, seed, pos=None, pos_stride=0, pos_off=0, out=None):
+    """x f32 [rows, ld] -> token ids int64 [rows]: arg-max where inv_temp[row] == 0, else a temperature sample
+    (model_worker.py:307-311) drawn with sample_uniform(seed[row], pos[row*pos_stride] + pos_off)"""
+    lib = _lib.load()
+    _chk(x, F32, "x"); _chk(inv_temp, F32, "inv_temp"); _chk(seed, I64, "seed")
+    if pos is not None:
+        _chk(pos, I32, "pos")
+    rows = x.numel() // x.shape[-1]
+    if out is None:
+        out = torch.empty((rows,), dtype=I64, device=x.device)
+    _lib.check(lib.gr_sample_rows(_p(x), _p(out), rows, V, x.shape[-1], _p(inv_temp), _p(seed), _p(pos), pos_stride, pos_off,
+                                  _stream()), "gr_sample_rows")
+    return out
+
+
 def greedy_advance(nxt, tok, unfinished, seq, pos, step, n_unfinished, *, eos, pad, inc_pos):
     """HF greedy_search bookkeeping of one step on the device (see include/groma_hip.h)"""
     lib = _lib.load()

@@ -68,7 +68,8 @@ class Request:
     ground_boxes: Optional[torch.Tensor] = None
     eos_token_id: Optional[int] = None
     stop_token_id: Optional[int] = None     # model_worker.py:277-283 `stop` when it tokenises to one id
-    seed: Optional[int] = None              # torch.manual_seed before the prefill (region shuffle)
+    seed: Optional[int] = None              # torch.manual_seed before the prefill (region shuffle); also keys the sampler
+    temperature: float = 0.0                # model_worker.py:269,307-311: < 1e-4 -> arg-max, else softmax(logits / T) sampling
     tokens: List[int] = field(default_factory=list)
     pred_boxes: Optional[torch.Tensor] = None
     slot: Optional[int] = None
@@ -125,16 +126,18 @@ class ContinuousBatcher:
         self.n_live = torch.zeros((1,), dtype=I32, device=dev)
         self._seq = torch.zeros((max_rows, 1), dtype=I64, device=dev)
         self.h = torch.zeros((max_rows, self.llm.T), dtype=F32, device=dev)
+        self.inv_temp = torch.zeros((max_rows,), dtype=F32, device=dev)   # per-row 1/temperature (0 = greedy)
+        self.seed = torch.zeros((max_rows,), dtype=I64, device=dev)       # per-row sampler seed
         self.graph = None
         self.steps = 0
 
     # ------------------------------------------------------------------ request intake
     def submit(self, input_ids, image, max_new_tokens=256, refer_boxes=None, ground_boxes=None, eos_token_id="config",
-               stop_token_id=None, seed=None):
+               stop_token_id=None, seed=None, temperature=0.0):
         if eos_token_id == "config":
             eos_token_id = self.model.generation_config.eos_token_id
         r = Request(self._next_rid, input_ids.reshape(-1).to(I64).cpu(), image, int(max_new_tokens), refer_boxes, ground_boxes,
-                    eos_token_id, stop_token_id, seed)
+                    eos_token_id, stop_token_id, seed, float(temperature))
         self._next_rid += 1
         self.queue.append(r)
         self.live[r.rid] = r
@@ -145,7 +148,8 @@ class ContinuousBatcher:
         llm = self.llm
         ops.embed_gather(self.tok, llm.w["embed"], llm.w["new_embed"], out=self.h)
         llm.forward(self.h, self.rows, 1, self.arena, pos_dev=self.pos, pos_stride=1)
-        ops.argmax_rows(llm.ws.get("dec_logits", (self.rows, llm.Vpad), F32, exact=True), llm.V, out=self.nxt)
+        ops.sample_rows(llm.ws.get("dec_logits", (self.rows, llm.Vpad), F32, exact=True), llm.V, self.inv_temp, self.seed,
+                        pos=self.pos, pos_stride=1, pos_off=1, out=self.nxt)  # greedy rows: inv_temp 0 -> arg-max
         ops.greedy_advance(self.nxt, self.tok, self.occupied, self._seq, self.pos, self.step_ctr, self.n_live,
                            eos=None, pad=0, inc_pos=2)
 
@@ -197,7 +201,12 @@ class ContinuousBatcher:
             if r.prompt_len + r.max_new_tokens > self.max_len:
                 r.done, r.error = True, "prompt + max_new_tokens exceeds the KV slot (max_len)"
                 continue
-            first = int(ops.argmax_rows(out.logits[i, r.prompt_len - 1][None].contiguous(), out.logits.shape[-1])[0])
+            it = 0.0 if r.temperature < 1e-4 else 1.0 / r.temperature
+            dev = self.tok.device
+            first = int(ops.sample_rows(out.logits[i, r.prompt_len - 1][None].contiguous(), out.logits.shape[-1],
+                                        torch.tensor([it], dtype=F32, device=dev),
+                                        torch.tensor([int(r.seed or 0)], dtype=I64, device=dev),
+                                        pos=torch.tensor([r.prompt_len], dtype=I32, device=dev))[0])
             self._emit(r, first)
             if r.done:
                 continue
@@ -207,6 +216,8 @@ class ContinuousBatcher:
             self.tok[r.slot] = first
             self.pos[r.slot] = r.prompt_len
             self.occupied[r.slot] = 1
+            self.inv_temp[r.slot] = it
+            self.seed[r.slot] = int(r.seed or 0)
         if rows:
             dev = self.tok.device
             src = torch.tensor(rows, dtype=I64, device=dev)

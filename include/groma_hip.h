@@ -161,6 +161,12 @@ int gr_embed_gather(const long* ids, const void* table0, const void* table1, flo
                     hipStream_t stream);
 int gr_scatter_rows_f32(const float* src, const int* row_idx, float* dst, long n, int C, hipStream_t stream);
 int gr_argmax_rows(const float* x, long* out, int rows, int V, long ld, hipStream_t stream);
+/* the serving loop's sampler (groma/serve/model_worker.py:307-311): inv_temp[row] == 0 (or inv_temp NULL) -> arg-max, else
+ * token ~ softmax(logits * inv_temp[row]) by inverse CDF with u = splitmix64(seed[row], pos[row*pos_stride] + pos_off) in
+ * [0,1) -- a counter-based draw keyed on the request's seed and the new token's absolute position (independent of batching,
+ * replayable in a hipGraph, recomputable on the host). */
+int gr_sample_rows(const float* x, long* out, int rows, int V, long ld, const float* inv_temp, const long* seed,
+                   const int* pos, int pos_stride, int pos_off, hipStream_t stream);
 /* one step of HF 4.32 GenerationMixin.greedy_search bookkeeping on the device (reference: the loop HF runs around
  * groma/model/groma.py:176-200): n = unfinished ? nxt : pad; seq[:, *step] = n; tok = n; unfinished &= n != eos;
  * ++*step; pos[0..pos_rows) += inc_pos; *n_unfinished = sum(unfinished).  eos < 0 = no stopping token.

@@ -543,3 +543,43 @@ def test_attention_reads_q_in_place(dev, B, H, hd, L, rope, causal):
     assert relerr(out, ref) < 2e-3
     if not rope:
         assert torch.equal(out, ref)
+
+
+def test_sample_rows_inverse_cdf_and_greedy(dev):
+    """gr_sample_rows (the serving sampler, R: groma/serve/model_worker.py:307-311): every drawn token must be THE inverse-CDF
+    sample of softmax(logits / T) for the host-recomputed counter-based uniform (float64 CDF, fp32 slack at the bin edges);
+    inv_temp 0 rows are plain arg-max; draws are reproducible and follow the distribution."""
+    ops = _ops()
+    V, ld, rows = 32114, 32128, 6
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn((rows, ld), generator=g) * 3.0
+    x[:, V:] = 1e9  # padding columns must never be picked
+    temps = [0.0, 0.7, 1.0, 0.2, 1.5, 1e-5]
+    inv = torch.tensor([0.0 if t < 1e-4 else 1.0 / t for t in temps])
+    seeds = torch.tensor([11, 22, 33, 44, 55, 66])
+    pos = torch.tensor([700, 701, 5, 9000, 42, 3], dtype=torch.int32)
+    xd = x.to(dev)
+    out = ops.sample_rows(xd, V, inv.to(dev), seeds.to(dev), pos=pos.to(dev), pos_stride=1, pos_off=1).cpu()
+    assert torch.equal(out, ops.sample_rows(xd, V, inv.to(dev), seeds.to(dev), pos=pos.to(dev), pos_stride=1, pos_off=1).cpu())
+    am = x[:, :V].argmax(-1)
+    for r in range(rows):
+        if temps[r] < 1e-4:
+            assert int(out[r]) == int(am[r]) == int(ops.argmax_rows(xd[r:r + 1].contiguous(), V)[0])
+            continue
+        p = torch.softmax(x[r, :V].double() / temps[r], -1)
+        cdf = torch.cumsum(p, 0)
+        u = ops.sample_uniform(int(seeds[r]), int(pos[r]) + 1)
+        t = int(out[r])
+        lo = float(cdf[t - 1]) if t > 0 else 0.0
+        assert lo - 2e-5 <= u <= float(cdf[t]) + 2e-5, (r, t, u, lo, float(cdf[t]))
+    # distribution: 4000 draws (different positions) from one row at T = 1 against the exact probabilities of the top bins
+    n = 4000
+    row = (torch.randn((1, ld), generator=g) * 2.5)
+    xs = row.expand(n, ld).contiguous().to(dev)
+    draws = ops.sample_rows(xs, V, torch.ones(n, device=dev), torch.full((n,), 7, dtype=torch.int64, device=dev),
+                            pos=torch.arange(n, dtype=torch.int32, device=dev), pos_stride=1).cpu()
+    p = torch.softmax(row[0, :V].double(), -1)
+    top = p.topk(5).indices
+    for t in top:
+        f, e = (draws == t).double().mean().item(), p[t].item()
+        assert abs(f - e) < 5 * (e * (1 - e) / n) ** 0.5 + 1e-3

@@ -268,3 +268,33 @@ def test_proposer_graph_equals_eager(setup):
                 assert all(torch.equal(a, b) for a, b in zip(cur[3], ref[3]))
                 assert torch.equal(cur[4], ref[4])
     model.proposer_graph = True
+
+
+def test_generate_sampling_reproducible_and_graph_equals_eager(setup):
+    """generate(do_sample=True, temperature=T): the serving sampler (R: groma/serve/model_worker.py:307-311) with a
+    counter-based draw keyed on (row seed, token position) -- so the captured-graph loop and the eager loop sample the SAME
+    tokens, a fixed torch.manual_seed reproduces them, and greedy decoding is untouched."""
+    cfg, sd, tk, model, images, ids = setup
+    gc = model.generation_config
+    old = (gc.eos_token_id, model.decode_graph)
+    try:
+        gc.eos_token_id = None
+        outs = {}
+        for graph in (True, False, True):
+            model.decode_graph = graph
+            torch.manual_seed(123)
+            outs.setdefault(graph, []).append(model.generate(ids.clone(), images=images, do_sample=True, temperature=0.9,
+                                                             max_new_tokens=10).cpu())
+        assert torch.equal(outs[True][0], outs[True][1]) and torch.equal(outs[True][0], outs[False][0])
+        torch.manual_seed(124)
+        other = model.generate(ids.clone(), images=images, do_sample=True, temperature=0.9, max_new_tokens=10).cpu()
+        assert not torch.equal(other[:, ids.shape[1]:], outs[True][0][:, ids.shape[1]:])  # another seed, another sample
+        torch.manual_seed(123)
+        greedy = model.generate(ids.clone(), images=images, max_new_tokens=10).cpu()
+        torch.manual_seed(123)
+        cold = model.generate(ids.clone(), images=images, do_sample=True, temperature=1e-6, max_new_tokens=10).cpu()
+        assert torch.equal(greedy, cold)  # temperature < 1e-4 is arg-max (model_worker.py:307)
+        with pytest.raises(NotImplementedError):
+            model.generate(ids.clone(), images=images, do_sample=True, top_p=0.9, max_new_tokens=2)
+    finally:
+        gc.eos_token_id, model.decode_graph = old

@@ -132,3 +132,28 @@ def test_generate_stream_yields_growing_prefixes(setup):
     assert chunks[-1] == _solo_generate(model, ids, image, 7, seed) or len(chunks[-1]) == 7
     assert all(chunks[i] == chunks[i + 1][:len(chunks[i])] for i in range(len(chunks) - 1))
     assert b.live[other].done
+
+
+def test_sampled_rows_are_independent_of_batch_composition(setup):
+    """temperature sampling in the batcher: a request's tokens are a function of its own (seed, positions) only -- the same
+    alone, beside greedy neighbours, or admitted late; and a cold temperature equals the greedy tokens"""
+    from groma_amd.serving import ContinuousBatcher
+    cfg, model, reqs = setup
+    ids, image, n, seed = reqs[1]
+    b = ContinuousBatcher(model, max_rows=4, max_len=1024)
+    rid = b.submit(ids, image, max_new_tokens=9, seed=seed, temperature=0.8)
+    b.run_until_done()
+    alone = b.result(rid).tokens
+    b = ContinuousBatcher(model, max_rows=4, max_len=1024)
+    others = [b.submit(*reqs[i][:2], max_new_tokens=12, seed=reqs[i][3]) for i in (0, 2)]
+    b.step(); b.step()
+    rid = b.submit(ids, image, max_new_tokens=9, seed=seed, temperature=0.8)
+    b.run_until_done()
+    assert b.result(rid).tokens == alone
+    greedy = [b.result(o).tokens for o in others]
+    assert greedy[0] == _solo_generate(model, *reqs[0][:2], 12, reqs[0][3])
+    b = ContinuousBatcher(model, max_rows=2, max_len=1024)
+    rid = b.submit(ids, image, max_new_tokens=9, seed=seed, temperature=1e-6)
+    b.run_until_done()
+    assert b.result(rid).tokens == _solo_generate(model, ids, image, 9, seed)
+    assert alone != b.live.get(rid, None)
