@@ -1,83 +1,136 @@
 // Exact-fp32 GEMM on the f32-input MFMA (v_mfma_f32_16x16x4_f32) for the Deformable-DETR
 // proposer (kept fp32 so top-k / NMS indices are reproducible) and the
 // small region-encoder MLPs (groma/model/roi_align.py:254-261).
-//   C[M,N] = act(A[M,K] . W[N,K]^T + bias)      A, W, C row-major fp32
-// The MFMA result is a k-ordered fmaf chain (cdna_hip_programming.md §3), i.e. plain fp32
-// arithmetic.  Tile 64x64x16, 256 threads = 4 waves (2x2), each wave 32x32 = 2x2 MFMA tiles.
-// M = 300..4096, N <= 1024, K <= 1024 here: launch-latency class, not roofline class.
+//   C[M,N] = act(A[M,K] . W[N,K]^T + bias) (+ resid)      A, W, C row-major fp32
+// Every product and sum is plain IEEE fp32 (the MFMA accumulates an fmaf chain per output element); only the ORDER of the
+// K summation differs from a CPU loop.
+//
+// Round-2 kernel.  Round 1's 64x64x16 tile read its operands with scalar ds_read_b32 (4 LDS reads per 4 MFMAs) and
+// measured 17 TF/s = 11 % of the 157 TF/s f32-MFMA peak -- 11.8 ms of a 138 ms step at 14 images, and NOT hidden: the
+// proposer's kernels fill the chip, so they time-share it with the region pyramid on the other stream.  Now:
+//  * tile BM x BN x 16 with BM = BN = 128 (4 waves = 2x2, each 64x64 = 4x4 MFMA tiles) when that still yields >= 128
+//    blocks, else 64 x 64 (waves 32x32): 64 / 16 MFMAs (32 clk each) per wave and K-step against 8 / 4 LDS reads;
+//  * the K index inside a 16-deep step is PERMUTED so that a lane's four operands (one per 16x16x4 MFMA) are contiguous:
+//    lane (row fr, k-group fk) owns k = 4*fk .. 4*fk+3 and fetches them with ONE ds_read_b128 (any permutation is legal
+//    as long as A and W use the same one -- it only reorders the fp32 sum);
+//  * LDS rows are 64 B (16 floats); the 16-B chunk c of row r is stored at c ^ ((r >> 2) & 3): the 16 lanes of a b128
+//    read (16 consecutive rows, same chunk) then cover all 64 banks exactly once -- conflict-free without padding;
+//  * global -> register prefetch of step t+1 is issued before the MFMAs of step t; double-buffered LDS, one barrier per step;
+//  * 16-B epilogue stores (bias, ReLU, residual fused).
 #include "gr_common.h"
 #include "../../include/groma_hip.h"
 
-#define FBM 64
-#define FBN 64
 #define FBK 16
-#define LDP 17  // padded k-stride (floats) -> conflict-free column reads
 
+template <int BM, int BN>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__ A, const float* __restrict__ W,
                                                        float* __restrict__ C, const float* __restrict__ bias,
                                                        const float* __restrict__ resid, int M, int N, int K, long lda,
                                                        long ldw, long ldc, int act) {
-  __shared__ float as[2][FBM * LDP];
-  __shared__ float ws[2][FBN * LDP];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  constexpr int TM = BM / 32, TN = BN / 32;         // 16x16 MFMA tiles per wave in m / n
+  constexpr int NA = BM * 4 / 256, NW = BN * 4 / 256;  // 16-B chunks staged per thread and step
+  __shared__ __attribute__((aligned(16))) float as[2][BM * FBK];
+  __shared__ __attribute__((aligned(16))) float ws[2][BN * FBK];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
-  const int m0 = blockIdx.y * FBM, n0 = blockIdx.x * FBN;
-  // staging: thread -> (row = tid/4, 4 floats at k = (tid%4)*4)
-  const int srow = tid >> 2, sk = (tid & 3) * 4;
-  int am = m0 + srow; if (am > M - 1) am = M - 1;
-  int wnr = n0 + srow; if (wnr > N - 1) wnr = N - 1;
-  const float* ap = A + (long)am * lda + sk;
-  const float* wp = W + (long)wnr * ldw + sk;
-  const int nt = K / FBK;
-  f32x4 acc[2][2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  f32x4 ra = *(const f32x4*)ap, rw = *(const f32x4*)wp;
+  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
   const int fr = lane & 15, fk = lane >> 4;
+
+  // staging: chunk q = i*256 + tid -> row q>>2, chunk q&3 (4 consecutive k); rows past the edge re-read the last row
+  const float* ap[NA];
+  const float* wp[NW];
+  int aoff[NA], woff[NW];  // swizzled LDS float offsets
+#pragma unroll
+  for (int i = 0; i < NA; ++i) {
+    const int q = i * 256 + tid, r = q >> 2, c = q & 3;
+    int m = m0 + r;
+    if (m > M - 1) m = M - 1;
+    ap[i] = A + (long)m * lda + c * 4;
+    aoff[i] = r * FBK + ((c ^ ((r >> 2) & 3)) << 2);
+  }
+#pragma unroll
+  for (int i = 0; i < NW; ++i) {
+    const int q = i * 256 + tid, r = q >> 2, c = q & 3;
+    int n = n0 + r;
+    if (n > N - 1) n = N - 1;
+    wp[i] = W + (long)n * ldw + c * 4;
+    woff[i] = r * FBK + ((c ^ ((r >> 2) & 3)) << 2);
+  }
+  f32x4 ra[NA], rw[NW];
+#pragma unroll
+  for (int i = 0; i < NA; ++i) ra[i] = *(const f32x4*)ap[i];
+#pragma unroll
+  for (int i = 0; i < NW; ++i) rw[i] = *(const f32x4*)wp[i];
+
+  f32x4 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // fragment reads: row R = base + 16*i + fr -> (R >> 2) & 3 == (fr >> 2) & 3 (bases are multiples of 16)
+  const int fsw = ((fk ^ ((fr >> 2) & 3)) << 2);
+  const int a_lane = (wm * (BM / 2) + fr) * FBK + fsw;
+  const int w_lane = (wn * (BN / 2) + fr) * FBK + fsw;
+
+  const int nt = K / FBK;
   for (int t = 0; t < nt; ++t) {
     const int buf = t & 1;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      as[buf][srow * LDP + sk + e] = ra[e];
-      ws[buf][srow * LDP + sk + e] = rw[e];
-    }
+    for (int i = 0; i < NA; ++i) *(f32x4*)(&as[buf][aoff[i]]) = ra[i];
+#pragma unroll
+    for (int i = 0; i < NW; ++i) *(f32x4*)(&ws[buf][woff[i]]) = rw[i];
     __syncthreads();
     if (t + 1 < nt) {
-      ra = *(const f32x4*)(ap + (long)(t + 1) * FBK);
-      rw = *(const f32x4*)(wp + (long)(t + 1) * FBK);
+#pragma unroll
+      for (int i = 0; i < NA; ++i) ra[i] = *(const f32x4*)(ap[i] + (long)(t + 1) * FBK);
+#pragma unroll
+      for (int i = 0; i < NW; ++i) rw[i] = *(const f32x4*)(wp[i] + (long)(t + 1) * FBK);
     }
+    f32x4 af[TM], wf[TN];
 #pragma unroll
-    for (int k4 = 0; k4 < 4; ++k4) {
-      float af[2], wf[2];
+    for (int i = 0; i < TM; ++i) af[i] = *(const f32x4*)(&as[buf][a_lane + i * 16 * FBK]);
 #pragma unroll
-      for (int i = 0; i < 2; ++i) af[i] = as[buf][(wm * 32 + i * 16 + fr) * LDP + k4 * 4 + fk];
+    for (int j = 0; j < TN; ++j) wf[j] = *(const f32x4*)(&ws[buf][w_lane + j * 16 * FBK]);
 #pragma unroll
-      for (int j = 0; j < 2; ++j) wf[j] = ws[buf][(wn * 32 + j * 16 + fr) * LDP + k4 * 4 + fk];
-      // swapped operands: rows of the MFMA result = n, columns = m  (lane gets 4 consecutive n)
+    for (int k4 = 0; k4 < 4; ++k4)
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[j], af[i], acc[i][j], 0, 0, 0);
-    }
-    // next iteration writes the other buffer; the barrier at its top orders those writes after these reads
+        for (int j = 0; j < TN; ++j)  // swapped operands: MFMA rows = n, columns = m (a lane gets 4 consecutive n)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[j][k4], af[i][k4], acc[i][j], 0, 0, 0);
+    // the next iteration writes the other buffer; the barrier at its top orders those writes after these reads
   }
+  const bool vec = (ldc & 3) == 0 && (N & 3) == 0 && (((uintptr_t)C) & 15) == 0 && (!resid || (((uintptr_t)resid) & 15) == 0) &&
+                   (!bias || (((uintptr_t)bias) & 15) == 0);
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int m = m0 + wm * 32 + i * 16 + fr;
+  for (int i = 0; i < TM; ++i) {
+    const int m = m0 + wm * (BM / 2) + i * 16 + fr;
     if (m >= M) continue;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int n = n0 + wn * 32 + j * 16 + fk * 4;
+    for (int j = 0; j < TN; ++j) {
+      const int n = n0 + wn * (BN / 2) + j * 16 + fk * 4;
+      if (n >= N) continue;
+      f32x4 v = acc[i][j];
+      if (vec) {
+        if (bias) v += *(const f32x4*)(bias + n);
+        if (act == 2) {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        if (n + e < N) {
-          float v = acc[i][j][e];
-          if (bias) v += bias[n + e];
-          if (act == 2) v = fmaxf(v, 0.f);
-          if (resid) v += resid[(long)m * ldc + n + e];
-          C[(long)m * ldc + n + e] = v;
+          for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+        }
+        if (resid) v += *(const f32x4*)(resid + (long)m * ldc + n);
+        *(f32x4*)(C + (long)m * ldc + n) = v;
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          if (n + e < N) {
+            float x = v[e];
+            if (bias) x += bias[n + e];
+            if (act == 2) x = fmaxf(x, 0.f);
+            if (resid) x += resid[(long)m * ldc + n + e];
+            C[(long)m * ldc + n + e] = x;
+          }
         }
       }
     }
@@ -88,8 +141,15 @@ extern "C" int gr_gemm_f32(const float* A, const float* W, float* C, const float
                            int K, long lda, long ldw, long ldc, int act, hipStream_t stream) {
   if (!A || !W || !C || M <= 0 || N <= 0 || K <= 0 || K % FBK != 0) return GR_EINVAL;
   if (lda % 4 != 0 || ldw % 4 != 0) return GR_EINVAL;
-  dim3 grid(gr_cdiv(N, FBN), gr_cdiv(M, FBM));
-  hipLaunchKernelGGL(gemm_f32_kernel, grid, dim3(256), 0, stream, A, W, C, bias, resid, M, N, K, lda, ldw, ldc, act);
+  if ((((uintptr_t)A) & 15) != 0 || (((uintptr_t)W) & 15) != 0) return GR_EINVAL;
+  const long big = (long)gr_cdiv(M, 128) * gr_cdiv(N, 128);
+  if (big >= 128 && N >= 96) {
+    dim3 grid(gr_cdiv(N, 128), gr_cdiv(M, 128));
+    hipLaunchKernelGGL((gemm_f32_kernel<128, 128>), grid, dim3(256), 0, stream, A, W, C, bias, resid, M, N, K, lda, ldw, ldc, act);
+  } else {
+    dim3 grid(gr_cdiv(N, 64), gr_cdiv(M, 64));
+    hipLaunchKernelGGL((gemm_f32_kernel<64, 64>), grid, dim3(256), 0, stream, A, W, C, bias, resid, M, N, K, lda, ldw, ldc, act);
+  }
   GR_CHECK_LAUNCH();
   return GR_OK;
 }
