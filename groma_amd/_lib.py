@@ -53,6 +53,7 @@ SIGNATURES = {
     "gr_decode_attention": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _P, _I, _I, _P, _P],
     "gr_resize_h_u8": [_P, _P, _P, _P, _I, _I, _I, _I, _P],
     "gr_resize_v_norm": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
+    "gr_cv2_resize_norm": [_P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
     "gr_patchify": [_P, _P, _I, _I, _I, _I, _P],
     "gr_fill_rows_f32": [_P, _P, _I, _I, _L, _P],
     "gr_mean4_tokens": [_P, _P, _P, _P, _P, _I, _I, _I, _P],

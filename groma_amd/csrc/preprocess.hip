@@ -92,3 +92,70 @@ extern "C" int gr_resize_v_norm(const void* in, void* out_u8, float* out_f32, co
   GR_CHECK_LAUNCH();
   return GR_OK;
 }
+
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The eval datasets' mmdet pipeline (groma/data/datasets/refcoco_rec.py:38-65): Resize((448,448), keep_ratio=False) =
+// cv2.resize INTER_LINEAR on the 8-bit BGR image (mmcv/image/geometric.py:51-101), then Normalize(mean, std, to_rgb) =
+// mmcv.imnormalize (mmcv/image/photometric.py:9-45), fused: one thread per output pixel.
+// OpenCV's 8-bit bilinear arithmetic (resize.cpp; cv2 itself is not in this image -- see oracle/cv2_pipeline.py):
+//   horizontal  D = S[sx] * a0 + S[sx + 1] * a1 (int32, 11-bit coefficients from the host tables),
+//   vertical    dst = (((b0 * (D0 >> 4)) >> 16) + ((b1 * (D1 >> 4)) >> 16) + 2) >> 2,
+//   exact 2x down-scale in both directions = the INTER_AREA fast path (s00 + s01 + s10 + s11 + 2) >> 2.
+// imnormalize with non-integer scalars runs in double and stores float32: y = f32(f64(f32(f64(v) - mean)) * stdinv).
+__global__ __launch_bounds__(256) void cv2_resize_norm_kernel(const uint8_t* __restrict__ in, int Hin, int Win,
+                                                              const int* __restrict__ xofs, const short* __restrict__ xa,
+                                                              const int* __restrict__ yofs, const short* __restrict__ yb,
+                                                              uint8_t* __restrict__ out_u8, float* __restrict__ out_f32,
+                                                              const double* __restrict__ mean,
+                                                              const double* __restrict__ stdinv, int to_rgb, int Hout,
+                                                              int Wout, int area2) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= Hout * Wout) return;
+  const int y = idx / Wout, x = idx - y * Wout;
+  int v[3];
+  if (area2) {
+    const uint8_t* r0 = in + ((long)(2 * y) * Win + 2 * x) * 3;
+    const uint8_t* r1 = r0 + (long)Win * 3;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) v[c] = ((int)r0[c] + (int)r0[3 + c] + (int)r1[c] + (int)r1[3 + c] + 2) >> 2;
+  } else {
+    const int sx = xofs[x], sx1 = min(sx + 1, Win - 1);
+    const int a0 = xa[2 * x], a1 = xa[2 * x + 1];
+    const int sy = yofs[y];
+    const int y0 = min(max(sy, 0), Hin - 1), y1 = min(max(sy + 1, 0), Hin - 1);
+    const int b0 = yb[2 * y], b1 = yb[2 * y + 1];
+    const uint8_t* p0 = in + (long)y0 * Win * 3;
+    const uint8_t* p1 = in + (long)y1 * Win * 3;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const int d0 = (int)p0[sx * 3 + c] * a0 + (int)p0[sx1 * 3 + c] * a1;
+      const int d1 = (int)p1[sx * 3 + c] * a0 + (int)p1[sx1 * 3 + c] * a1;
+      v[c] = (((b0 * (d0 >> 4)) >> 16) + ((b1 * (d1 >> 4)) >> 16) + 2) >> 2;
+    }
+  }
+  if (out_u8) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) out_u8[(long)idx * 3 + c] = (uint8_t)v[c];
+  }
+  if (out_f32) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {  // c = output channel; to_rgb: cvtColor(BGR2RGB) before the arithmetic
+      const int src = to_rgb ? 2 - c : c;
+      const float t = (float)((double)v[src] - mean[c]);
+      out_f32[(long)c * Hout * Wout + idx] = (float)((double)t * stdinv[c]);
+    }
+  }
+}
+extern "C" int gr_cv2_resize_norm(const void* in, int Hin, int Win, const int* xofs, const short* xalpha, const int* yofs,
+                                  const short* ybeta, void* out_u8, float* out_f32, const double* mean, const double* stdinv,
+                                  int to_rgb, int Hout, int Wout, hipStream_t stream) {
+  if (!in || Hin <= 0 || Win <= 0 || Hout <= 0 || Wout <= 0 || (!out_u8 && !out_f32)) return GR_EINVAL;
+  if (out_f32 && (!mean || !stdinv)) return GR_EINVAL;
+  const int area2 = Hin == 2 * Hout && Win == 2 * Wout;
+  if (!area2 && (!xofs || !xalpha || !yofs || !ybeta)) return GR_EINVAL;
+  hipLaunchKernelGGL(cv2_resize_norm_kernel, dim3(gr_cdiv((long)Hout * Wout, 256)), dim3(256), 0, stream, (const uint8_t*)in,
+                     Hin, Win, xofs, xalpha, yofs, ybeta, (uint8_t*)out_u8, out_f32, mean, stdinv, to_rgb, Hout, Wout, area2);
+  GR_CHECK_LAUNCH();
+  return GR_OK;
+}

@@ -123,3 +123,78 @@ class ImagePreprocessor:
                 im = torch.from_numpy(np.ascontiguousarray(np.asarray(im)))
             self._run(im, want_u8=False, want_f32=True, out_f32=out[i])
         return out
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The eval datasets' route (groma/data/datasets/refcoco_rec.py:38-65 and the other mmdet-style datasets):
+#   LoadImageFromFile (cv2.imread: uint8 HWC BGR) -> Resize((448, 448), keep_ratio=False) = cv2.resize INTER_LINEAR
+#   -> Normalize(mean * 255, std * 255, to_rgb=True) = mmcv.imnormalize -> Pad(size_divisor=448) (no-op) -> CHW tensor.
+MMDET_MEAN = (0.485 * 255, 0.456 * 255, 0.406 * 255)
+MMDET_STD = (0.229 * 255, 0.224 * 255, 0.225 * 255)
+_CV_COEF_SCALE = 2048  # INTER_RESIZE_COEF_SCALE (11 bits)
+
+
+def cv2_linear_tables(src, dst, clamp_taps):
+    """OpenCV's per-axis bilinear tables (imgproc/resize.cpp): tap index and the two 11-bit coefficients
+    short(cvRound((1 - f) * 2048)), short(cvRound(f * 2048)) with f = float((d + 0.5) * scale - 0.5) - floor(.).
+    clamp_taps=True is the x axis (index clamped, f zeroed at both borders); rows keep f and clip indices in the kernel."""
+    scale = 1.0 / (dst / src)
+    ofs = np.zeros(dst, dtype=np.int32)
+    coef = np.zeros((dst, 2), dtype=np.int16)
+    for d in range(dst):
+        f = np.float32((d + 0.5) * scale - 0.5)
+        s = int(np.floor(f))
+        f = np.float32(f - np.float32(s))
+        if clamp_taps:
+            if s < 0:
+                s, f = 0, np.float32(0.0)
+            if s >= src - 1:
+                s, f = src - 1, np.float32(0.0)
+        ofs[d] = s
+        coef[d, 0] = int(np.rint(np.float32(np.float32(np.float32(1.0) - f) * np.float32(_CV_COEF_SCALE))))  # cvRound
+        coef[d, 1] = int(np.rint(np.float32(f * np.float32(_CV_COEF_SCALE))))
+    return ofs, coef
+
+
+class MmdetTestPipeline:
+    """uint8 [H, W, 3] **BGR** images (what cv2.imread / LoadImageFromFile yields; any size) -> f32 [B, 3, 448, 448] on the
+    device, through one fused kernel per image (csrc/preprocess.hip::cv2_resize_norm_kernel)."""
+
+    def __init__(self, size=448, mean=MMDET_MEAN, std=MMDET_STD, to_rgb=True, device="cuda"):
+        self.size, self.device, self.to_rgb = int(size), torch.device(device), bool(to_rgb)
+        self.mean = torch.tensor(mean, dtype=torch.float64, device=self.device)
+        self.stdinv = (1.0 / torch.tensor(std, dtype=torch.float64)).to(self.device)
+        self._tab = {}
+
+    def _tables(self, n, clamp):
+        key = (n, clamp)
+        if key not in self._tab:
+            o, c = cv2_linear_tables(n, self.size, clamp)
+            self._tab[key] = (torch.from_numpy(o).to(self.device), torch.from_numpy(c).to(self.device).contiguous())
+        return self._tab[key]
+
+    def _run(self, img, out_f32=None, want_u8=False):
+        lib = _lib.load()
+        if img.dtype != torch.uint8 or img.dim() != 3 or img.shape[2] != 3:
+            raise ValueError("expected a uint8 [H, W, 3] BGR image")
+        img = img.to(self.device).contiguous()
+        H, W, S = img.shape[0], img.shape[1], self.size
+        xo, xa = self._tables(W, True)
+        yo, yb = self._tables(H, False)
+        o8 = torch.empty((S, S, 3), dtype=torch.uint8, device=self.device) if want_u8 else None
+        _lib.check(lib.gr_cv2_resize_norm(ops._p(img), H, W, ops._p(xo), ops._p(xa), ops._p(yo), ops._p(yb), ops._p(o8),
+                                          ops._p(out_f32), ops._p(self.mean), ops._p(self.stdinv), int(self.to_rgb), S, S,
+                                          ops._stream()), "gr_cv2_resize_norm")
+        return o8
+
+    def resize_u8(self, img):
+        """cv2.resize(img, (size, size), interpolation=cv2.INTER_LINEAR) of the same pixels"""
+        return self._run(img, None, want_u8=True)
+
+    def __call__(self, images):
+        out = torch.empty((len(images), 3, self.size, self.size), dtype=torch.float32, device=self.device)
+        for i, im in enumerate(images):
+            if not torch.is_tensor(im):
+                im = torch.from_numpy(np.ascontiguousarray(np.asarray(im)))
+            self._run(im, out[i])
+        return out

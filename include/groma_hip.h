@@ -140,6 +140,15 @@ int gr_resize_h_u8(const void* in, void* out, const int* bounds, const int* coef
 int gr_resize_v_norm(const void* in, void* out_u8, float* out_f32, const int* bounds, const int* coef, const float* lut,
                      int Hin, int Hout, int W, int ksize, hipStream_t stream);
 
+/* the eval datasets' mmdet pipeline (groma/data/datasets/refcoco_rec.py:38-65): cv2.resize INTER_LINEAR of the uint8 HWC (BGR)
+ * image (mmcv/image/geometric.py:51-101) fused with mmcv.imnormalize(mean, std, to_rgb) (mmcv/image/photometric.py:9-45).
+ * xofs [Wout] / xalpha int16 [Wout,2] and yofs [Hout] / ybeta int16 [Hout,2]: OpenCV's per-axis tap index and 11-bit fixed-point
+ * coefficients, computed on the host as OpenCV does (groma_amd/preprocess.py); an exact 2x down-scale takes the INTER_AREA fast
+ * path and needs no tables.  out_u8 [Hout,Wout,3] (the resized image, optional) and/or out_f32 [3,Hout,Wout] (normalised). */
+int gr_cv2_resize_norm(const void* in, int Hin, int Win, const int* xofs, const short* xalpha, const int* yofs,
+                       const short* ybeta, void* out_u8, float* out_f32, const double* mean, const double* stdinv, int to_rgb,
+                       int Hout, int Wout, hipStream_t stream);
+
 /* ------------------------------------------------------------------------- packing / movement -- */
 int gr_patchify(const float* images, void* out, int B, int S, int P, int Kpad, hipStream_t stream);
 int gr_fill_rows_f32(const float* src, float* dst, int rows, int C, long ld_dst, hipStream_t stream);

@@ -53,3 +53,29 @@ def test_normalise_table_equals_hf_processor():
     lut = normalise_table()
     ref = np.stack([lut[c][a[..., c]] for c in range(3)])
     assert np.array_equal(np.asarray(out, dtype=np.float32), ref)
+
+
+def test_cv2_tables_and_oracle_properties():
+    """the mmdet / cv2 route (oracle/cv2_pipeline.py; parity unpinned: OpenCV is not in this image): the host tables of the
+    product equal the oracle's, and the restated resize has the properties OpenCV's has -- identity at equal size, constants
+    preserved, exact 2x down-scale = 2x2 box average, coefficients sum to 2048 +- 1, Normalize = mmcv's double arithmetic."""
+    from groma_amd import preprocess as PP
+    from oracle import cv2_pipeline as CV
+    for src, dst in ((640, 448), (480, 448), (37, 448), (448, 448), (1333, 448)):
+        o1, c1 = PP.cv2_linear_tables(src, dst, True)
+        o2, c2 = CV.linear_tables(src, dst)
+        assert np.array_equal(o1, o2) and np.array_equal(c1, c2)
+        o3, c3 = PP.cv2_linear_tables(src, dst, False)
+        o4, c4 = CV.linear_tables_y(src, dst)
+        assert np.array_equal(o3, o4) and np.array_equal(c3, c4)
+        assert np.all(np.abs(c1.astype(int).sum(1) - 2048) <= 1) and o1.min() >= 0 and o1.max() <= src - 1
+    rng = np.random.default_rng(0)
+    img = rng.integers(0, 256, (61, 83, 3), dtype=np.uint8)
+    assert np.array_equal(CV.resize_linear_u8(img, 61, 83), img)
+    assert (CV.resize_linear_u8(np.full((20, 30, 3), 77, np.uint8), 448, 448) == 77).all()
+    big = rng.integers(0, 256, (896, 896, 3), dtype=np.uint8)
+    s = big.astype(np.int32)
+    assert np.array_equal(CV.resize_linear_u8(big, 448, 448), ((s[0::2, 0::2] + s[0::2, 1::2] + s[1::2, 0::2] + s[1::2, 1::2] + 2) >> 2))
+    x = CV.imnormalize(img, PP.MMDET_MEAN, PP.MMDET_STD, True)
+    ref = (img[..., ::-1].astype(np.float64) - np.array(PP.MMDET_MEAN)) / np.array(PP.MMDET_STD)
+    assert x.dtype == np.float32 and np.abs(x - ref).max() < 1e-6

@@ -49,3 +49,19 @@ def test_preprocessed_batch_feeds_the_model(dev):
     torch.manual_seed(1); l1, _ = model.forward(input_ids=ids.clone(), images=x_dev)
     torch.manual_seed(1); l2, _ = model.forward(input_ids=ids.clone(), images=x_ref)
     assert torch.equal(l1, l2)
+
+
+@pytest.mark.parametrize("H,W", [(480, 640), (448, 448), (896, 896), (37, 53), (1000, 333), (449, 447)])
+def test_mmdet_cv2_pipeline_bit_exact_vs_oracle(dev, H, W):
+    """Resize((448,448)) + Normalize(to_rgb) of the eval datasets (R: groma/data/datasets/refcoco_rec.py:38-65) on the device
+    against the numpy restatement of OpenCV's 8-bit bilinear + mmcv.imnormalize: resized bytes and normalised floats
+    bit-identical (integer arithmetic / IEEE double arithmetic on both sides)."""
+    from groma_amd.preprocess import MmdetTestPipeline
+    from oracle import cv2_pipeline as CV
+    rng = np.random.default_rng(H * 1000 + W)
+    img = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+    pipe = MmdetTestPipeline(448)
+    u8 = pipe.resize_u8(torch.from_numpy(img)).cpu().numpy()
+    assert np.array_equal(u8, CV.resize_linear_u8(img, 448, 448))
+    out = pipe([torch.from_numpy(img)])[0].cpu().numpy()
+    assert np.array_equal(out, CV.mmdet_test_pipeline(img, 448))
