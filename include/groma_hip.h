@@ -83,7 +83,8 @@ int gr_gemm_f32(const float* A, const float* W, float* C, const float* bias, con
                 long lda, long ldw, long ldc, int act, hipStream_t stream);
 
 /* ------------------------------------------------------------------------------ normalisation -- */
-/* out = LN(x (+ add)) * gamma + beta over C (C % 256 == 0, C <= 4096); out bf16 or f32. */
+/* out = LN(x (+ add)) * gamma + beta over C (C % 4 == 0; register-resident kernel for C = 256 * 2^k <= 4096, a streaming
+ * kernel for every other width); out bf16 or f32. */
 int gr_layernorm(const float* x, const float* add, const float* gamma, const float* beta, void* out, int rows, int C,
                  long ldx, long ldo, float eps, int out_bf16, int relu_in, hipStream_t stream);
 /* fp8 row quantisation: q = e4m3(x / s), s[m] = max|x[m,:]| / 448 ; and the fused norm -> fp8 variant */

@@ -3,12 +3,13 @@
     rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d <dir>/fetch -- python bench.py --steps 1 --warmup 1 --batch B --no-cpu-baseline
     rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d <dir>/write -- python bench.py --steps 1 --warmup 1 --batch B --no-cpu-baseline
 
-into profiles/r01_pmc_traffic_b<B>.json: per kernel, average counter value per launch (KB) and bytes per launch with the
+into profiles/<round>_pmc_traffic_b<B>.json: per kernel, average counter value per launch (KB) and bytes per launch with the
 guide's gfx950 correction (FETCH_SIZE counts a wide streaming read at half its bytes -> x2; WRITE_SIZE taken as is).
-usage: python profiles/pmc_summarize.py <dir> <batch>"""
+usage: python profiles/pmc_summarize.py <dir> <batch> [round tag, default r02]"""
 import csv, glob, json, os, sys, collections
 
 d, batch = sys.argv[1], int(sys.argv[2])
+tag = sys.argv[3] if len(sys.argv) > 3 else "r02"
 
 
 def load(sub, counter):
@@ -32,6 +33,6 @@ for k in sorted(set(fe) | set(wr)):
     fk = f[0] / max(f[1], 1); wk = w[0] / max(w[1], 1)
     out["kernels"][k] = {"FETCH_SIZE_KB_per_launch": fk, "launches": max(f[1], w[1]), "WRITE_SIZE_KB_per_launch": wk,
                          "traffic_bytes_per_launch": (2.0 * fk + wk) * 1024.0}
-p = os.path.join(os.path.dirname(os.path.abspath(__file__)), f"r01_pmc_traffic_b{batch}.json")
+p = os.path.join(os.path.dirname(os.path.abspath(__file__)), f"{tag}_pmc_traffic_b{batch}.json")
 json.dump(out, open(p, "w"), indent=1)
 print(p, len(out["kernels"]), "kernels")

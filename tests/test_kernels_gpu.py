@@ -147,7 +147,7 @@ def test_gemm_f32(dev, M, N, K):
     assert relerr(out, a.double() @ w.double().t()) < 1e-6
 
 
-@pytest.mark.parametrize("C", [256, 1024, 4096])
+@pytest.mark.parametrize("C", [256, 1024, 4096, 768, 5120, 1280, 8192, 100])
 def test_norms(dev, C):
     ops = _ops()
     x = rnd((37, C), dev, 2.0, seed=1) + 0.5
