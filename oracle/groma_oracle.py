@@ -9,9 +9,13 @@ PARITY PIN STATUS
   * MSDA: pinned by the reference's own recipe (mmcv/tests/test_ops/test_ms_deformable_attn.py:54-70) -- the
     grid_sample formulation of mmcv/mmcv/ops/multi_scale_deform_attn.py:93-150 is used verbatim here.
   * DINOv2 / Deformable-DETR layers / LLaMA arithmetic lives in the un-vendored `transformers==4.32.0`
-    (pyproject.toml:19 of the reference) -- NOT under /root/reference, and no reference test pins it:
-    **parity unpinned** for those stages.  They are restated from the published 4.32 algorithm and cross-checked
-    against the transformers 5.15 modules on disk where the math is unchanged (tests/test_oracle_vs_hf.py).
+    (pyproject.toml:19 of the reference) -- NOT under /root/reference, not installable here, and no reference test pins
+    it.  It is restated from the published 4.32 algorithm and PINNED to the closest executable statement of it, the
+    transformers 5.15 modules on disk, at 2e-5 (tests/test_oracle_vs_hf.py): Dinov2Model, LlamaModel (right padding,
+    incremental decoding), DeformableDetrEncoderLayer / DecoderLayer / MultiscaleDeformableAttention /
+    SinePositionEmbedding / get_reference_points / gen_encoder_output_proposals / get_proposal_pos_embed /
+    MLPPredictionHead / inverse_sigmoid (4.32 <-> 5.15 renames mapped in the test).  T8 (4.32's position-table
+    resize) is restated from the 4.32 formula: that one line is unpinned.
 
 Every function cites the reference file:line it follows ("R:" = /root/reference/, "HF:" = transformers 4.32 semantics,
 cross-checked in /usr/local/lib/python3.10/dist-packages/transformers/models/...).
