@@ -133,6 +133,44 @@ def cpu_baseline(cfg_name, threads=None, full_reps=1):
                       f"(vit {t_vit * nv:.2f}, ddetr {t_det:.2f}, region {t_fuse * nf + t_roi:.2f}, llm {t_llm * nl + t_head:.2f})"}
 
 
+def measure_traffic(batch, kernel="gemm_bf16_256_kernel"):
+    """HBM-side traffic of the dominant kernel, measured NOW: two separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE --
+    they do not fit one pass on gfx950) of `bench.py --steps 1 --warmup 1 --batch B` as child processes, exactly the recipe of
+    MI355X_MICROARCH.md (cwd /tmp, TMPDIR=/tmp, counters with --kernel-trace only).  Returns bytes per launch with the guide's
+    gfx950 correction (FETCH_SIZE counts a wide streaming read at half its bytes -> x2), or None if the profiler is unavailable."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    if shutil.which("rocprofv3") is None:
+        return None
+    tmp = tempfile.mkdtemp(prefix="groma_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    avg = {}
+    try:
+        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(tmp, ctr)
+            cmd = ["rocprofv3", "--pmc", ctr, "--kernel-trace", "--output-format", "csv", "-d", out, "--", sys.executable,
+                   os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "1", "--batch", str(batch), "--no-cpu-baseline",
+                   "--no-traffic"]
+            subprocess.run(cmd, cwd="/tmp", env=env, timeout=420, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=True)
+            tot, n = 0.0, 0
+            for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
+                for r in csv.DictReader(open(f)):
+                    if r["Counter_Name"] == ctr and r["Kernel_Name"].startswith(kernel):
+                        tot += float(r["Counter_Value"])
+                        n += 1
+            if n == 0:
+                return None
+            avg[ctr] = tot / n
+        return (2.0 * avg["FETCH_SIZE"] + avg["WRITE_SIZE"]) * 1024.0
+    except Exception:
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -155,6 +193,8 @@ def main():
                          "processed in micro-batches of --batch.  BASELINE configs[3] = --mode generate --global-batch 32 --batch 4 "
                          "(4 images per GPU at 8 ranks).  0 (default) = weak scaling, --batch images on every rank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-traffic", action="store_true",
+                    help="skip the live rocprofv3 PMC passes for roofline.traffic (the committed profiles/ summary is reported instead)")
     ap.add_argument("--cpu-baseline-reps", type=int, default=1, help="timed full-depth oracle forwards (median is reported)")
     ap.add_argument("--gemm-breakdown", default=None, help="write a per-shape GEMM table (from the HIP-event hook) here")
     args = ap.parse_args()
@@ -238,18 +278,24 @@ def main():
     gemm_ms = sum(r[4] for r in dom)
     gemm_launches = len(dom)
     gemm_flops = sum(2.0 * r[0] * r[1] * r[2] for r in dom)
-    # HBM-side traffic of the dominant kernel: rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE, separate runs, gfx950
-    # correction applied) of THIS command, summarised under profiles/ -- bench.py cannot drive the profiler itself
-    traffic, traffic_file = None, None
-    try:
-        import glob
-        cands = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_pmc_traffic_b{args.batch}.json")))
-        if cands and args.config == "7b" and not fp8 and not gen:
-            traffic_file = os.path.basename(cands[-1])  # the newest round's counters
-            with open(cands[-1]) as f:
-                traffic = json.load(f)["kernels"]["gemm_bf16_256_kernel(GemmArgs)"]["traffic_bytes_per_launch"]
-    except Exception:
-        traffic = None
+    # HBM-side traffic of the dominant kernel: measured live by two rocprofv3 --pmc child runs of this command (rank 0, one
+    # GPU, forward mode); if the profiler cannot run here, the newest committed summary of the same passes is reported and
+    # `traffic_source` says so
+    traffic, traffic_source = None, None
+    if rank == 0 and world == 1 and not args.no_traffic and args.config == "7b" and not fp8 and not gen:
+        traffic = measure_traffic(args.batch)
+        if traffic is not None:
+            traffic_source = "measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (separate child runs, gfx950 x2 fetch correction)"
+    if traffic is None and args.config == "7b" and not fp8 and not gen:
+        try:
+            import glob
+            cands = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_pmc_traffic_b{args.batch}.json")))
+            if cands:
+                with open(cands[-1]) as f:
+                    traffic = json.load(f)["kernels"]["gemm_bf16_256_kernel(GemmArgs)"]["traffic_bytes_per_launch"]
+                traffic_source = "committed summary of the same rocprofv3 passes: profiles/" + os.path.basename(cands[-1])
+        except Exception:
+            traffic = None
     ips = job.global_batch * args.steps / elapsed
     peak = 5000.0 if fp8 else 2500.0  # dense MFMA peak of the operand type (MI355X_MICROARCH.md)
     kname = "gemm_fp8_256_kernel(GemmArgs) -- 256x256 ping-pong e4m3 MFMA GEMM" if fp8 else \
@@ -270,8 +316,8 @@ def main():
                    "parallelism": f"dp{world} (image batch sharded, full replica per GPU)"},
         "roofline": {"bound": "mfma", "kernel": kname,
                      "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
-                     "traffic_note": "bytes/launch of gemm_bf16_256_kernel at the L2<->fabric boundary (Infinity-Cache hits "
-                                     "included), rocprofv3 PMC passes of this command committed as profiles/%s" % traffic_file if traffic else None,
+                     "traffic_note": ("bytes/launch of gemm_bf16_256_kernel at the L2<->fabric boundary (Infinity-Cache hits "
+                                      "included; DESIGN.md 3a); " + traffic_source) if traffic else None,
                      "launches_per_step": gemm_launches / max(args.steps, 1),
                      "avg_launch_us": gemm_ms * 1e3 / max(gemm_launches, 1),
                      "flops_per_launch": gemm_flops / max(gemm_launches, 1),
