@@ -298,3 +298,23 @@ def test_generate_sampling_reproducible_and_graph_equals_eager(setup):
             model.generate(ids.clone(), images=images, do_sample=True, top_p=0.9, max_new_tokens=2)
     finally:
         gc.eos_token_id, model.decode_graph = old
+
+
+def test_forward_with_hundreds_of_refer_boxes(setup):
+    """300 proposals + 260 refer / ground boxes per image = 560 NMS candidates: above the one-workgroup limit of 512 that used
+    to return EINVAL; the three-launch general NMS path must give the oracle's keep ids, order and logits."""
+    cfg, sd, tk, model, images, ids = setup
+    g = torch.Generator().manual_seed(3)
+    refer = [torch.cat([torch.rand((200, 2), generator=g), 0.05 + 0.2 * torch.rand((200, 2), generator=g)], 1) for _ in range(2)]
+    ground = [torch.cat([torch.rand((60, 2), generator=g), 0.05 + 0.2 * torch.rand((60, 2), generator=g)], 1) for _ in range(2)]
+    torch.manual_seed(8)
+    out = model.forward(input_ids=ids.clone(), images=images, refer_boxes=refer, ground_boxes=ground, return_dict=True)
+    dev_h = [h.cpu() for h in model._last_aux["hidden4"]]
+    torch.manual_seed(8)
+    ref = O.groma_forward(sd, cfg.to_dict(), util.tok_dict(tk), ids.clone(), images, refer_boxes=refer, ground_boxes=ground,
+                          hidden_states=tuple(dev_h))
+    for i in range(2):
+        assert torch.equal(model._last_aux["nms_keep"][i], ref["nms_inds"][i])
+        assert (ref["nms_inds"][i] >= 300).any()  # refer boxes (score 1.0) really took part
+    assert torch.equal(model._last_aux["input_ids"], ref["input_ids"])
+    assert util.relerr(out.logits, ref["logits"]) < 2e-2
