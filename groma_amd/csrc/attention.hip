@@ -50,35 +50,7 @@ extern "C" int gr_diag_att_clk(unsigned long long* out) { return (int)hipMemcpyF
 #define ATT_MARK(i)
 #endif
 
-// Cross-row reductions of the soft-max statistics (lanes that differ in bits 4 and 5 hold the same query): gfx950's
-// v_permlane16_swap / v_permlane32_swap exchange register halves inside the VALU, where __shfl_xor(x, 16 | 32) compiles to
-// ds_bpermute_b32 -- an LDS-crossbar round trip on the critical path max -> exp -> sum of every tile.  With both operands = x
-// the swap leaves (x[lane], x[lane ^ 16|32]) in the two results (in either order), so a commutative op gives the same bits.
-__device__ __forceinline__ void xswap16(float x, float& a, float& b) {
-  const auto r = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, x), __builtin_bit_cast(unsigned, x), false, false);
-  a = __builtin_bit_cast(float, r[0]);
-  b = __builtin_bit_cast(float, r[1]);
-}
-__device__ __forceinline__ void xswap32(float x, float& a, float& b) {
-  const auto r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, x), __builtin_bit_cast(unsigned, x), false, false);
-  a = __builtin_bit_cast(float, r[0]);
-  b = __builtin_bit_cast(float, r[1]);
-}
-__device__ __forceinline__ float rows_max(float x) {
-  float a, b;
-  xswap16(x, a, b);
-  x = fmaxf(a, b);
-  xswap32(x, a, b);
-  return fmaxf(a, b);
-}
-__device__ __forceinline__ float rows_sum(float x) {
-  float a, b;
-  xswap16(x, a, b);
-  x = a + b;
-  xswap32(x, a, b);
-  return a + b;
-}
-
+// (soft-max row statistics are reduced across the four 16-lane rows with rows_max / rows_sum, gr_common.h)
 #ifndef ATT_G
 #define ATT_G (HD == 128 ? 8 : 2)  // K / V^T fragments per prefetch group (A/B: hd 128 -5 % with 8, hd 64 neutral)
 #endif

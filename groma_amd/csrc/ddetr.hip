@@ -133,17 +133,118 @@ __global__ __launch_bounds__(320) void mha32_kernel(const float* __restrict__ qk
   }
 }
 
+// ---- the same operator on the f32-input MFMA (Q <= 320: the reference runs 300 queries) --------------------------------
+// Round 1's kernel above walks 300 keys x 32 dims per query thread with one broadcast LDS read per FMA (240 us standalone at
+// 1 image, 441 us at 14 while time-sharing the chip: 2.6 ms of a step).  Here a wave owns 16 queries:
+//   S^T = K . (Q*scale)^T      20 key tiles x 8 v_mfma_f32_16x16x4_f32, all of S^T kept in registers (80 VGPRs / lane) --
+//                              a lane holds 4 consecutive keys of ONE query, so the exact two-pass soft-max (max, then
+//                              exp / sum: torch.softmax semantics) is in-lane + 2 permlane swaps;
+//   O^T = V^T . P^T            P^T is the MFMA B operand straight from those registers (the key order inside a 16-key tile
+//                              is permuted identically on the V^T side: key fg*4 + e is "k-slot fg" of step e);
+// K rows are padded to 36 floats and V is transposed into [dim][key + 4] while staging, so every fragment is one
+// conflict-free ds_read_b128.  Everything is fp32 (products, sums, exp): same tolerance class as gemm_f32.
+template <int NKT>  // key tiles of 16
+__global__ __launch_bounds__(640) void mha32_mfma_kernel(const float* __restrict__ qk, const float* __restrict__ v,
+                                                         float* __restrict__ out, int Q, int heads, int ldqk, float scale) {
+  constexpr int QP = NKT * 16, KS = 36, VS = QP + 4;
+  extern __shared__ __attribute__((aligned(16))) float sm2[];
+  float* ks = sm2;             // [QP][KS]   K rows (dims 0..31)
+  float* vt = sm2 + QP * KS;   // [32][VS]   V transposed
+  const int bh = blockIdx.y, b = bh / heads, h = bh % heads;
+  const int D = heads * 32;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int fr = lane & 15, fg = lane >> 4;
+  for (int i = tid; i < QP * 8; i += 640) {  // 16-B chunks of K and V
+    const int r = i >> 3, c = (i & 7) * 4;
+    f32x4 kv = {0.f, 0.f, 0.f, 0.f}, vv = {0.f, 0.f, 0.f, 0.f};
+    if (r < Q) {
+      kv = *(const f32x4*)(qk + ((long)b * Q + r) * ldqk + D + h * 32 + c);
+      vv = *(const f32x4*)(v + ((long)b * Q + r) * D + h * 32 + c);
+    }
+    *(f32x4*)(ks + r * KS + c) = kv;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) vt[(c + e) * VS + r] = vv[e];
+  }
+  __syncthreads();
+  const int q0 = (blockIdx.x * 10 + wave) * 16;
+  if (q0 >= Q) return;
+  int qrow = q0 + fr;
+  if (qrow > Q - 1) qrow = Q - 1;
+  // B operand of S^T: lane (query fr, k-group fg) owns dims fg*8 .. fg*8+7 (the same dim permutation as the K side)
+  const float* qp = qk + ((long)b * Q + qrow) * ldqk + h * 32 + fg * 8;
+  f32x4 qa = *(const f32x4*)qp, qb = *(const f32x4*)(qp + 4);
+  qa *= scale; qb *= scale;
+  f32x4 s[NKT];
+#pragma unroll
+  for (int t = 0; t < NKT; ++t) {
+    const float* kp = ks + (t * 16 + fr) * KS + fg * 8;
+    const f32x4 ka = *(const f32x4*)kp, kb = *(const f32x4*)(kp + 4);
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ka[e], qa[e], acc, 0, 0, 0);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(kb[e], qb[e], acc, 0, 0, 0);
+    s[t] = acc;  // keys t*16 + fg*4 + {0..3} of query fr
+  }
+  float mx = -INFINITY;
+#pragma unroll
+  for (int t = 0; t < NKT; ++t)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      if (t * 16 + fg * 4 + e >= Q) s[t][e] = -INFINITY;
+      mx = fmaxf(mx, s[t][e]);
+    }
+  mx = rows_max(mx);
+  float den = 0.f;
+#pragma unroll
+  for (int t = 0; t < NKT; ++t)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float p = expf(s[t][e] - mx);  // exp(-inf) = 0 for the padded keys
+      s[t][e] = p;
+      den += p;
+    }
+  den = rows_sum(den);
+  f32x4 o[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+  for (int t = 0; t < NKT; ++t) {
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt) {
+      const f32x4 va = *(const f32x4*)(vt + (dt * 16 + fr) * VS + t * 16 + fg * 4);  // V^T[dim][keys t*16 + fg*4 + e]
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(va[e], s[t][e], o[dt], 0, 0, 0);
+    }
+  }
+  if (q0 + fr < Q) {
+    const float inv = 1.f / den;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+      *(f32x4*)(out + ((long)b * Q + q0 + fr) * D + h * 32 + dt * 16 + fg * 4) = o[dt] * inv;
+  }
+}
+
 extern "C" int gr_mha32_f32(const float* qk, const float* v, float* out, int B, int Q, int heads, int ldqk, float scale,
                             hipStream_t stream) {
   if (!qk || !v || !out || B <= 0 || Q <= 0 || Q > 1024) return GR_EINVAL;
-  const size_t smem = (size_t)Q * 64 * sizeof(float);
-  if (smem > 160 * 1024) return GR_EINVAL;
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)mha32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e == hipSuccess)
+      e = hipFuncSetAttribute((const void*)mha32_mfma_kernel<20>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
     if (e != hipSuccess) return (int)e;
     attr_set = true;
   }
+  const bool aligned = (ldqk & 3) == 0 && ((((uintptr_t)qk) | ((uintptr_t)v) | ((uintptr_t)out)) & 15) == 0;
+  if (Q <= 320 && aligned) {  // the reference's 300 queries: MFMA kernel, 160 queries per block
+    constexpr int NKT = 20;
+    const size_t smem = ((size_t)NKT * 16 * 36 + 32 * (NKT * 16 + 4)) * sizeof(float);
+    hipLaunchKernelGGL(mha32_mfma_kernel<NKT>, dim3(gr_cdiv(Q, 160), B * heads), dim3(640), smem, stream, qk, v, out, Q, heads,
+                       ldqk, scale);
+    GR_CHECK_LAUNCH();
+    return GR_OK;
+  }
+  const size_t smem = (size_t)Q * 64 * sizeof(float);
+  if (smem > 160 * 1024) return GR_EINVAL;
   hipLaunchKernelGGL(mha32_kernel, dim3(B * heads), dim3(320), smem, stream, qk, v, out, Q, heads, ldqk, scale);
   GR_CHECK_LAUNCH();
   return GR_OK;

@@ -54,6 +54,37 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
+// Reductions across the four 16-lane rows of a wave (lanes that differ in bits 4 and 5) inside the VALU: gfx950's
+// v_permlane16_swap / v_permlane32_swap exchange register halves, where __shfl_xor(x, 16 | 32) compiles to ds_bpermute_b32 (an
+// LDS-crossbar round trip).  With both operands = x the swap leaves (x[lane], x[lane ^ 16|32]) in the two results, in either
+// order, so a commutative op gives the same bits as the shuffle form.
+// Inline asm on purpose: with hipcc (ROCm 7.2) __builtin_amdgcn_permlane{16,32}_swap returns its FIRST result for both elements
+// of the result pair (the ISA read v_add v, v0, v0 / dropped the max altogether), which silently breaks every reduction.
+__device__ __forceinline__ void xswap16(float x, float& a, float& b) {
+  a = x;
+  b = x;
+  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));  // rows 1,3 of a <-> rows 0,2 of b
+}
+__device__ __forceinline__ void xswap32(float x, float& a, float& b) {
+  a = x;
+  b = x;
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));  // lanes 32..63 of a <-> lanes 0..31 of b
+}
+__device__ __forceinline__ float rows_max(float x) {
+  float a, b;
+  xswap16(x, a, b);
+  x = fmaxf(a, b);
+  xswap32(x, a, b);
+  return fmaxf(a, b);
+}
+__device__ __forceinline__ float rows_sum(float x) {
+  float a, b;
+  xswap16(x, a, b);
+  x = a + b;
+  xswap32(x, a, b);
+  return a + b;
+}
+
 // block-wide sum for blockDim.x <= 1024 (multiple of 64); red must hold 16 floats
 __device__ __forceinline__ float block_sum(float v, float* red) {
   v = wave_sum(v);

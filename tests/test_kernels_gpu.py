@@ -345,18 +345,23 @@ def test_msda(dev, rdim):
     assert relerr(out, ref) < 1e-5
 
 
-def test_mha32(dev):
+@pytest.mark.parametrize("B,Q,sharp", [(2, 300, 1.0), (14, 300, 4.0), (3, 77, 1.0), (1, 320, 2.0), (2, 400, 1.0), (1, 16, 1.0)])
+def test_mha32(dev, B, Q, sharp):
+    """decoder self-attention (fp32, 8 heads x 32): the MFMA kernel for Q <= 320 (partial key / query tiles, padded keys
+    masked) and the per-thread fallback above that, against torch's exact softmax"""
     ops = _ops()
-    B, Q, heads = 2, 300, 8
+    heads = 8
     D = heads * 32
-    qk = rnd((B * Q, 2 * D), dev, seed=1)
+    qk = rnd((B * Q, 2 * D), dev, sharp, seed=1)
     v = rnd((B * Q, D), dev, seed=2)
     scale = 32 ** -0.5
     q_ = qk[:, :D].view(B, Q, heads, 32).transpose(1, 2) * scale
     k_ = qk[:, D:].view(B, Q, heads, 32).transpose(1, 2)
     v_ = v.view(B, Q, heads, 32).transpose(1, 2)
-    ref = (torch.softmax(q_ @ k_.transpose(-1, -2), -1) @ v_).transpose(1, 2).reshape(B * Q, D)
-    assert relerr(ops.mha32(qk, v, B=B, Q=Q, heads=heads, scale=scale), ref) < 1e-5
+    ref = (torch.softmax(q_.double() @ k_.double().transpose(-1, -2), -1) @ v_.double()).transpose(1, 2).reshape(B * Q, D).float()
+    out = ops.mha32(qk, v, B=B, Q=Q, heads=heads, scale=scale)
+    assert relerr(out, ref) < 1e-5
+    assert torch.equal(out, ops.mha32(qk, v, B=B, Q=Q, heads=heads, scale=scale))
 
 
 def test_ddetr_small(dev):
