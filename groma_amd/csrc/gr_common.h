@@ -43,17 +43,6 @@ __device__ __forceinline__ float silu_f(float x) {  // x * sigmoid(x); v_exp + v
 }
 __device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + expf(-x)); }
 
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
-}
-__device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-  return v;
-}
-
 // Reductions across the four 16-lane rows of a wave (lanes that differ in bits 4 and 5) inside the VALU: gfx950's
 // v_permlane16_swap / v_permlane32_swap exchange register halves, where __shfl_xor(x, 16 | 32) compiles to ds_bpermute_b32 (an
 // LDS-crossbar round trip).  With both operands = x the swap leaves (x[lane], x[lane ^ 16|32]) in the two results, in either
@@ -83,6 +72,28 @@ __device__ __forceinline__ float rows_sum(float x) {
   x = a + b;
   xswap32(x, a, b);
   return a + b;
+}
+
+// Wave-wide all-reduce: inside a 16-lane row by DPP rotations (row_ror 8, 4, 2, 1: VALU data path), across the four rows by the
+// permlane swaps above.  (__shfl_xor compiles to ds_bpermute_b32 for every distance on this compiler -- six dependent LDS-crossbar
+// round trips per reduction, which is most of the latency of the small decode / DDETR kernels.)
+template <int N>
+__device__ __forceinline__ float dpp_ror(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x120 + N, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float wave_sum(float v) {
+  v += dpp_ror<8>(v);
+  v += dpp_ror<4>(v);
+  v += dpp_ror<2>(v);
+  v += dpp_ror<1>(v);
+  return rows_sum(v);
+}
+__device__ __forceinline__ float wave_max(float v) {
+  v = fmaxf(v, dpp_ror<8>(v));
+  v = fmaxf(v, dpp_ror<4>(v));
+  v = fmaxf(v, dpp_ror<2>(v));
+  v = fmaxf(v, dpp_ror<1>(v));
+  return rows_max(v);
 }
 
 // block-wide sum for blockDim.x <= 1024 (multiple of 64); red must hold 16 floats

@@ -469,7 +469,7 @@ class GromaModel:
         return dec
 
     def _generate_graph(self, seqs, ids, images, refer_boxes, ground_boxes, max_new_tokens, eos, pad, return_dict,
-                        output_hidden_states, temperature=0.0, seeds=None):
+                        output_hidden_states, temperature=0.0, draw_seeds=None):
         """generate() with the per-token step captured once in a hipGraph (engine.GreedyDecoder): the step position,
         the token fed back, the finished mask and the output ids all live on the device, so one replay = one token
         and the host only reads the unfinished-row count when an EOS id is configured."""
@@ -479,11 +479,11 @@ class GromaModel:
         bound = P + n_img_tok + 2 * self.config.max_region_num + (sum(len(b) for b in refer_boxes) if refer_boxes else 0)
         smax = engine._ru(bound + max_new_tokens + 1, 256)
         dec = self._decoder(bs, smax, engine._ru(max_new_tokens, 64), eos, pad)
-        dec.set_sampling(temperature, seeds)
         first = self.forward(input_ids=ids, images=images, refer_boxes=refer_boxes, ground_boxes=ground_boxes,
                              use_cache=True, output_hidden_states=output_hidden_states, return_dict=True,
                              _last_logits_only=True, _reserve=max_new_tokens, _cache=dec.cache)
         L = dec.cache.seq_len
+        dec.set_sampling(temperature, draw_seeds() if draw_seeds is not None else None)
         n = dec.run(first.logits[:, -1, :], L, max_new_tokens)
         dec.cache.seq_len = L + n - 1
         seqs = torch.cat([seqs, dec.seq[:, :n]], dim=-1)
@@ -511,8 +511,9 @@ class GromaModel:
             if kw.get("top_k") not in (None, 0) or kw.get("top_p") not in (None, 1.0):
                 raise NotImplementedError("top_k / top_p sampling is not implemented (temperature sampling only)")
             temperature = float(kw.get("temperature", getattr(gc, "temperature", 1.0) or 1.0))
-        # one draw of the CPU global RNG seeds the rows' counter-based samplers (torch.manual_seed makes a run reproducible)
-        seeds = torch.randint(0, 2 ** 62, (input_ids.shape[0],), dtype=I64) if do_sample else None
+        # The rows' counter-based samplers are seeded by ONE draw of the CPU global RNG taken AFTER the prefill (so the region
+        # shuffle's torch.randperm, trap T4, sees the same RNG state as in a greedy call; torch.manual_seed reproduces a run)
+        draw_seeds = (lambda: torch.randint(0, 2 ** 62, (input_ids.shape[0],), dtype=I64)) if do_sample else (lambda: None)
         if max_new_tokens is None:
             max_new_tokens = getattr(gc, "max_new_tokens", 20) or 20
         eos = getattr(gc, "eos_token_id", None)
@@ -524,7 +525,7 @@ class GromaModel:
         ids_for_model = input_ids.to(dev)
         if self.decode_graph and max_new_tokens > 1:
             return self._generate_graph(seqs, ids_for_model, images, refer_boxes, ground_boxes, max_new_tokens, eos, pad,
-                                        return_dict_in_generate, output_hidden_states, temperature, seeds)
+                                        return_dict_in_generate, output_hidden_states, temperature, draw_seeds)
         out = self.forward(input_ids=ids_for_model, images=images, refer_boxes=refer_boxes, ground_boxes=ground_boxes,
                            use_cache=True, output_hidden_states=output_hidden_states, return_dict=True,
                            _last_logits_only=True, _reserve=max_new_tokens)
@@ -534,6 +535,7 @@ class GromaModel:
         unfinished = torch.ones(seqs.shape[0], dtype=I64, device=dev)
         bs = seqs.shape[0]
         inv_t = torch.full((bs,), 0.0 if temperature < 1e-4 else 1.0 / temperature, dtype=F32, device=dev)
+        seeds = draw_seeds()
         seed_t = (seeds if seeds is not None else torch.zeros((bs,), dtype=I64)).to(dev)
         pos_t = torch.zeros((1,), dtype=I32, device=dev)
         L0 = cache.seq_len  # expanded prompt length: the first new token sits at position L0
