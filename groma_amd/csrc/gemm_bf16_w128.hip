@@ -1,31 +1,28 @@
 // 256x256 bf16 MFMA GEMM, ONE wave per SIMD: 4 waves (2 x 2), each a 128x128 output block held in 256 accumulator
-// registers (AGPRs) as 4 x 4 tiles of v_mfma_f32_32x32x16_bf16; operands staged global -> VGPR -> LDS.
+// registers (AGPRs) as 8 x 8 tiles of v_mfma_f32_16x16x32_bf16; the LDS is refilled by LDS-DMA.
 //
 // Why: per flop a 128x128 wave block reads a third fewer LDS bytes than the ping-pong kernel's 128x64 blocks
-// (gemm_bf16_256.hip) and no barrier ever gates the matrix pipe.  What the two earlier attempts at this shape taught:
-//   * round 1 fed the LDS with LDS-DMA: 1.07-1.12 PF -- an LDS-DMA issue costs ~60 clk of the only wave's issue time;
-//   * round 2, first version (git 5e7914d): plain `global_load_dwordx4` into spare VGPRs + `ds_write_b128`, 16x16x32
-//     MFMAs, 32-deep steps: bit-identical to the ping-pong kernel, 1.15-1.23 PF.  Ablation builds: without the loop's
-//     fragment reads 1.40 PF, without its global loads 1.51 PF -- a 16-clk MFMA gap hides ~one other instruction, and a
-//     32-deep step fetches HALF of every 128-B line per request.
-// Hence here: the 32x32x16 MFMA (32-clk gaps, half as many issues for the same flops) and 64-deep K-tiles fetched as
-// whole 128-B rows.  (The vendor library's kernel for these shapes has the same outline: 256 threads, 256x256x64
-// macro-tile, 512 registers, ~130 KB LDS -- profiles/r02_blas_yardstick.txt.)
+// (gemm_bf16_256.hip) and no barrier gates the matrix pipe.  (The vendor library's kernel for these shapes has this
+// outline: 256 threads, 256x256x64 macro-tile, 512 registers, direct-to-LDS loads -- profiles/r02_blas_yardstick.txt.)
+// History of the shape in this repo, all bit-identical to the ping-pong kernel:
+//   * round 1: LDS-DMA, "2 ds_read + 1 DMA + 8 MFMA" per chunk: 1.07-1.12 PF;
+//   * round 2 (git 5e7914d): global_load -> VGPR -> ds_write_b128, 16x16x32, 32-deep steps: 1.15-1.23 PF;
+//   * round 2 (git bbb44ae): the same with 32x32x16 MFMAs and 64-deep K-tiles: 1.19-1.26 PF.
+// What the price list (tests/diag/filler_price.py: one instruction between two MFMAs of a wave that owns its SIMD, all
+// four SIMDs running the same stream) says about them: a ds_read_b128 per 16-clk gap is free (+0.5 clk) but two in one
+// gap cost +15; a ds_write_b128 costs ~15 clk wherever it sits (13 clk of store path per instruction, CU-wide); an LDS-DMA
+// costs ~8 clk when there is one in every fourth gap -- and four times that when it shares its neighbourhood with LDS
+// reads and writes.  Hence this version: no ds_write in the loop at all, and the DMA issues spread out.
 //
-// Pipeline.  K-tile S (64 k-values) lives in LDS stage S&1 (A 256 x 128 B, then W 256 x 128 B = 64 KB) and is computed
-// in two sub-steps t = 2S, 2S+1 of 32 MFMAs each.  In sub-step t a wave
-//   * computes from the fragment buffer t&1 and reads the fragments of sub-step t+1 into the other one;
-//   * writes 8 of its 16 staging registers to LDS and refills each straight away:  odd t -> pieces 0-7 of K-tile
-//     (t+3)/2, refilled with the same pieces of the tile after it;  even t -> pieces 8-15 of K-tile t/2+1, likewise.
-//     A register therefore has 16 issue slots = two sub-steps (>= 2 x 1024 clk) of flight; `s_waitcnt vmcnt(15)`
-//     before each write is exact (the loads are inline asm, so the counts are ours, not the compiler's).
-//   * one block barrier per K-tile, after the even sub-step: it publishes tile S+1 (written during t = 2S-1 and 2S)
-//     for the fragment reads of t = 2S+1, and it separates the last reads of a stage (during the even sub-step two
-//     tiles earlier) from the first write that reuses it.
-//   * the loop body is branch-free: past the end, loads re-fetch the last K-tile and writes land in a dead stage.
-// LDS image: 128-B rows, 16-B chunk position = k-chunk ^ ((row >> 1) & 7): conflict-free for the 16-lane groups
-// ds_read_b128 is serviced in when a fragment spans 32 consecutive rows; the global side applies the XOR to the per-lane
-// source chunk so the ds_write_b128 is lane-linear (8 rows x 128 B per wave-instruction).
+// Pipeline.  K-tile S (64 k-values) lives in LDS stage S&1 (A 256 x 128 B, then W 256 x 128 B = 64 KB) and is computed in
+// two sub-steps of 64 MFMAs (k-halves h = 0, 1), each from one of two fragment register sets:
+//   even sub-step (S,0): reads the fragments of (S,1); then `vmcnt(0)` (tile S+1, issued a whole sub-step ago, has
+//        landed), `lgkmcnt(0)`, block barrier -- the ONLY one per K-tile: it publishes tile S+1 and tells every wave that
+//        stage S&1 has been read for the last time;
+//   odd sub-step (S,1):  reads the fragments of (S+1,0) and issues this wave's 16 DMA pieces of tile S+2 into stage S&1.
+// The loop body is branch-free: past the end the DMA re-fetches the last K-tile into a stage nobody reads.
+// LDS image (as in the ping-pong kernel): 128-B rows, 16-B chunk position = k-chunk ^ (row & 7); the DMA writes
+// lane-linearly (8 rows x 128 B per wave-instruction) with the XOR applied to the per-lane SOURCE chunk.
 // Epilogue: the shared LDS-staged batched epilogue (gemm_common.h), four 64-row passes.
 // Plain GEMM only (no implicit-conv gather, no fp8); operands must be addressable with 32-bit byte offsets.
 #include "gemm_common.h"
@@ -37,34 +34,21 @@
 #define WSTAGE 65536   // bytes per stage
 #define WB_OFF 32768
 
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-
-// timing ablations for tests/diag (results are wrong with any of them): -DW128_NO_R / _NO_W / _NO_G drop the loop's
-// fragment reads / stage writes / global loads; _NO_WAIT the counted vmcnt waits; _NO_BAR the per-K-tile barrier
+// timing ablations for tests/diag (results are wrong with any of them)
 #ifdef W128_NO_R
 #define W128_R(X)
 #else
 #define W128_R(X) X
 #endif
-#ifdef W128_NO_W
-#define W128_W(X)
+#ifdef W128_NO_G
+#define W128_G(X)
 #else
-#define W128_W(X) X
-#endif
-#ifdef W128_NO_WAIT
-#define W128_WAIT(X)
-#else
-#define W128_WAIT(X) X
+#define W128_G(X) X
 #endif
 #ifdef W128_NO_BAR
 #define W128_BAR(X)
 #else
 #define W128_BAR(X) X
-#endif
-#ifdef W128_NO_G
-#define W128_G(X)
-#else
-#define W128_G(X) X
 #endif
 
 __global__ __launch_bounds__(WNT, 1) void gemm_bf16_w128_kernel(GemmArgs p) {
@@ -88,14 +72,13 @@ __global__ __launch_bounds__(WNT, 1) void gemm_bf16_w128_kernel(GemmArgs p) {
   const int kt_begin = z * per;
   const int nt = min(kt_total, kt_begin + per) - kt_begin;
 
-  // ---- staging geometry: piece c (0..15) of a K-tile = 8 rows x 128 B = 1 KB per wave; rows (c&7)*32 + wave*8 + (lane>>3)
-  // of A (c < 8) or W (c >= 8); the lane's 16-B slot lane&7 of its row holds global k-chunk slot ^ swz(row)
-  const int drow = lane >> 3, dpos = lane & 7;
+  // ---- DMA geometry: piece c (0..15) of a K-tile = 8 rows x 128 B = 1 KB per wave; rows (c&7)*32 + wave*8 + (lane>>3) of
+  // A (c < 8) or W (c >= 8).  The row's low 3 bits are lane>>3, so the lane's LDS slot lane&7 holds k-chunk (lane&7)^(lane>>3).
+  const int drow = lane >> 3, kc = (lane & 7) ^ (lane >> 3);
   unsigned goff[16];  // per-lane byte offset from the (uniform) operand base of the K-tile
 #pragma unroll
   for (int c = 0; c < 16; ++c) {
     const int r = (c & 7) * 32 + wave * 8 + drow;
-    const int kc = dpos ^ ((r >> 1) & 7);
     if (c < 8) {
       int m = m0 + r;
       if (m > p.M - 1) m = p.M - 1;
@@ -108,129 +91,97 @@ __global__ __launch_bounds__(WNT, 1) void gemm_bf16_w128_kernel(GemmArgs p) {
   }
   const char* gA = (const char*)p.A + (long)kt_begin * (WKT * 2);
   const char* gW = (const char*)p.W + (long)kt_begin * (WKT * 2);
-  // Inline asm so that the vmcnt waits are OURS.  Rules that follow: a staging register is only read behind an explicit
-  // `s_waitcnt vmcnt(N)`, and the queue is drained (vmcnt(0)) before the registers are dead.
-  auto gload = [&](int c, int tile) -> u32x4 {
+  auto dma_src = [&](int c, int tile) -> const char* {
     const int tc = tile < nt ? tile : nt - 1;  // branch-free tail: re-fetch the last K-tile
-    const char* ptr = (c < 8 ? gA : gW) + (long)tc * (WKT * 2) + goff[c];
-    u32x4 v;
-    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(ptr) : "memory");
-    return v;
+    return (c < 8 ? gA : gW) + (long)tc * (WKT * 2) + goff[c];
   };
-  const int w_lane = wave * 1024 + lane * 16;
-  auto lwrite = [&](int c, int tile, u32x4 v) {
-    *(u32x4*)(smem + (tile & 1) * WSTAGE + w_lane + (c < 8 ? 0 : WB_OFF) + (c & 7) * 4096) = v;
+  auto dma_issue = [&](const char* src, int c, int tile) {  // piece c of K-tile `tile` into stage tile&1
+    glds16(src, smem + (tile & 1) * WSTAGE + (c < 8 ? 0 : WB_OFF) + (c & 7) * 4096 + wave * 1024);
   };
+  auto dma = [&](int c, int tile) { dma_issue(dma_src(c, tile), c, tile); };
 
-  // ---- fragment geometry (swapped operands: the W fragment is the MFMA's first operand, so a lane owns groups of 4
-  // consecutive output columns of one row).  32x32x16: lane -> row lane&31, k-half lane>>5 of the 16-k slice.
-  const int fr = lane & 31, hi = lane >> 5;
-  const int coff = (hi ^ ((fr >> 1) & 7)) << 4;  // chunk (slice*2 + hi) ^ swz(row): the slice enters as XOR (slice << 5)
-  const int a_lane = (wm * 128 + fr) * 128 + coff;
-  const int b_lane = WB_OFF + (wn * 128 + fr) * 128 + coff;
+  // ---- fragment geometry (swapped operands: the W fragment is the MFMA's first operand, so a lane owns 4 consecutive
+  // output columns of one row)
+  const int fr = lane & 15, fg = lane >> 4;
+  const int off0 = (fg ^ (fr & 7)) << 4;  // k-half h enters as XOR (h << 6)
+  const int a_lane = (wm * 128 + fr) * 128 + off0;
+  const int b_lane = WB_OFF + (wn * 128 + fr) * 128 + off0;
 
-  f32x16 acc[4][4];  // [mi][nj]
+  f32x4 acc[8][8];  // [mi][nj]
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < 8; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    for (int j = 0; j < 8; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  bf16x8 af[2][4][2], bf[2][4][2];  // [buffer][tile index][k-slice of the sub-step]
-  u32x4 stg[16];
-  // fragment `idx` (32 rows) of operand `which` (0: W, 1: A), k-slice kk of sub-step t, into buffer buf
-  auto read_frag = [&](int buf, int t, int which, int idx, int kk) {
+  bf16x8 af[2][8], bf[2][8];  // [fragment set][16-row tile]
+  // fragment r (0-7: W tile r, 8-15: A tile r-8) of sub-step t into set `buf`
+  auto read_frag = [&](int buf, int t, int r) {
     const char* st = smem + ((t >> 1) & 1) * WSTAGE;
-    const int x = (((t & 1) * 2 + kk) << 5);
-    if (which == 0) bf[buf][idx][kk] = *(const bf16x8*)(st + (b_lane ^ x) + idx * 4096);
-    else af[buf][idx][kk] = *(const bf16x8*)(st + (a_lane ^ x) + idx * 4096);
+    const int x = (t & 1) << 6;
+    if (r < 8) bf[buf][r] = *(const bf16x8*)(st + (b_lane ^ x) + r * 2048);
+    else af[buf][r - 8] = *(const bf16x8*)(st + (a_lane ^ x) + (r - 8) * 2048);
   };
 
-  // ---- prologue: K-tile 0 and pieces 0-7 of K-tile 1 written and published; pieces 8-15 of tile 1 and 0-7 of tile 2
-  // in flight (issued in the steady-state order); fragments of sub-step 0 in registers
-  {
-    u32x4 tmp[8];
+  // ---- prologue: K-tiles 0 and 1 in their stages; fragments of sub-step 0 in registers
 #pragma unroll
-    for (int c = 0; c < 16; ++c) stg[c] = gload(c, 0);
+  for (int c = 0; c < 16; ++c) dma(c, 0);
 #pragma unroll
-    for (int c = 0; c < 8; ++c) tmp[c] = gload(c, 1);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-    for (int c = 0; c < 16; ++c) lwrite(c, 0, stg[c]);
-#pragma unroll
-    for (int c = 0; c < 8; ++c) lwrite(c, 1, tmp[c]);
-  }
-#pragma unroll
-  for (int c = 8; c < 16; ++c) stg[c] = gload(c, 1);
-#pragma unroll
-  for (int c = 0; c < 8; ++c) stg[c] = gload(c, 2);
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  for (int c = 0; c < 16; ++c) dma(c, 1);
+  asm volatile("s_waitcnt vmcnt(16)" ::: "memory");  // tile 0 landed (tile 1 may fly: waited for at the end of sub-step 0)
   __builtin_amdgcn_s_barrier();
 #pragma unroll
-  for (int idx = 0; idx < 4; ++idx)
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk) { read_frag(0, 0, 0, idx, kk); read_frag(0, 0, 1, idx, kk); }
-
+  for (int r = 0; r < 16; ++r) read_frag(0, 0, r);
   // hipcc's waitcnt pass understands this builtin (not an asm string): with the prologue's reads retired here, the wait it
-  // puts at the loop top is the one the back edge needs, not lgkmcnt(0)
+  // puts at the loop top is the one the back edge needs
   __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0)
 
-  // One sub-step = 32 k-values = 32 MFMAs in 8 chunks of 4; chunk c computes acc[c&3][0..3] from k-slice c>>2.  Every
-  // non-MFMA instruction sits directly behind an MFMA issue (pinned with sched_barriers).  RD(r), r = 0..15: the
-  // fragment reads of the next sub-step in the order it needs them (per slice: W 0-3, then A 0-3).
-  // EVEN sub-step (ends with the block barrier): all its LDS traffic sits in chunks 0-5, so the lgkmcnt(0) before the
-  // barrier finds nothing in flight -- with reads issued up to the last chunk that drain cost more than anything else
-  // in the loop (ablation: 1.25 PF with the reads, 1.58 PF without).  Pieces 8-15: written in chunks 0-1, refilled in 2-3.
-  // ODD sub-step: piece c written and refilled in chunk c.  Either way a piece has >= 14 chunks of flight and exactly 15
-  // younger loads behind it when an odd sub-step writes it, 15-k when the even one writes its k-th.
+  // One sub-step = 64 MFMAs; MFMA g (0..63) computes acc[g>>3][g&7].  Every other instruction sits directly behind an MFMA
+  // issue, never two in one gap (pinned with sched_barriers).
 #define SB __builtin_amdgcn_sched_barrier(0);
-#define MF(MI, NJ, KK) acc[MI][NJ] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[CUR_][NJ][KK], af[CUR_][MI][KK], acc[MI][NJ], 0, 0, 0);
-#define RD(R) W128_R(read_frag(1 - CUR_, t + 1, ((R) >> 2) & 1, (((R) >> 1) & 1) * 2 + ((R) & 1), (R) >> 3);)
-#define VMWAIT(N) W128_G(W128_WAIT(asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory");))
-#define WR(PC) W128_W(lwrite(PC, wt, stg[PC]);)
-#define GL(PC) W128_G(stg[PC] = gload(PC, wt + 1);)
-#define CHUNK(C, F0, F1, F2, F3)                                                                             \
-  MF((C) & 3, 0, (C) >> 2) SB F0 SB MF((C) & 3, 1, (C) >> 2) SB F1 SB MF((C) & 3, 2, (C) >> 2) SB F2 SB      \
-  MF((C) & 3, 3, (C) >> 2) SB F3 SB
+#define MF(G) acc[(G) >> 3][(G) & 7] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[CUR_][(G) & 7], af[CUR_][(G) >> 3], acc[(G) >> 3][(G) & 7], 0, 0, 0);
+  // EVEN: the 16 fragment reads of the odd sub-step in every 3rd gap (all issued by gap 45, so the drain before the
+  // barrier finds them done)
 #define W128_EVEN(T)                                                                                         \
   {                                                                                                         \
     constexpr int CUR_ = 0;                                                                                 \
     const int t = (T);                                                                                      \
-    const int wt = t / 2 + 1;                               /* K-tile whose pieces 8-15 are written here */   \
-    CHUNK(0, VMWAIT(15) WR(8), VMWAIT(14) WR(9), VMWAIT(13) WR(10), VMWAIT(12) WR(11))                      \
-    CHUNK(1, VMWAIT(11) WR(12), VMWAIT(10) WR(13), VMWAIT(9) WR(14), VMWAIT(8) WR(15))                      \
-    CHUNK(2, RD(0) GL(8), RD(1) GL(9), RD(2) GL(10), RD(3) GL(11))                                          \
-    CHUNK(3, RD(4) GL(12), RD(5) GL(13), RD(6) GL(14), RD(7) GL(15))                                        \
-    CHUNK(4, RD(8), RD(9), RD(10), RD(11))                                                                  \
-    CHUNK(5, RD(12), RD(13), RD(14), RD(15))                                                                \
-    CHUNK(6, , , , )                                                                                        \
-    CHUNK(7, , , , )                                                                                        \
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); /* this wave's reads of stage S and writes of S+1 are done */ \
+    _Pragma("unroll") for (int g = 0; g < 64; ++g) {                                                        \
+      MF(g) SB                                                                                              \
+      if (g % 3 == 0 && g / 3 < 16) { W128_R(read_frag(1, t + 1, g / 3);) }                                 \
+      SB                                                                                                    \
+    }                                                                                                       \
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); /* next K-tile landed; this wave's reads of the stage done */ \
     W128_BAR(__builtin_amdgcn_s_barrier();)                                                                 \
   }
+  // ODD: fragment read r in gap 4r, DMA piece d in gap 4d+2 (-DW128_PTR_EARLY: its 64-bit source address in gap 4d+1)
+#ifdef W128_PTR_EARLY
+#define W128_DMA_AT(G, TILE)                                                                                 \
+  if (((G) & 3) == 1) { dsrc = dma_src((G) >> 2, TILE); asm volatile("" : "+v"(dsrc)); }                    \
+  if (((G) & 3) == 2) dma_issue(dsrc, (G) >> 2, TILE);
+#else
+#define W128_DMA_AT(G, TILE) if (((G) & 3) == 2) dma((G) >> 2, TILE);
+#endif
 #define W128_ODD(T)                                                                                          \
   {                                                                                                         \
     constexpr int CUR_ = 1;                                                                                 \
     const int t = (T);                                                                                      \
-    const int wt = (t + 3) / 2;                             /* K-tile whose pieces 0-7 are written here */    \
-    CHUNK(0, RD(0), RD(1), VMWAIT(15) WR(0), GL(0))                                                         \
-    CHUNK(1, RD(2), RD(3), VMWAIT(15) WR(1), GL(1))                                                         \
-    CHUNK(2, RD(4), RD(5), VMWAIT(15) WR(2), GL(2))                                                         \
-    CHUNK(3, RD(6), RD(7), VMWAIT(15) WR(3), GL(3))                                                         \
-    CHUNK(4, RD(8), RD(9), VMWAIT(15) WR(4), GL(4))                                                         \
-    CHUNK(5, RD(10), RD(11), VMWAIT(15) WR(5), GL(5))                                                       \
-    CHUNK(6, RD(12), RD(13), VMWAIT(15) WR(6), GL(6))                                                       \
-    CHUNK(7, RD(14), RD(15), VMWAIT(15) WR(7), GL(7))                                                       \
+    const char* dsrc = nullptr;                                                                             \
+    (void)dsrc;                                                                                             \
+    _Pragma("unroll") for (int g = 0; g < 64; ++g) {                                                        \
+      MF(g) SB                                                                                              \
+      if ((g & 3) == 0) { W128_R(read_frag(0, t + 1, g >> 2);) }                                            \
+      W128_G(W128_DMA_AT(g, (t + 3) / 2))                                                                   \
+      SB                                                                                                    \
+    }                                                                                                       \
   }
 
   for (int S = 0; S < nt; ++S) {
     W128_EVEN(2 * S)
     W128_ODD(2 * S + 1)
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the tail's re-fetches still target the staging registers
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the tail's re-fetches still target the stage buffers
 
-  // ---- epilogue through LDS in 4 passes of 64 rows: pass q stages the 32-row tile mi = q of every wave
+  // ---- epilogue through LDS in 4 passes of 64 rows: pass q stages m-tiles 2q, 2q+1 of every wave
   __syncthreads();
   EpiCols<4> ec4;
   EpiCols<2> ec2;
@@ -240,13 +191,10 @@ __global__ __launch_bounds__(WNT, 1) void gemm_bf16_w128_kernel(GemmArgs p) {
   else ec1.load(p, n0 + (tid & 63) * 4);
   // The pass loop stays rolled (one copy of the epilogue code); only the 16 accumulator -> LDS writes are written out
   // per pass, so acc[] is never indexed dynamically (that would push all 256 accumulators through scratch).
-  // 32x32 accumulator layout: register 4g+e of lane (fr, hi) = row fr, column g*8 + hi*4 + e of the tile.
-#define W128_STAGE(Q)                                                                                      \
-  _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                             \
-    _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                                         \
-      f32x4 v = {acc[Q][j][4 * g], acc[Q][j][4 * g + 1], acc[Q][j][4 * g + 2], acc[Q][j][4 * g + 3]};      \
-      stage_write4<WT>(buf, wm * 32 + fr, wn * 32 + j * 8 + g * 2 + hi, v);                                 \
-    }
+#define W128_STAGE(Q)                                                                                  \
+  _Pragma("unroll") for (int e = 0; e < 2; ++e)                                                         \
+    _Pragma("unroll") for (int j = 0; j < 8; ++j)                                                       \
+      stage_write4<WT>(buf, wm * 32 + e * 16 + fr, wn * 32 + j * 4 + fg, acc[2 * (Q) + e][j]);
 #pragma nounroll
   for (int q = 0; q < 4; ++q) {
     char* buf = smem + (q & 1) * 65536;
@@ -263,7 +211,7 @@ __global__ __launch_bounds__(WNT, 1) void gemm_bf16_w128_kernel(GemmArgs p) {
 
 bool gr_w128_eligible(const GemmArgs& p) {
   return p.conv_C == 0 && (long)p.M * p.lda * 2 < (1L << 32) && (long)p.N * p.ldw * 2 < (1L << 32) && p.K % WKT == 0 &&
-         (p.K / WKT) % p.splits == 0 && p.K / WKT / p.splits >= 3;
+         (p.K / WKT) % p.splits == 0 && p.K / WKT / p.splits >= 2;
 }
 
 int gr_launch_gemm_w128(const GemmArgs& p, hipStream_t stream) {
