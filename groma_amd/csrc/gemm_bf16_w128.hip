@@ -12,7 +12,20 @@
 // four SIMDs running the same stream) says about them: a ds_read_b128 per 16-clk gap is free (+0.5 clk) but two in one
 // gap cost +15; a ds_write_b128 costs ~15 clk wherever it sits (13 clk of store path per instruction, CU-wide); an LDS-DMA
 // costs ~8 clk when there is one in every fourth gap -- and four times that when it shares its neighbourhood with LDS
-// reads and writes.  Hence this version: no ds_write in the loop at all, and the DMA issues spread out.
+// reads and writes.  Hence this version (v4): no ds_write in the loop at all, and the DMA issues spread out.
+//   * v5 (tried after this one, not kept): the same with a ring of four 32-deep slots (64-B LDS rows) to give a DMA piece
+//     two to three sub-steps of flight instead of one to two: 1.17 PF against v4's 1.36 PF.  A DMA instruction that covers
+//     16 rows x 64 B touches sixteen 128-B lines instead of eight, and the texture-address path prices a wave-instruction
+//     by the LINES it touches (~2 clk each): the refill of one K-tile then keeps it busy for as long as the MFMAs take.
+//     That is also what capped round 1's kernel and git 5e7914d.  Fetch whole lines.
+//   * v4b (not kept): landing wait split in two (W pieces first, `vmcnt(8)` + barrier at the end of the even sub-step;
+//     A pieces behind a second `vmcnt(8)` + barrier in the middle of the odd one) so that every piece has >= 1.5 sub-steps
+//     of flight: K = 11008 0.91 -> 0.93x, the ViT shapes 0.97 -> 1.00x, the big K = 4096 shapes 0.97 -> 0.95x.
+// Where v4 stands: 0.97-0.98x of the ping-pong kernel on the K <= 4096 shapes, 0.91x at K = 11008.  With two 64 KB stages
+// a piece cannot have more than one to two sub-steps (1100-2200 clk) of flight -- the stage is free for two sub-steps and
+// issuing its 16 pieces takes one -- and operands that come from HBM need more; the ping-pong kernel frees its stage in
+// four parts and gives every piece a whole K-tile.  Ablations of v4: without the DMA 1.60 PF, without the reads 1.51 PF.
+// NOT the default: gr_gemm_bf16 uses it for tile = 257 or GROMA_W128=1 only.
 //
 // Pipeline.  K-tile S (64 k-values) lives in LDS stage S&1 (A 256 x 128 B, then W 256 x 128 B = 64 KB) and is computed in
 // two sub-steps of 64 MFMAs (k-halves h = 0, 1), each from one of two fragment register sets:
@@ -153,14 +166,11 @@ __global__ __launch_bounds__(WNT, 1) void gemm_bf16_w128_kernel(GemmArgs p) {
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); /* next K-tile landed; this wave's reads of the stage done */ \
     W128_BAR(__builtin_amdgcn_s_barrier();)                                                                 \
   }
-  // ODD: fragment read r in gap 4r, DMA piece d in gap 4d+2 (-DW128_PTR_EARLY: its 64-bit source address in gap 4d+1)
-#ifdef W128_PTR_EARLY
+  // ODD: fragment read r in gap 4r, DMA piece d in gap 4d+2 with its 64-bit source address computed in gap 4d+1 (+1 % over
+  // having both in one gap)
 #define W128_DMA_AT(G, TILE)                                                                                 \
   if (((G) & 3) == 1) { dsrc = dma_src((G) >> 2, TILE); asm volatile("" : "+v"(dsrc)); }                    \
   if (((G) & 3) == 2) dma_issue(dsrc, (G) >> 2, TILE);
-#else
-#define W128_DMA_AT(G, TILE) if (((G) & 3) == 2) dma((G) >> 2, TILE);
-#endif
 #define W128_ODD(T)                                                                                          \
   {                                                                                                         \
     constexpr int CUR_ = 1;                                                                                 \
