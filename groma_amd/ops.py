@@ -4,6 +4,7 @@ torch is used for device memory and the current stream only; every computation b
 in groma_amd/csrc.  All wrappers raise (TypeError / RuntimeError) on bad inputs -- there is no eager path.
 """
 import ctypes
+import os
 
 import torch
 
@@ -44,6 +45,24 @@ def _gemv_ws(splits, M, N, device):
     return t
 
 
+# Split-K for under-filled launches (see _auto_splits).  It is the ONE place where the arithmetic of an image depends on its
+# batch mates: which GEMMs are split depends on M.  With it off, results are bitwise independent of the batch
+# (tests/test_fullsize_properties_gpu.py checks both settings).  GROMA_NO_AUTOSPLIT=1 turns it off for a process.
+AUTO_SPLIT_K = not bool(os.environ.get("GROMA_NO_AUTOSPLIT"))
+
+
+def _auto_splits(M, N, K):
+    """Split-K factor for an UNDER-FILLED launch (latency configurations: the 582-row LLaMA prefill or the 1025-row ViT of one
+    image leave most of the 256 CUs without a tile in the o-proj / down-proj / fc2 GEMMs).  The 128x128 kernel has 512 tile
+    slots; when the plain launch fills at most half of them and K is deep enough to pay for the extra pass, K is cut so that
+    they are filled, and the partials go through the deterministic reduce + epilogue kernel (same epilogue semantics).  At
+    the benchmark's 14 images per GPU every GEMM has far more than 256 tiles and this returns 1."""
+    t128 = -(-M // 128) * -(-N // 128)
+    if 2 * t128 > 512 or K < 2048 or not AUTO_SPLIT_K:
+        return 1
+    return max(1, min(512 // t128, K // 1024, 8))  # at least 16 K-steps of 64 per split
+
+
 def gemm(a, w, *, out=None, bias=None, scale=None, resid=None, act=0, out_f32=False, splits=1, ws=None,
          M=None, lda=None, conv=None, resid_mod=0, row_map=None, ldc=None, ldr=None, tile=0,
          a_scale=None, w_scale=None):
@@ -76,6 +95,8 @@ def gemm(a, w, *, out=None, bias=None, scale=None, resid=None, act=0, out_f32=Fa
     if tile == 0 and conv is None and not fp8 and M <= 8 and splits == 1 and N * K >= (1 << 20):
         tile, splits = 1, (K + 511) // 512  # decode step: weight-streaming kernel + deterministic split-K reduce
         ws = _gemv_ws(splits, M, N, a.device)
+    elif tile == 0 and conv is None and not fp8 and splits == 1 and ws is None and M > 8:
+        splits = _auto_splits(M, N, K)
     n_out = N // 2 if act == 3 else N
     if out is None:
         out = torch.empty((M, n_out), dtype=F32 if out_f32 else BF16, device=a.device)

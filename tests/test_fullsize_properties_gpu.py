@@ -1,8 +1,10 @@
 """BASELINE.json full-size configuration (Groma-7B dims, random-init bf16) checked through size-independent properties
 -- the fp32 CPU oracle cannot run a 7B model in test time, so at full size we assert what must hold for ANY weights:
   P1 determinism              same inputs + same host RNG seed -> bit-identical logits, boxes, ids
-  P2 batch independence       an image's results do not depend on its batch mates (every kernel reduces over K in a
-                              fixed order per output element, so this holds BITWISE, across the 128/256 GEMM kernels)
+  P2 batch independence       an image's results do not depend on its batch mates: every kernel reduces over K in a fixed
+                              order per output element, so under ONE GEMM plan this holds BITWISE, across the 128/256 GEMM
+                              kernels (ops.AUTO_SPLIT_K off); the default plan splits K for under-filled single-image
+                              launches, and then it holds to bf16 noise
   P3 KV-cache consistency     logits of position L-1 from a full prefill == prefill of L-1 tokens + 1 decode step
                               (same weights, different kernels/shapes: bf16 tolerance)
   P4 contract at full size    N=100 regions/image at box_score_thres=0, L=582, logits [bs,582,32114], finite,
@@ -47,8 +49,7 @@ def test_contract_and_determinism(big):
     assert all(torch.equal(x, y) for x, y in zip(o2.hidden_states[1]["pred_boxes"], boxes1))
 
 
-def test_batch_independence_bitwise(big):
-    m, images, ids = big
+def _batch_vs_single(m, images, ids, check):
     # the host RNG draws one randperm(100) per image in batch order: replay the same permutations per image
     torch.manual_seed(5)
     perms = [torch.randperm(100) for _ in range(3)]
@@ -62,7 +63,55 @@ def test_batch_independence_bitwise(big):
         out = m.forward(input_ids=ids[i:i + 1].clone(), images=images[i:i + 1], return_dict=True)
         assert torch.equal(m._last_aux["nms_keep"][0], keep_all[i])
         assert torch.equal(m._last_aux["sel_idx"][0], keep_all[i][perms[i]])
-        assert torch.equal(out.logits[0], la[i]), f"image {i}: logits depend on batch mates"
+        check(i, out.logits[0], la[i])
+
+
+def test_batch_independence_bitwise(big, monkeypatch):
+    """With one GEMM plan for every batch size (ops.AUTO_SPLIT_K off) an image's logits do not depend on its batch mates --
+    bit for bit, through all 24 + 6 + 32 layers."""
+    from groma_amd import ops
+    monkeypatch.setattr(ops, "AUTO_SPLIT_K", False)
+    m, images, ids = big
+
+    def check(i, single, batched):
+        assert torch.equal(single, batched), f"image {i}: logits depend on batch mates"
+    _batch_vs_single(m, images, ids, check)
+
+
+def test_batch_independence_default_plan(big):
+    """Default plan: a single image's o-proj / down-proj / fc2 GEMMs are split along K to fill the chip (ops._auto_splits), a
+    batch of three is not -- fp32 sums in another order, so the bf16 roundings behind them differ at noise level.  Checked
+    stage by stage on identical stage inputs: the ViT states agree to bf16 noise; the LLaMA stage, fed the batch run's own
+    input embeddings, gives logits that agree to bf16 noise and pick the same token wherever the margin is clear of it.
+    (The region selection in between is discrete; with random-init weights the proposal scores are near-tied, so which
+    boxes survive is decided by that noise -- measured 73 of 100 in common.  Selection exactness is what the a7 tests pin,
+    on inputs whose score gaps are clear: tests/test_fullwidth_parity_gpu.py.)"""
+    m, images, ids = big
+    m.capture_embeds = True
+    try:
+        o_all, a_all = _fwd(m, images, ids, seed=5)
+    finally:
+        m.capture_embeds = False
+    la = o_all.logits.float().clone()
+    emb_all = a_all["inputs_embeds"].clone()
+    h4_all = [h.float().clone() for h in a_all["hidden4"]]
+    L = emb_all.shape[1]
+    for i in (0, 2):
+        torch.manual_seed(5)
+        m.forward(input_ids=ids[i:i + 1].clone(), images=images[i:i + 1], return_dict=True)
+        for hs, hb in zip(m._last_aux["hidden4"], h4_all):
+            hs, hb = hs.float().reshape(-1), hb.reshape(3, -1)[i]
+            assert ((hs - hb).norm() / hb.norm()).item() < 1e-2
+        cache = m.llm.new_cache(1, L, images.device)
+        logits, _ = m.llm.forward(emb_all[i].reshape(L, -1).clone(), 1, L, cache, kv_len=None, all_logits=True)
+        s, b = logits.float().reshape(L, -1), la[i]
+        rel = ((s - b).norm() / b.norm()).item()
+        assert rel < 2e-2, (i, rel)
+        err = (s - b).abs().amax(-1)
+        top2 = b.topk(2, dim=-1).values
+        clear = (top2[:, 0] - top2[:, 1]) > 4 * err
+        assert torch.equal(s.argmax(-1)[clear], b.argmax(-1)[clear])
+        assert clear.float().mean().item() > 0.3
 
 
 def test_kv_cache_step_matches_prefill(big):
