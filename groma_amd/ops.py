@@ -95,6 +95,9 @@ def gemm(a, w, *, out=None, bias=None, scale=None, resid=None, act=0, out_f32=Fa
     if tile == 0 and conv is None and not fp8 and M <= 8 and splits == 1 and N * K >= (1 << 20):
         tile, splits = 1, (K + 511) // 512  # decode step: weight-streaming kernel + deterministic split-K reduce
         ws = _gemv_ws(splits, M, N, a.device)
+    # (not for the implicit-conv GEMMs: their K = 9*C passes the depth test already in the small test configuration, where
+    # the serving tests assert that a row's tokens are bit-independent of who shares its admission batch; measured gain at
+    # one image per GPU was within box-to-box spread)
     elif tile == 0 and conv is None and not fp8 and splits == 1 and ws is None and M > 8:
         splits = _auto_splits(M, N, K)
     n_out = N // 2 if act == 3 else N

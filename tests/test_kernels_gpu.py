@@ -149,6 +149,9 @@ def test_gemm_conv3x3(dev, imgs, H, C, Cout, segs, tile):
     wk = torch.cat([w.permute(0, 2, 3, 1).reshape(Cout, 9 * C) for w in ws], dim=1).contiguous()
     out = ops.gemm(pad, wk, conv=(imgs, H, H, C, imgs * (H + 2) * (H + 2) * C), out_f32=True, tile=tile)
     assert relerr(out, ref) < 1e-5
+    # split-K over the gathered K (what ops._auto_splits asks for when a single image leaves the chip under-filled)
+    out = ops.gemm(pad, wk, conv=(imgs, H, H, C, imgs * (H + 2) * (H + 2) * C), out_f32=True, tile=tile, splits=3)
+    assert relerr(out, ref) < 1e-5
 
 
 @pytest.mark.parametrize("M,N,K", [(1024, 256, 1024), (300, 96, 256), (100, 256, 16), (77, 4, 256)])
