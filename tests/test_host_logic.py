@@ -195,3 +195,28 @@ def test_rec_meter_matches_reference_loop():
     assert abs(s["m_iou"] - miou / bs) < 1e-6 and invalid > 0 and hits > 0
     res = evalkit.lvis_results(seqs[:2], P, boxes[:2], [7, 8], [1, 2], [(480, 640), (100, 200)], tok_ids)
     assert all(set(r) == {"image_id", "category_id", "bbox", "score"} for r in res)
+
+
+def test_auto_split_k_plan():
+    """ops._auto_splits: the GEMM plan of the benchmark configuration (14 images per GPU: LLaMA M = 8148, ViT M = 14350) is
+    never split; the single-image prefill (M = 582) and ViT (M = 1025) split exactly the launches that leave the chip
+    under-filled; the switch turns it off."""
+    from groma_amd import ops
+    llama = [(12288, 4096), (4096, 4096), (22016, 4096), (4096, 11008), (32128, 4096)]  # (N, K): qkv, o, gate-up, down, head
+    vit = [(3072, 1024), (1024, 1024), (4096, 1024), (1024, 4096)]                       # qkv, proj, fc1, fc2
+    for N, K in llama:
+        assert ops._auto_splits(8148, N, K) == 1 and ops._auto_splits(4 * 582, N, K) == 1
+    for N, K in vit:
+        assert ops._auto_splits(14350, N, K) == 1
+    assert [ops._auto_splits(582, N, K) for N, K in llama] == [1, 3, 1, 3, 1]
+    assert [ops._auto_splits(1025, N, K) for N, K in vit] == [1, 1, 1, 4]
+    for M, N, K in [(582, 4096, 4096), (1025, 1024, 4096), (16, 4096, 4096)]:
+        s = ops._auto_splits(M, N, K)
+        assert 1 < s <= 8 and K // s >= 1024                                    # at least 16 K-steps of 64 per split
+        assert -(-M // 128) * -(-N // 128) * s <= 512                           # never more work items than tile slots
+    old = ops.AUTO_SPLIT_K
+    try:
+        ops.AUTO_SPLIT_K = False
+        assert ops._auto_splits(582, 4096, 11008) == 1
+    finally:
+        ops.AUTO_SPLIT_K = old
