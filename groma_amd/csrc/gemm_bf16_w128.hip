@@ -220,7 +220,8 @@ __global__ __launch_bounds__(WNT, 1) void gemm_bf16_w128_kernel(GemmArgs p) {
 }
 
 bool gr_w128_eligible(const GemmArgs& p) {
-  return p.conv_C == 0 && (long)p.M * p.lda * 2 < (1L << 32) && (long)p.N * p.ldw * 2 < (1L << 32) && p.K % WKT == 0 &&
+  // (per-lane byte offsets are 32-bit: the last row's last chunk must still fit)
+  return p.conv_C == 0 && (long)p.M * p.lda * 2 <= (1L << 32) - 256 && (long)p.N * p.ldw * 2 <= (1L << 32) - 256 && p.K % WKT == 0 &&
          (p.K / WKT) % p.splits == 0 && p.K / WKT / p.splits >= 2;
 }
 
