@@ -7,7 +7,9 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("GROMA_HIP_LIB") or os.path.join(_HERE, "csrc", "libgroma_hip.so")  # override: A/B builds
+# The one library the product loads.  (Measurement scripts under tests/diag that A/B another build assign
+# `groma_amd._lib.LIB_PATH = ...` before the first load -- tests/diag/_variant.py; the product reads no environment switch.)
+LIB_PATH = os.path.join(_HERE, "csrc", "libgroma_hip.so")
 
 c_void_p = ctypes.c_void_p
 c_int = ctypes.c_int

@@ -9,7 +9,6 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 SOURCES = {
     "gemm_bf16.hip": [],
     "gemm_bf16_256.hip": [],
-    "gemm_bf16_w128.hip": [],
     "gemv_bf16.hip": [],
     "gemm_fp8_256.hip": [],
     "fp8.hip": [],

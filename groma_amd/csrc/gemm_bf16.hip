@@ -14,7 +14,6 @@
 // The MFMA is issued "swapped" (W as the A operand) so each lane ends up with 4
 // consecutive output columns of one row -> vector epilogue loads/stores.
 #include "gemm_common.h"
-#include <cstdlib>
 
 #define BM 128
 #define BN 128
@@ -23,7 +22,6 @@
 // time of one 256^2 K-step on a CU relative to one 128^2 K-step of two co-resident blocks (4x the MACs of one
 // block = 2x the work per CU-interval, executed ~1.45x faster per flop)
 #define G256_COST 1.41
-#include <stdlib.h>
 
 __global__ __launch_bounds__(NTHREADS) void gemm_bf16_kernel(GemmArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -250,7 +248,8 @@ extern "C" int gr_gemm_bf16(const gr_gemm_desc* d, hipStream_t stream) {
   const bool gemv = d->tile == 1 || d->tile == 2;  // decode-step shape: weights streamed once, no MFMA (gemv_bf16.hip)
   const bool partials_only = d->tile == 2;         // the caller's next kernel consumes ws[splits, M, N] (decode.hip)
   if (gemv && (p.M > 8 || p.conv_C > 0 || splits != gr_cdiv(p.K, 512) || !p.ws)) return GR_EINVAL;
-  if (d->tile == 256 || d->tile == 257 || d->fp8) use256 = true;  // fp8 exists for the 256x256 kernel only
+  if (d->tile != 0 && d->tile != 1 && d->tile != 2 && d->tile != 128 && d->tile != 256) return GR_EINVAL;
+  if (d->tile == 256 || d->fp8) use256 = true;  // fp8 exists for the 256x256 kernel only
   else if (d->tile == 0) {
     const long t128 = (long)gr_cdiv(p.M, 128) * gr_cdiv(p.N, 128), t256 = (long)gr_cdiv(p.M, 256) * gr_cdiv(p.N, 256);
     const double ksteps = (double)(p.K / 64) / splits;
@@ -281,10 +280,7 @@ extern "C" int gr_gemm_bf16(const gr_gemm_desc* d, hipStream_t stream) {
     const int rc = gr_launch_gemv(p, stream);
     if (rc != GR_OK) return rc;
   } else if (use256) {
-    static const int w128_env = getenv("GROMA_W128") ? atoi(getenv("GROMA_W128")) : -1;  // A/B switch (tests/diag)
-    const bool w128 = !d->fp8 && (d->tile == 257 || (d->tile != 256 && w128_env == 1)) && gr_w128_eligible(p);
-    if (d->tile == 257 && !w128) return GR_EINVAL;
-    const int rc = d->fp8 ? gr_launch_gemm256_fp8(p, stream) : w128 ? gr_launch_gemm_w128(p, stream) : gr_launch_gemm256(p, stream);
+    const int rc = d->fp8 ? gr_launch_gemm256_fp8(p, stream) : gr_launch_gemm256(p, stream);
     if (rc != GR_OK) return rc;
   } else {
     hipLaunchKernelGGL(gemm_bf16_kernel, grid, dim3(NTHREADS), 65536, stream, p);

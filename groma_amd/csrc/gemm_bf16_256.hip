@@ -22,7 +22,6 @@
 //  * LDS image: 128-B rows, 16-B chunk position = k-chunk ^ (row & 7): written lane-linearly by the DMA with the
 //    XOR applied to the per-lane SOURCE address, mirrored on the ds_read_b128 side (conflict-free).
 #include "gemm_common.h"
-#include <cstdlib>
 
 #define T256 256
 #define NT 512
@@ -319,7 +318,11 @@ int G256_LAUNCH(const GemmArgs& p, hipStream_t stream) {
     if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return GR_EINVAL;
     n_cu = prop.multiProcessorCount > 8 ? (prop.multiProcessorCount & ~7) : 8;
   }
-  static const bool persist_off = G256_FP8 || getenv("GROMA_G256_NO_PERSIST") != nullptr;  // env: A/B switch for measurements
+#ifdef G256_NO_PERSIST  // diagnostic build (tests/diag/build_variant.py name -DG256_NO_PERSIST): one tile per workgroup
+  const bool persist_off = true;
+#else
+  const bool persist_off = G256_FP8 != 0;
+#endif
   const int tiles = p.tiles_m * p.tiles_n;
   dim3 grid(persist_off ? tiles : (tiles < n_cu ? tiles : n_cu), p.splits);
   hipLaunchKernelGGL(G256_KERNEL, grid, dim3(NT), 2 * STAGE_BYTES, stream, p);

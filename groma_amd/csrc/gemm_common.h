@@ -383,8 +383,5 @@ __device__ __forceinline__ void epi_dispatch(const GemmArgs& p, const char* base
 int gr_launch_gemv(const GemmArgs& p, hipStream_t stream);
 // 256x256x64 ping-pong kernel (gemm_bf16_256.hip)
 int gr_launch_gemm256(const GemmArgs& p, hipStream_t stream);
-// one-wave-per-SIMD 256x256 kernel (gemm_bf16_w128.hip): plain bf16 GEMMs that pass gr_w128_eligible
-bool gr_w128_eligible(const GemmArgs& p);
-int gr_launch_gemm_w128(const GemmArgs& p, hipStream_t stream);
 // OCP-fp8 build of the same kernel (gemm_fp8_256.hip); A/W are e4m3 bytes, K % 128 == 0
 int gr_launch_gemm256_fp8(const GemmArgs& p, hipStream_t stream);

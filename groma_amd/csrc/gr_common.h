@@ -77,6 +77,12 @@ __device__ __forceinline__ float rows_sum(float x) {
 // Wave-wide all-reduce: inside a 16-lane row by DPP rotations (row_ror 8, 4, 2, 1: VALU data path), across the four rows by the
 // permlane swaps above.  (__shfl_xor compiles to ds_bpermute_b32 for every distance on this compiler -- six dependent LDS-crossbar
 // round trips per reduction, which is most of the latency of the small decode / DDETR kernels.)
+// PRECONDITION of wave_sum / wave_max / rows_sum / rows_max: ALL 64 lanes of the wave are active at the call (no divergent
+// early exit, no partial tail wave).  bound_ctrl makes an inactive source lane read as 0 -- not the neutral element of max --
+// and the permlane swaps do not exchange with inactive lanes.  Every caller in csrc/ satisfies it by construction: one wave
+// per row with a wave-uniform `if (row >= rows) return;` (norm.hip, fp8.hip), full 1024-thread blocks (decode.hip), full
+// waves per weight-row group (gemv_bf16.hip), whole-wave query tiles (attention.hip, ddetr.hip).  Lanes without data must
+// contribute the neutral element themselves (0 for sums, -inf / -1e30 for maxima) instead of skipping the call.
 template <int N>
 __device__ __forceinline__ float dpp_ror(float v) {
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x120 + N, 0xf, 0xf, true));

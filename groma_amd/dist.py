@@ -16,14 +16,23 @@ def shard_range(global_batch, world, rank):
     return lo, lo + q + (1 if rank < r else 0)
 
 
-def init(backend=None, device=None):
+def init(backend=None, device=None, single_process=False):
+    """Join the process group the launcher described (RANK / WORLD_SIZE / MASTER_* in the environment, as torchrun and
+    bench.py's own launcher export them).  A missing RANK or WORLD_SIZE raises: N processes that each silently became
+    "rank 0 of 1" would report single-GPU numbers as if scaling had worked.  single_process=True is the explicit request for a
+    one-rank group (smoke test of the collective path on one GPU)."""
     import torch.distributed as dist
     if dist.is_initialized():
         return dist
+    if single_process:
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+    missing = [k for k in ("RANK", "WORLD_SIZE") if k not in os.environ]
+    if missing:
+        raise RuntimeError(f"groma_amd.dist.init: {', '.join(missing)} not set -- launch one process per GPU with "
+                           f"torch.distributed.run (or `python bench.py --gpus N`, which does), or pass single_process=True")
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29511")
-    os.environ.setdefault("RANK", "0")
-    os.environ.setdefault("WORLD_SIZE", "1")
     backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")
     kw = {"device_id": device} if (backend == "nccl" and device is not None) else {}
     dist.init_process_group(backend, **kw)

@@ -374,7 +374,16 @@ class LlamaEngine:
             cache.grow(_ru(past + L + 64, 64))
         if L == 1 and M <= 8 and not w["fp8"] and T <= 8192 and cache.smax <= 8192:
             return self._decode_forward(h, bs, cache, kv_len, pos_dev, pos_stride, past)
-        q = ws.get("llm_q", (bs, H, L, hd), BF16)
+        # A decode step that does not fit the weight-streaming path (more than 8 rows, e4m3 operands, > 8192 keys) runs the
+        # general kernels below.  Its scratch may be baked into GreedyDecoder's captured hipGraph, so -- like _decode_forward --
+        # it uses dedicated never-moved tensors (a later, larger prefill regrows the shared arenas and would free memory the
+        # graph still addresses) and leaves its logits in the same `dec_logits` buffer the sampler reads.
+        dec = dyn or L == 1
+
+        def buf(name, shape, dtype):
+            return ws.get(name + "_dec", shape, dtype, exact=True) if dec else ws.get(name, shape, dtype)
+
+        q = None if Q_IN_PLACE else buf("llm_q", (bs, H, L, hd), BF16)
         fp8 = w["fp8"]
 
         def lin(x_f32, gain, wt, tag=None, **kw):
@@ -382,7 +391,7 @@ class LlamaEngine:
             if fp8:
                 x8, sx = ops.norm_fp8(x_f32, gain, None, self.eps, True)
                 return ops.gemm(x8, wt[0], a_scale=sx, w_scale=wt[1], **kw)
-            x = ops.rmsnorm(x_f32, gain, self.eps, out=ws.get("llm_x", (M, T), BF16))
+            x = ops.rmsnorm(x_f32, gain, self.eps, out=buf("llm_x", (M, T), BF16))
             if tag:
                 _trace(tag, x)
             return ops.gemm(x, wt[0], **kw)
@@ -397,11 +406,11 @@ class LlamaEngine:
             t0 = TRACE is not None and i == 0
             if t0:
                 _trace("llm0.h_in", h)
-            qkv = lin(h, Lw["n1"], Lw["wqkv"], tag="llm0.n1" if t0 else None, out=ws.get("llm_qkv", (M, 3 * T), BF16))
+            qkv = lin(h, Lw["n1"], Lw["wqkv"], tag="llm0.n1" if t0 else None, out=buf("llm_qkv", (M, 3 * T), BF16))
             ops.qkv_split(qkv, None if Q_IN_PLACE else q, cache.k[i], cache.vt[i], B=bs, H=H, L=L, hd=hd, pos0=past,
                           cos=w["cos"], sin=w["sin"], pos_dev=pos_dev, pos_stride=pos_stride)
             att_kw = dict(Skv=cache.smax if dyn else past + L, causal=True, q_pos0=past, kv_len=kv_len,
-                          out=ws.get("llm_ctx", (M, T), BF16), pos_dev=pos_dev, pos_stride=pos_stride)
+                          out=buf("llm_ctx", (M, T), BF16), pos_dev=pos_dev, pos_stride=pos_stride)
             if Q_IN_PLACE:  # q is read (and rotated) in place: no packed q copy, no round trip
                 ctx = ops.attention(qkv, cache.k[i], cache.vt[i], fused=dict(B=bs, H=H, Lq=L, hd=hd, cos=w["cos"], sin=w["sin"]),
                                     **att_kw)
@@ -410,15 +419,18 @@ class LlamaEngine:
             lin_bf16(ctx, Lw["wo"], resid=h, out=h, out_f32=True)
             if t0:
                 _trace("llm0.qkv", qkv), _trace("llm0.ctx", ctx), _trace("llm0.h_attn", h)
-            y = lin(h, Lw["n2"], Lw["wgu"], tag="llm0.n2" if t0 else None, act=3, out=ws.get("llm_y", (M, self.I), BF16))
+            y = lin(h, Lw["n2"], Lw["wgu"], tag="llm0.n2" if t0 else None, act=3, out=buf("llm_y", (M, self.I), BF16))
             lin_bf16(y, Lw["wd"], resid=h, out=h, out_f32=True)
             if t0:
                 _trace("llm0.act", y), _trace("llm0.h_out", h)
         if not dyn:
             cache.seq_len = past + L
-        hn = ops.rmsnorm(h, w["norm"], self.eps, out=ws.get("llm_x", (M, T), BF16))
+        hn = ops.rmsnorm(h, w["norm"], self.eps, out=buf("llm_x", (M, T), BF16))
         if len(w["layers"]) == 1:
             _trace("llm.final_norm", hn)
+        if L == 1:  # decode step: the sampler (GreedyDecoder._step, serving) reads this buffer
+            logits = ops.gemm(hn, w["head"], out_f32=True, out=self.decode_logits(bs))
+            return logits.view(bs, 1, self.Vpad)[:, :, : self.V], hn
         if not all_logits and L > 1:
             hn = hn.view(bs, L, T)[:, -1].contiguous()
             logits = ops.gemm(hn, w["head"], out_f32=True)
@@ -427,6 +439,11 @@ class LlamaEngine:
         # recycled arena view (the caching allocator re-serves the block once the caller drops the previous result)
         logits = ops.gemm(hn, w["head"], out_f32=True)
         return logits.view(bs, L, self.Vpad)[:, :, : self.V], hn
+
+    def decode_logits(self, bs):
+        """the padded f32 [bs, Vpad] buffer every single-position step (either path) leaves its logits in: a dedicated tensor,
+        so a captured decode graph and its sampler keep addressing the same memory"""
+        return self.ws.get("dec_logits", (bs, self.Vpad), F32, exact=True)
 
     def _decode_forward(self, h, bs, cache, kv_len, pos_dev, pos_stride, past):
         """One new position per row.  Weight GEMVs leave their split-K partials for the next kernel
@@ -439,24 +456,40 @@ class LlamaEngine:
         y = ws.get("dec_y", (bs, self.I), BF16, exact=True)
         part, splits = None, 0
         for i, Lw in enumerate(w["layers"]):
+            t0 = TRACE is not None and i == 0
+            if t0:
+                _trace("dec0.h_in", h)
             ops.decode_reduce_norm(part, splits, h, Lw["n1"], x, self.eps)  # (+ previous layer's down-proj partials)
+            if t0:
+                _trace("dec0.n1", x)
             pq, sq = ops.gemv_partials(x, Lw["wqkv"][0])
             ops.decode_qkv_rope(pq, sq, q, cache.k[i], cache.vt[i], w["cos"], w["sin"], B=bs, H=H, hd=hd, pos0=past,
                                 pos_dev=pos_dev, pos_stride=pos_stride)
             att = ops.decode_attention(q, cache.k[i], cache.vt[i], ctx, Smax=cache.smax if dyn else past + 1, q_pos0=past,
                                        kv_len=kv_len, pos_dev=pos_dev, pos_stride=pos_stride)
+            if t0:
+                _trace("dec0.q", q)
+                TRACE["dec0.nsplit"] = att[1] if isinstance(att, tuple) else 1
+                if not isinstance(att, tuple):
+                    _trace("dec0.ctx", ctx)
             if isinstance(att, tuple):  # key slices on separate blocks: the o-proj merges them while loading x
                 po, so = ops.gemv_partials(None, Lw["wo"][0], a_parts=att)
             else:
                 po, so = ops.gemv_partials(ctx, Lw["wo"][0])
             ops.decode_reduce_norm(po, so, h, Lw["n2"], x, self.eps)
+            if t0:
+                _trace("dec0.h_attn", h), _trace("dec0.n2", x)
             ops.gemm(x, Lw["wgu"][0], act=3, out=y, tile=1, splits=(T + 511) // 512,
                      ws=ops._gemv_ws((T + 511) // 512, bs, 2 * self.I, h.device))
+            if t0:
+                _trace("dec0.act", y)
             part, splits = ops.gemv_partials(y, Lw["wd"][0])
         if not dyn:
             cache.seq_len = past + 1
         ops.decode_reduce_norm(part, splits, h, w["norm"], x, self.eps)
-        logits = ops.gemm(x, w["head"], out_f32=True, out=ws.get("dec_logits", (bs, self.Vpad), F32, exact=True))
+        if TRACE is not None and len(w["layers"]) == 1:
+            _trace("dec.h_out", h), _trace("dec.final_norm", x)
+        logits = ops.gemm(x, w["head"], out_f32=True, out=self.decode_logits(bs))
         return logits.view(bs, 1, self.Vpad)[:, :, : self.V], x
 
 
@@ -502,7 +535,7 @@ class GreedyDecoder:
         ops.embed_gather(self.tok, llm.w["embed"], llm.w["new_embed"], out=self.h)
         llm.forward(self.h, self.bs, 1, self.cache, pos_dev=self.pos, pos_stride=0)
         # the token sampled from the logits at position `pos` sits at pos + 1 (pos_off = 1)
-        ops.sample_rows(llm.ws.get("dec_logits", (self.bs, llm.Vpad), F32, exact=True), llm.V, self.inv_temp, self.seed,
+        ops.sample_rows(llm.decode_logits(self.bs), llm.V, self.inv_temp, self.seed,
                         pos=self.pos, pos_stride=0, pos_off=1, out=self.nxt)
         self._advance(1)
 

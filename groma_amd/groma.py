@@ -70,6 +70,10 @@ class GromaModel:
         # ~330 launches of fp32 kernels that are launch-latency-bound) captured once per batch size and replayed
         self.proposer_graph = True
         self.fp8 = bool(fp8)  # BASELINE configs[4]: OCP e4m3 operands for the DINOv2 and LLaMA GEMMs (extension)
+        # which GEMMs are split along K (ops.plan_splits): "throughput" = none (batched eval / the benchmark), "latency" = a
+        # fixed per-(N, K) factor tuned for one request per call.  Either way a function of the layer shape only, so results
+        # never depend on batch composition; the two plans differ from each other by fp32 summation order (bf16-noise level).
+        self.gemm_plan = "throughput"
         self.device = torch.device(device)
         self.training = False
         self.pad_token_id = None
@@ -217,6 +221,9 @@ class GromaModel:
         if self.proposer_graph and debug is None and max(n_extra) == 0:
             # fixed shapes, no host value in any kernel argument: replay the captured chain
             pred_boxes, scores, topk_idx, keep, n_keep = self._propose_graph(hidden4)
+            # the graph owns its output buffers and the next replay overwrites them: what leaves this call (aux, _last_aux,
+            # the selected boxes) is the caller's own copy (KB-sized)
+            pred_boxes, scores, topk_idx = pred_boxes.clone(), scores.clone(), topk_idx.clone()
             Q = pred_boxes.shape[1]
             boxes_all, scores_all = pred_boxes, scores
         else:
@@ -273,10 +280,13 @@ class GromaModel:
         pool = self.__dict__.setdefault("_pgraphs", {})
         ent = pool.get(key)
         if ent is None:
+            # the general NMS path (> 512 candidates) takes a workspace pointer: the graph gets its own, kept alive in `ent`
+            nms_ws = ops.nms_workspace(hidden4[0].shape[0], int(cfg.perceiver_cfg.ddetr_cfg.two_stage_num_proposals), self.device)
+
             def chain():
                 pred, scores, idx = self.proposer.forward(hidden4)
                 keep, n_keep = ops.nms(pred.contiguous(), scores.contiguous(), float(cfg.nms_thres), float(cfg.box_score_thres),
-                                       int(cfg.max_region_num))
+                                       int(cfg.max_region_num), workspace=nms_ws)
                 return pred, scores, idx, keep, n_keep
             chain()  # warm-up: lazy per-kernel attributes, workspaces
             torch.cuda.synchronize(self.device)  # nothing else of this forward (side stream) may overlap the capture
@@ -285,7 +295,7 @@ class GromaModel:
                 outs = chain()
             if len(pool) >= 4:
                 pool.pop(next(iter(pool)))
-            ent = pool[key] = (g, outs)
+            ent = pool[key] = (g, outs, nms_ws)
         ent[0].replay()
         return ent[1]
 
@@ -318,7 +328,7 @@ class GromaModel:
             raise NotImplementedError("output_attentions is not available from the fused attention kernel")
         dev = self.device
         vis_outputs = None
-        with torch.no_grad():
+        with torch.no_grad(), ops.gemm_plan(self.gemm_plan):
             if past_key_values is None:
                 images = images.to(device=dev, dtype=F32).contiguous()
                 hidden4 = self.vit.forward(images)
@@ -457,7 +467,7 @@ class GromaModel:
 
     # ------------------------------------------------------------------ hipGraph decode loop
     def _decoder(self, bs, smax, max_new, eos, pad):
-        key = (bs, smax, max_new, eos, pad)
+        key = (bs, smax, max_new, eos, pad, self.gemm_plan)  # the plan is baked into the captured launches
         pool = self.__dict__.setdefault("_decoders", {})
         dec = pool.get(key)
         if dec is None:
@@ -493,9 +503,13 @@ class GromaModel:
         return GenerateOutput(sequences=seqs, hidden_states=hs, past_key_values=dec.cache)
 
     # ------------------------------------------------------------------ generate (HF 4.32 greedy_search semantics)
-    def generate(self, input_ids, images=None, refer_boxes=None, ground_boxes=None, use_cache=True, do_sample=False,
-                 max_new_tokens=None, return_dict_in_generate=False, output_hidden_states=False, generation_config=None,
-                 **kw):
+    def generate(self, *a, **kw):
+        with ops.gemm_plan(self.gemm_plan):
+            return self._generate(*a, **kw)
+
+    def _generate(self, input_ids, images=None, refer_boxes=None, ground_boxes=None, use_cache=True, do_sample=False,
+                  max_new_tokens=None, return_dict_in_generate=False, output_hidden_states=False, generation_config=None,
+                  **kw):
         """Greedy decoding as HF GenerationMixin.greedy_search drives the reference model
         (groma/eval/eval_rec.py:93-104): the next token is the arg-max of the LAST position of the right-padded
         expanded sequence; finished rows emit pad; `sequences` = original prompt + new ids."""

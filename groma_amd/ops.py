@@ -4,7 +4,6 @@ torch is used for device memory and the current stream only; every computation b
 in groma_amd/csrc.  All wrappers raise (TypeError / RuntimeError) on bad inputs -- there is no eager path.
 """
 import ctypes
-import os
 
 import torch
 
@@ -45,22 +44,60 @@ def _gemv_ws(splits, M, N, device):
     return t
 
 
-# Split-K for under-filled launches (see _auto_splits).  It is the ONE place where the arithmetic of an image depends on its
-# batch mates: which GEMMs are split depends on M.  With it off, results are bitwise independent of the batch
-# (tests/test_fullsize_properties_gpu.py checks both settings).  GROMA_NO_AUTOSPLIT=1 turns it off for a process.
-AUTO_SPLIT_K = not bool(os.environ.get("GROMA_NO_AUTOSPLIT"))
+# ---- GEMM plan: which launches are split along K ----------------------------------------------------------------------------
+# Split-K changes the fp32 summation order, so the plan must not depend on anything but the GEMM's own (N, K): an image's
+# logits, its selected regions and a served request's tokens are then bitwise independent of who shares the batch -- under
+# EITHER plan (tests/test_fullsize_properties_gpu.py, tests/test_serving_gpu.py at Groma-7B width).
+#   "throughput" (default): never split.  The benchmark's 14 images per GPU fill the chip with whole tiles.
+#   "latency": splits = f(N, K) -- the factor that fills the 512 tile slots of the 128x128 kernel for ONE request-sized row
+#              block (640 rows: a 582-token prompt, a 1025-token ViT image rounds to the same factor), applied at every M.
+#              One image per call: 39 -> 47 img/s (o-proj / down-proj / ViT fc2 / bridge leave most CUs idle otherwise); at
+#              large M it costs the partial-sum traffic, which is why it is a plan the CALLER picks (GromaModel.gemm_plan),
+#              not something inferred from the batch.
+_PLAN = ["throughput"]
+_PLAN_REF_ROWS = 640
 
 
-def _auto_splits(M, N, K):
-    """Split-K factor for an UNDER-FILLED launch (latency configurations: the 582-row LLaMA prefill or the 1025-row ViT of one
-    image leave most of the 256 CUs without a tile in the o-proj / down-proj / fc2 GEMMs).  The 128x128 kernel has 512 tile
-    slots; when the plain launch fills at most half of them and K is deep enough to pay for the extra pass, K is cut so that
-    they are filled, and the partials go through the deterministic reduce + epilogue kernel (same epilogue semantics).  At
-    the benchmark's 14 images per GPU every GEMM has far more than 256 tiles and this returns 1."""
-    t128 = -(-M // 128) * -(-N // 128)
-    if 2 * t128 > 512 or K < 2048 or not AUTO_SPLIT_K:
+def plan_splits(N, K, plan=None):
+    """split-K factor of a plain bf16 GEMM with this (N, K) under `plan` (default: the active plan); a function of (N, K) only"""
+    plan = plan or _PLAN[0]
+    if plan == "throughput" or K < 2048:
+        return 1
+    t128 = -(-_PLAN_REF_ROWS // 128) * -(-N // 128)
+    if 2 * t128 > 512:
         return 1
     return max(1, min(512 // t128, K // 1024, 8))  # at least 16 K-steps of 64 per split
+
+
+class gemm_plan:
+    """with ops.gemm_plan("latency"): ...  -- select the plan for the GEMMs launched inside (re-entrant, restores on exit)"""
+
+    def __init__(self, plan):
+        if plan not in ("throughput", "latency"):
+            raise ValueError(f"unknown GEMM plan {plan!r}")
+        self.plan = plan
+
+    def __enter__(self):
+        self.prev, _PLAN[0] = _PLAN[0], self.plan
+
+    def __exit__(self, *a):
+        _PLAN[0] = self.prev
+
+
+_SPLIT_WS = {}
+
+
+def _split_ws(splits, M, N, device):
+    """fp32 partial-sum workspace [splits, M, N], one growing arena per (device, stream): concurrent launches on the two streams
+    of a forward never share it, launches on one stream are ordered"""
+    key = (str(device), torch.cuda.current_stream().cuda_stream)
+    n = splits * M * N
+    t = _SPLIT_WS.get(key)
+    if t is None or t.numel() < n:
+        if t is not None:
+            torch.cuda.synchronize(device)
+        t = _SPLIT_WS[key] = torch.empty((max(n, 0 if t is None else t.numel() * 3 // 2),), dtype=F32, device=device)
+    return t[:n].view(splits, M, N)
 
 
 def gemm(a, w, *, out=None, bias=None, scale=None, resid=None, act=0, out_f32=False, splits=1, ws=None,
@@ -95,17 +132,15 @@ def gemm(a, w, *, out=None, bias=None, scale=None, resid=None, act=0, out_f32=Fa
     if tile == 0 and conv is None and not fp8 and M <= 8 and splits == 1 and N * K >= (1 << 20):
         tile, splits = 1, (K + 511) // 512  # decode step: weight-streaming kernel + deterministic split-K reduce
         ws = _gemv_ws(splits, M, N, a.device)
-    # (not for the implicit-conv GEMMs: their K = 9*C passes the depth test already in the small test configuration, where
-    # the serving tests assert that a row's tokens are bit-independent of who shares its admission batch; measured gain at
-    # one image per GPU was within box-to-box spread)
+    # (the implicit-conv GEMMs are never split by the plan: measured gain at one image per GPU was within box-to-box spread)
     elif tile == 0 and conv is None and not fp8 and splits == 1 and ws is None and M > 8:
-        splits = _auto_splits(M, N, K)
+        splits = plan_splits(N, K)
     n_out = N // 2 if act == 3 else N
     if out is None:
         out = torch.empty((M, n_out), dtype=F32 if out_f32 else BF16, device=a.device)
     _chk(out, F32 if out_f32 else BF16, "out")
     if splits > 1 and ws is None:
-        ws = torch.empty((splits, M, N), dtype=F32, device=a.device)
+        ws = _split_ws(splits, M, N, a.device)
     d.A, d.W, d.C = a.data_ptr(), w.data_ptr(), out.data_ptr()
     d.bias = _chk(bias, F32, "bias").data_ptr() if bias is not None else None
     d.scale = _chk(scale, F32, "scale").data_ptr() if scale is not None else None
@@ -481,15 +516,23 @@ def _nms_ws(B, n, device):
     return _NMS_WS[key]
 
 
-def nms(boxes_cxcywh, scores, iou_thr, score_thr, max_num, n_valid=None):
+def nms_workspace(B, n, device):
+    """a workspace of the general NMS path (n > 512) that the CALLER owns (None when the one-workgroup path needs none): for
+    launches captured in a hipGraph, whose pointer arguments must outlive the shared cache above"""
+    nbytes = _lib.load().gr_nms_workspace_bytes(B, n)
+    return torch.empty((nbytes,), dtype=torch.uint8, device=device) if nbytes else None
+
+
+def nms(boxes_cxcywh, scores, iou_thr, score_thr, max_num, n_valid=None, workspace=None):
     """boxes [B,n,4] (cx,cy,w,h), scores [B,n] -> keep int64 [B,max_num] (-1 padded), n_keep int32 [B]"""
     lib = _lib.load()
     _chk(boxes_cxcywh, F32, "boxes"); _chk(scores, F32, "scores")
     B, n = scores.shape
     keep = torch.empty((B, max_num), dtype=I64, device=scores.device)
     n_keep = torch.empty((B,), dtype=I32, device=scores.device)
+    ws = workspace if workspace is not None else _nms_ws(B, n, scores.device)
     _lib.check(lib.gr_nms_f32(_p(boxes_cxcywh), _p(scores), B, n, iou_thr, score_thr, max_num, _p(n_valid), _p(keep),
-                              _p(n_keep), _p(_nms_ws(B, n, scores.device)), _stream()), "gr_nms_f32")
+                              _p(n_keep), _p(ws), _stream()), "gr_nms_f32")
     return keep, n_keep
 
 

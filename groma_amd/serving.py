@@ -148,7 +148,7 @@ class ContinuousBatcher:
         llm = self.llm
         ops.embed_gather(self.tok, llm.w["embed"], llm.w["new_embed"], out=self.h)
         llm.forward(self.h, self.rows, 1, self.arena, pos_dev=self.pos, pos_stride=1)
-        ops.sample_rows(llm.ws.get("dec_logits", (self.rows, llm.Vpad), F32, exact=True), llm.V, self.inv_temp, self.seed,
+        ops.sample_rows(llm.decode_logits(self.rows), llm.V, self.inv_temp, self.seed,
                         pos=self.pos, pos_stride=1, pos_off=1, out=self.nxt)  # greedy rows: inv_temp 0 -> arg-max
         ops.greedy_advance(self.nxt, self.tok, self.occupied, self._seq, self.pos, self.step_ctr, self.n_live,
                            eos=None, pad=0, inc_pos=2)

@@ -64,9 +64,7 @@ typedef struct gr_gemm_desc {
                          kernel (M <= 8; requires splits == ceil(K/512) and ws); 2 = the same kernel but
                          the split-K partials are LEFT in ws [splits, M, N] f32 for a fused consumer
                          (gr_decode_reduce_norm / gr_decode_qkv_rope): C and the epilogue fields are unused;
-                         257 = the one-wave-per-SIMD 256x256 kernel (gemm_bf16_w128.hip; bit-identical to 256, not the
-                         default -- also selected for eligible shapes by GROMA_W128=1): plain bf16 GEMM, K % 64 == 0,
-                         at least two K-tiles per split, operands below 4 GiB; GR_EINVAL otherwise */
+                         any other value: GR_EINVAL */
   /* OCP fp8 (e4m3) operands (BASELINE configs[4]): A, W are 1-byte elements, K % 128 == 0, no conv gather;
    * the result is dequantised as acc * a_scale[m] * w_scale[n] before the rest of the epilogue */
   int fp8;

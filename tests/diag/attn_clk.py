@@ -1,6 +1,7 @@
 """GROMA_HIP_LIB=tests/diag/libgroma_hip_clk.so: per-iteration segment clocks of the prefill attention kernel"""
 import ctypes, os, sys
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__))); import _variant; _variant.use_env()
 import torch
 from groma_amd import ops, _lib
 lib = _lib.load()

@@ -1,6 +1,7 @@
 """A/B of epilogue forms of the 256x256 GEMM (GROMA_HIP_LIB=<variant build> selects the other library)"""
 import os, sys, statistics, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__))); import _variant; _variant.use_env()
 from groma_amd import ops
 dev = torch.device("cuda")
 tag = os.path.basename(os.environ.get("GROMA_HIP_LIB", "staged"))

@@ -1,6 +1,7 @@
 """Run with GROMA_HIP_LIB=tests/diag/libgroma_hip_clk.so: shader clock + per-tile phase times of the 256x256 GEMM."""
 import ctypes, os, sys
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__))); import _variant; _variant.use_env()
 import torch
 from groma_amd import ops, _lib
 

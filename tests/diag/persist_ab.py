@@ -1,6 +1,7 @@
-"""shape-level timing of the 256x256 GEMM (run twice: default, and with GROMA_G256_NO_PERSIST=1)"""
+"""shape-level timing of the 256x256 GEMM (run twice: default, and GROMA_HIP_LIB=<build_variant.py nopersist -DG256_NO_PERSIST>)"""
 import os, sys, statistics, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__))); import _variant; _variant.use_env()
 from groma_amd import ops
 dev = torch.device("cuda")
 def once(fn, n=10):
@@ -9,7 +10,7 @@ def once(fn, n=10):
     for _ in range(n): fn()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / n * 1e3
-tag = "no-persist" if os.environ.get("GROMA_G256_NO_PERSIST") else "persist"
+tag = os.path.basename(os.environ.get("GROMA_HIP_LIB", "persist"))
 for M, N, K, kw in [(8148, 22016, 4096, dict(act=3)), (8148, 12288, 4096, {}), (8148, 4096, 11008, dict(res=1)), (8148, 4096, 4096, dict(res=1)),
                     (14350, 4096, 1024, dict(act=1)), (14350, 1024, 4096, {}), (14350, 3072, 1024, {}), (14350, 1024, 1024, {})]:
     a = torch.randn((M, K), device=dev).bfloat16(); w = (torch.randn((N, K), device=dev) * 0.02).bfloat16()

@@ -197,26 +197,27 @@ def test_rec_meter_matches_reference_loop():
     assert all(set(r) == {"image_id", "category_id", "bbox", "score"} for r in res)
 
 
-def test_auto_split_k_plan():
-    """ops._auto_splits: the GEMM plan of the benchmark configuration (14 images per GPU: LLaMA M = 8148, ViT M = 14350) is
-    never split; the single-image prefill (M = 582) and ViT (M = 1025) split exactly the launches that leave the chip
-    under-filled; the switch turns it off."""
+def test_gemm_plan_is_a_function_of_the_layer_shape_only():
+    """ops.plan_splits: the split-K factor depends on (N, K) and the plan the caller picked -- never on M, so an image's
+    arithmetic cannot depend on its batch mates.  "throughput" (default) never splits; "latency" splits exactly the GEMMs that
+    leave the chip under-filled for one request (o-proj, down-proj, ViT fc2, bridge)."""
     from groma_amd import ops
+    import inspect
+    assert list(inspect.signature(ops.plan_splits).parameters) == ["N", "K", "plan"]  # no M anywhere
     llama = [(12288, 4096), (4096, 4096), (22016, 4096), (4096, 11008), (32128, 4096)]  # (N, K): qkv, o, gate-up, down, head
     vit = [(3072, 1024), (1024, 1024), (4096, 1024), (1024, 4096)]                       # qkv, proj, fc1, fc2
-    for N, K in llama:
-        assert ops._auto_splits(8148, N, K) == 1 and ops._auto_splits(4 * 582, N, K) == 1
-    for N, K in vit:
-        assert ops._auto_splits(14350, N, K) == 1
-    assert [ops._auto_splits(582, N, K) for N, K in llama] == [1, 3, 1, 3, 1]
-    assert [ops._auto_splits(1025, N, K) for N, K in vit] == [1, 1, 1, 4]
-    for M, N, K in [(582, 4096, 4096), (1025, 1024, 4096), (16, 4096, 4096)]:
-        s = ops._auto_splits(M, N, K)
-        assert 1 < s <= 8 and K // s >= 1024                                    # at least 16 K-steps of 64 per split
-        assert -(-M // 128) * -(-N // 128) * s <= 512                           # never more work items than tile slots
-    old = ops.AUTO_SPLIT_K
-    try:
-        ops.AUTO_SPLIT_K = False
-        assert ops._auto_splits(582, 4096, 11008) == 1
-    finally:
-        ops.AUTO_SPLIT_K = old
+    assert ops._PLAN[0] == "throughput"
+    assert all(ops.plan_splits(N, K) == 1 for N, K in llama + vit)
+    with ops.gemm_plan("latency"):
+        assert [ops.plan_splits(N, K) for N, K in llama] == [1, 3, 1, 3, 1]
+        assert [ops.plan_splits(N, K) for N, K in vit] == [1, 1, 1, 4]
+        for N, K in [(4096, 4096), (1024, 4096), (4096, 11008)]:
+            sp = ops.plan_splits(N, K)
+            assert 1 < sp <= 8 and K // sp >= 1024                                       # at least 16 K-steps of 64 per split
+        with ops.gemm_plan("throughput"):                                                # re-entrant
+            assert ops.plan_splits(4096, 4096) == 1
+        assert ops.plan_splits(4096, 4096) == 3
+    assert ops._PLAN[0] == "throughput" and ops.plan_splits(4096, 4096, "latency") == 3
+    import pytest
+    with pytest.raises(ValueError):
+        ops.gemm_plan("auto")

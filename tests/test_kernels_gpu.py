@@ -65,7 +65,7 @@ def test_gemm_fp32_residual_large_shapes(dev, M, N, K):
     assert torch.equal(out, ops.gemm(a, w, resid=resid, out_f32=True, tile=256))  # deterministic
 
 
-@pytest.mark.parametrize("tile", [128, 256, 257])
+@pytest.mark.parametrize("tile", [128, 256])
 def test_gemm_epilogues(dev, tile):
     import functools
     ops = _ops()
@@ -89,7 +89,7 @@ def test_gemm_epilogues(dev, tile):
     g, u = base[:, 0::2], base[:, 1::2]
     assert relerr(ops.gemm(a, w, bias=bias, act=3), F.silu(g) * u) < 4e-3
     # split-K
-    out = ops.gemm(a, w, bias=bias, resid=resid, out_f32=True, splits=2 if tile == 257 else 3)  # 257: whole K-tiles per split
+    out = ops.gemm(a, w, bias=bias, resid=resid, out_f32=True, splits=3)
     assert relerr(out, resid + base) < 1e-5
     # position-embedding style residual + row remap (patch tokens -> rows 1.. of each image)
     pos = rnd((100, N), dev, seed=6)
@@ -100,19 +100,13 @@ def test_gemm_epilogues(dev, tile):
     assert buf.view(3, 101, N)[:, 0].abs().max().item() == 0.0
 
 
-@pytest.mark.parametrize("M,N,K", [(577, 768, 1024), (300, 4096, 256), (1025, 1000, 4096), (2052, 2048, 11008)])
-def test_gemm_w128_bit_identical(dev, M, N, K):
-    """tile=257 (one-wave-per-SIMD 256x256 kernel, gemm_bf16_w128.hip; opt-in) sums in the same order as the ping-pong
-    kernel: identical bits, ragged edges included; shapes it does not cover are refused, not silently rerouted"""
+def test_gemm_unknown_tile_is_refused(dev):
+    """the tile field of the descriptor names a kernel; an unknown value is an error, never a silent reroute"""
     ops = _ops()
-    a = rnd((M, K), dev, seed=1).bfloat16()
-    w = rnd((N, K), dev, 0.05, seed=2).bfloat16()
-    resid = rnd((M, N), dev, seed=3)
-    assert torch.equal(ops.gemm(a, w, tile=257), ops.gemm(a, w, tile=256))
-    assert torch.equal(ops.gemm(a, w, resid=resid, out_f32=True, tile=257), ops.gemm(a, w, resid=resid, out_f32=True, tile=256))
-    assert relerr(ops.gemm(a, w, tile=257), a.float() @ w.float().t()) < 4e-3
-    with pytest.raises(Exception):
-        ops.gemm(a[:, :64].contiguous(), w[:, :64].contiguous(), tile=257)  # a single K-tile: below its pipeline depth
+    a = rnd((300, 256), dev, seed=1).bfloat16()
+    w = rnd((512, 256), dev, 0.1, seed=2).bfloat16()
+    with pytest.raises(RuntimeError):
+        ops.gemm(a, w, tile=257)
 
 
 @pytest.mark.parametrize("M,N,K", [(1, 4096, 4096), (3, 1024, 11008), (8, 2816, 512), (4, 32128, 4096)])

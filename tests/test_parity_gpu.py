@@ -318,3 +318,41 @@ def test_forward_with_hundreds_of_refer_boxes(setup):
         assert (ref["nms_inds"][i] >= 300).any()  # refer boxes (score 1.0) really took part
     assert torch.equal(model._last_aux["input_ids"], ref["input_ids"])
     assert util.relerr(out.logits, ref["logits"]) < 2e-2
+
+
+def test_generate_nine_rows_graph_equals_eager_and_survives_a_larger_prefill(setup):
+    """More than 8 rows leave the weight-streaming decode kernels (gemv_bf16: M <= 8) for the general GEMM path.  The captured
+    step must then (a) hand its logits to the sampler (round-2 regression: the sampler read a buffer only the M <= 8 path
+    wrote, so every token after the first was id 0) and (b) keep addressing live memory after a LARGER prefill regrew the
+    shared scratch arenas between two generate() calls."""
+    cfg, sd, tk, model, images, ids = setup
+    from groma_amd import synth
+    im9, id9 = synth.make_inputs(cfg, tk, bs=9, seed=4321)
+    gc = model.generation_config
+    old = (gc.eos_token_id, model.decode_graph)
+    try:
+        gc.eos_token_id, model.decode_graph = None, False
+        torch.manual_seed(5)
+        eager = model.generate(id9.clone(), images=im9, max_new_tokens=6).cpu()
+        model.decode_graph = True
+        torch.manual_seed(5)
+        g1 = model.generate(id9.clone(), images=im9, max_new_tokens=6).cpu()
+        assert torch.equal(g1, eager), (g1[:, id9.shape[1]:].tolist(), eager[:, id9.shape[1]:].tolist())
+        new = eager[:, id9.shape[1]:]
+        assert (new[:, 1:] != 0).any(), "decode steps produced only id 0: the sampler is not reading the step's logits"
+        # a larger prefill (12 rows) regrows every shared arena; the 9-row graph is then replayed again
+        im12, id12 = synth.make_inputs(cfg, tk, bs=12, seed=99)
+        torch.manual_seed(6)
+        model.forward(input_ids=id12.clone(), images=im12, return_dict=True)
+        torch.manual_seed(5)
+        g2 = model.generate(id9.clone(), images=im9, max_new_tokens=6).cpu()
+        assert torch.equal(g2, eager)
+    finally:
+        gc.eos_token_id, model.decode_graph = old
+    # and the tokens are the oracle's (HF greedy over the CPU restatement), row by row
+    dev_h = [model._ws.get(f"vit_h{i}", (9, model.vit.T, model.vit.D), torch.float32).cpu() for i in range(4)]
+    torch.manual_seed(5)
+    ref = O.greedy_generate(sd, cfg.to_dict(), util.tok_dict(tk), id9.clone(), im9, 6, eos_token_id=-1, hidden_states=tuple(dev_h))
+    P = id9.shape[1]
+    ncmp = util.assert_greedy_tokens_match(eager[:, P:], ref["sequences"][:, P:], ref["margins"], MIN_MARGIN, "9 rows")
+    assert ncmp >= 6
