@@ -153,7 +153,7 @@ def measure_traffic(batch, kernel="gemm_bf16_256_kernel"):
             out = os.path.join(tmp, ctr)
             cmd = ["rocprofv3", "--pmc", ctr, "--kernel-trace", "--output-format", "csv", "-d", out, "--", sys.executable,
                    os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "1", "--batch", str(batch), "--no-cpu-baseline",
-                   "--no-traffic"]
+                   "--no-traffic", "--no-extras"]
             subprocess.run(cmd, cwd="/tmp", env=env, timeout=420, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=True)
             tot, n = 0.0, 0
             for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
@@ -169,6 +169,165 @@ def measure_traffic(batch, kernel="gemm_bf16_256_kernel"):
         return None
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
+
+
+def _free_port():
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        return so.getsockname()[1]
+
+
+def launch_ranks(args, argv):
+    """`python bench.py --gpus N` with no launcher around it: become the launcher.  Re-executes this file under
+    torch.distributed.run with one process per GPU (the reference launches its data-parallel eval the same way:
+    groma/eval/eval_rec.py:63-83 under torchrun), rendezvous on 127.0.0.1, and returns the children's exit code.  Refuses
+    (non-zero) when fewer than N devices are visible instead of quietly measuring fewer ranks."""
+    import subprocess
+    if not args.dry_exchange:
+        n_dev = torch.cuda.device_count()
+        if n_dev < args.gpus:
+            print(f"bench.py: --gpus {args.gpus} but only {n_dev} GPU(s) visible", file=sys.stderr)
+            return 3
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC (RCCL across processes needs it on this driver)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + argv
+    return subprocess.run(cmd, env=env).returncode
+
+
+ROW_BOXES = 400  # 100 region slots x (cx, cy, w, h)
+
+
+def pack_rows(head, boxes_list):
+    """One f32 row per image for the step's single all-gather: [head | 100 x 4 box slots (zero padded) | N_i].
+    head = the <r0..r99> logits of the last position (forward) or the generated ids (generate; ids < 2^24 are exact in f32)."""
+    b = head.shape[0]
+    out = torch.zeros((b, head.shape[1] + ROW_BOXES + 1), dtype=torch.float32, device=head.device)
+    out[:, : head.shape[1]] = head
+    if boxes_list and all(x.shape[0] == boxes_list[0].shape[0] for x in boxes_list):   # the benchmark: N_i = 100 everywhere
+        n = boxes_list[0].shape[0]
+        out[:, head.shape[1]: head.shape[1] + 4 * n] = torch.stack(boxes_list).reshape(b, 4 * n)
+        out[:, -1] = float(n)
+    else:
+        for i, bx in enumerate(boxes_list):
+            out[i, head.shape[1]: head.shape[1] + 4 * bx.shape[0]] = bx.reshape(-1)
+            out[i, -1] = float(bx.shape[0])
+    return out
+
+
+def run_dry_exchange(args, rank, world):
+    """No model, no GPU: the launcher + process group + ShardedJob exchange + timing contract with synthetic rows (gloo).
+    What tests/test_bench_launcher.py runs with 2 ranks on CPU."""
+    from groma_amd import dist as gdist
+    dev = torch.device("cpu")
+    if world > 1:
+        gdist.init("gloo", None)
+    strong = args.global_batch > 0
+    head = 100
+    job = gdist.ShardedJob(dev, (head + ROW_BOXES + 1,), torch.float32,
+                           **(dict(global_batch=args.global_batch) if strong else dict(rows_per_rank=args.batch)))
+    ranks = gdist.count_ranks(dev)
+
+    def rows_of(lo, hi, i):   # deterministic function of the GLOBAL image index, so rank 0 can check what it gathered
+        idx = torch.arange(lo, hi, dtype=torch.float32)
+        heads = idx[:, None] * 1000.0 + torch.arange(head, dtype=torch.float32)[None] + float(i)
+        boxes = [torch.full((100 - (int(g) % 3), 4), float(g)) for g in idx]
+        return pack_rows(heads, boxes)
+
+    last = {}
+
+    def step(i):
+        last["i"], last["out"] = i, job.exchange(rows_of(job.lo, job.hi, i)) if job.rows else job.exchange(torch.zeros((0, head + ROW_BOXES + 1)))
+        return last["out"]
+    elapsed = job.timed(step, args.warmup, args.steps)
+    ok = torch.equal(last["out"], rows_of(0, job.global_batch, last["i"]))
+    if rank == 0:
+        print(json.dumps({"metric": "dry exchange (no model)", "value": job.global_batch * args.steps / elapsed, "unit": "rows/s",
+                          "n_gpus": world, "rccl_ranks": ranks, "backend": "gloo", "steps": args.steps, "warmup": args.warmup,
+                          "scaling": "strong" if strong else "weak", "global_batch": job.global_batch, "shards": job.counts,
+                          "exchange_ok": bool(ok), "exchanged_regions": int(last["out"][:, -1].sum().item())}), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0 if ok else 1
+
+
+def measure(model, cfg, args, dev, rank, job, P, gen, batch, plan="throughput", steps=None, warmup=None, strong=False):
+    """time `steps` steps of the hot path at `batch` images per forward call through `job`; returns (seconds, step_fn)"""
+    from groma_amd import synth
+    steps = args.steps if steps is None else steps
+    warmup = args.warmup if warmup is None else warmup
+    if strong:   # the same global images whatever the world size; this rank keeps its shard
+        images, ids = synth.make_inputs(cfg, model, job.global_batch, seed=1234, prompt_len=P)
+        images, ids = images[job.lo:job.hi], ids[job.lo:job.hi]
+    else:
+        images, ids = synth.make_inputs(cfg, model, job.rows, seed=1234 + rank, prompt_len=P)
+    images, ids = images.to(dev), ids.to(dev)
+    r0 = model.box_idx_token_ids[0]
+    chunks = [(lo, min(lo + batch, job.rows)) for lo in range(0, job.rows, batch)]
+    width = job.row_shape[0]
+
+    def step(i):
+        torch.manual_seed(1000 + i)  # the path draws torch.randperm (T4)
+        rows = []
+        for lo, hi in chunks:
+            if gen:
+                g = model.generate(ids[lo:hi], images=images[lo:hi], max_new_tokens=args.new_tokens, return_dict_in_generate=True,
+                                   output_hidden_states=True)
+                rows.append(pack_rows(g.sequences.float(), g.hidden_states[0][-1]["pred_boxes"]))
+            else:
+                out = model.forward(input_ids=ids[lo:hi], images=images[lo:hi], use_cache=False, return_dict=True)
+                rows.append(pack_rows(out.logits[:, -1, r0:r0 + 100], out.hidden_states[1]["pred_boxes"]))
+        if not rows:   # a rank whose shard is empty (global batch < world): it still takes part in the collective
+            return job.exchange(torch.zeros((0, width), dtype=torch.float32, device=dev))
+        return job.exchange(rows[0] if len(rows) == 1 else torch.cat(rows))
+
+    old = model.gemm_plan
+    model.gemm_plan = plan
+    try:
+        elapsed = job.timed(step, warmup, steps)
+    finally:
+        model.gemm_plan = old
+    return elapsed, step
+
+
+def extras_block(model, cfg, args, dev, P):
+    """Secondary lines measured in the SAME run, after (outside) the headline's timed region, N = 1 only: the small-batch
+    forward (SURVEY 8d configs[2] at 1 and 4 images per call), configs[3]'s per-GPU share (greedy generate, 4 images, 32 new
+    tokens) and configs[4] (e4m3 operands).  Each is its own ShardedJob.timed() with its own warm-up."""
+    from groma_amd import constants, dist as gdist
+    from groma_amd.groma import GromaModel
+    ex = {}
+
+    def line(m, batch, gen, plan="throughput", steps=10, warmup=3):
+        head = (P + args.new_tokens) if gen else 100
+        job = gdist.ShardedJob(dev, (head + ROW_BOXES + 1,), torch.float32, rows_per_rank=batch)
+        el, _ = measure(m, cfg, args, dev, 0, job, P, gen, batch, plan=plan, steps=steps, warmup=warmup)
+        return {"value": batch * steps / el, "unit": "images/s", "ms_per_step": el / steps * 1e3, "images_per_call": batch,
+                "gemm_plan": plan, "steps": steps, "warmup": warmup}
+
+    ex["forward_1_image_per_call"] = line(model, 1, False)
+    ex["forward_1_image_per_call_latency_plan"] = line(model, 1, False, plan="latency")
+    ex["forward_4_images_per_call"] = line(model, 4, False)
+    eos = model.generation_config.eos_token_id
+    model.generation_config.eos_token_id = None
+    try:
+        g = line(model, 4, True, steps=3, warmup=1)
+    finally:
+        model.generation_config.eos_token_id = eos
+    g["new_tokens"] = args.new_tokens
+    g["workload"] = "configs[3] per-GPU share: prefill + greedy decode (hipGraph replay), no EOS"
+    ex["generate_4_images_per_call"] = g
+    m8 = GromaModel.from_synthetic(cfg, seed=0, device=dev, fp8=True)
+    m8.init_special_token_id(constants.SyntheticTokenizer())
+    f8 = line(m8, args.batch, False, steps=5, warmup=2)
+    f8["dtype"] = "fp8 (OCP e4m3 operands for the DINOv2 / LLaMA linears, f32 accumulate; lm_head and region convs bf16)"
+    ex["forward_fp8"] = f8
+    del m8
+    torch.cuda.empty_cache()
+    return ex
 
 
 def main():
@@ -187,23 +346,39 @@ def main():
     ap.add_argument("--new-tokens", type=int, default=32)
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise the RCCL process group and run the per-step all-gather even with one rank (smoke test of "
-                         "the N>1 path on a 1-GPU box; launch under torch.distributed.run --nproc-per-node 1)")
+                         "the N>1 path on a 1-GPU box)")
     ap.add_argument("--global-batch", type=int, default=0,
                     help="STRONG scaling: a fixed number of images per step, sharded over the ranks (groma_amd.dist.shard_range) and "
                          "processed in micro-batches of --batch.  BASELINE configs[3] = --mode generate --global-batch 32 --batch 4 "
                          "(4 images per GPU at 8 ranks).  0 (default) = weak scaling, --batch images on every rank")
+    ap.add_argument("--gemm-plan", default="throughput", choices=["throughput", "latency"],
+                    help="split-K plan class of the headline measurement (ops.plan_splits): a function of the layer shape only")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-traffic", action="store_true",
                     help="skip the live rocprofv3 PMC passes for roofline.traffic (the committed profiles/ summary is reported instead)")
-    ap.add_argument("--cpu-baseline-reps", type=int, default=1, help="timed full-depth oracle forwards (median is reported)")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the `extras` block (1 and 4 images per call, greedy generate, e4m3 operands: measured after the "
+                         "headline's timed region, N = 1 only)")
+    ap.add_argument("--cpu-baseline-reps", type=int, default=3,
+                    help="timed full-depth oracle forwards after the reduced-depth warm-up; the median is reported (BASELINE.md 3)")
     ap.add_argument("--gemm-breakdown", default=None, help="write a per-shape GEMM table (from the HIP-event hook) here")
+    ap.add_argument("--dry-exchange", action="store_true",
+                    help="launcher / process-group / exchange / timing path only, with synthetic rows on CPU (gloo); no model")
     args = ap.parse_args()
 
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(launch_ranks(args, sys.argv[1:]))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus != world and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.gpus != world:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch one process per GPU (or let `python bench.py --gpus N` do it)")
+    if args.dry_exchange:
+        raise SystemExit(run_dry_exchange(args, rank, world))
+    if torch.cuda.device_count() <= local_rank:
+        raise SystemExit(f"rank {rank}: LOCAL_RANK {local_rank} but {torch.cuda.device_count()} GPU(s) visible")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     use_dist = world > 1 or args.force_dist
@@ -211,7 +386,10 @@ def main():
     from groma_amd import config as gconfig, constants, dist as gdist, ops, synth
     from groma_amd.groma import GromaModel
     if use_dist:
-        gdist.init("nccl", dev)  # RCCL over xGMI; rendezvous on 127.0.0.1 unless the launcher says otherwise
+        gdist.init("nccl", dev, single_process=(world == 1))  # RCCL over xGMI; rendezvous on 127.0.0.1 unless the launcher says otherwise
+    rccl_ranks = gdist.count_ranks(dev)  # all-reduce of ones: proves how many ranks took part (1 without a process group)
+    if rccl_ranks != world:
+        raise SystemExit(f"process group has {rccl_ranks} ranks, expected {world}")
 
     cfg = gconfig.groma_7b(box_score_thres=0.0) if args.config == "7b" else gconfig.groma_tiny(box_score_thres=0.0)
     fp8 = args.dtype == "fp8"
@@ -221,37 +399,21 @@ def main():
     gen = args.mode == "generate"
     strong = args.global_batch > 0
     # the per-rank driver (shard bookkeeping, ONE all-gather of the per-image rows per step, barrier + max-over-ranks
-    # timing) is groma_amd.dist.ShardedJob -- the same code tests/test_dist_gloo.py runs with 2 gloo ranks
-    row = (P + args.new_tokens,) if gen else (100,)
-    job = gdist.ShardedJob(dev, row, torch.int64 if gen else torch.float32,
+    # timing) is groma_amd.dist.ShardedJob -- the same code tests/test_dist_gloo.py runs with 2 gloo ranks.  A row carries
+    # everything SURVEY 8e lists: region logits (or generated ids), pred_boxes [100, 4], N_i
+    head_w = (P + args.new_tokens) if gen else 100
+    job = gdist.ShardedJob(dev, (head_w + ROW_BOXES + 1,), torch.float32,
                            **(dict(global_batch=args.global_batch) if strong else dict(rows_per_rank=args.batch)))
-    if strong:   # the same global images whatever the world size; this rank keeps its shard
-        images, ids = synth.make_inputs(cfg, model, job.global_batch, seed=1234, prompt_len=P)
-        images, ids = images[job.lo:job.hi], ids[job.lo:job.hi]
-    else:
-        images, ids = synth.make_inputs(cfg, model, args.batch, seed=1234 + rank, prompt_len=P)
-    images, ids = images.to(dev), ids.to(dev)
-    r0 = model.box_idx_token_ids[0]
-    chunks = [(lo, min(lo + args.batch, job.rows)) for lo in range(0, job.rows, args.batch)]
     if gen:
         model.generation_config.eos_token_id = None  # random-init weights: fixed-length decode, never an early stop
 
-    def step(i):
-        torch.manual_seed(1000 + i)  # the path draws torch.randperm (T4)
-        rows = []
-        for lo, hi in chunks:
-            if gen:
-                rows.append(model.generate(ids[lo:hi], images=images[lo:hi], max_new_tokens=args.new_tokens))
-            else:
-                logits, _ = model.forward(input_ids=ids[lo:hi], images=images[lo:hi], use_cache=False)
-                rows.append(logits[:, -1, r0:r0 + 100])
-        local = rows[0] if len(rows) == 1 else torch.cat(rows)
-        return job.exchange(local.contiguous())
-
-    elapsed = job.timed(step, args.warmup, args.steps)
+    elapsed, step = measure(model, cfg, args, dev, rank, job, P, gen, args.batch, plan=args.gemm_plan, strong=strong)
+    gathered = step(args.warmup + args.steps)  # one more (untimed) step: what the exchange delivered
+    exchanged_regions = int(gathered[:, -1].sum().item())
+    model.gemm_plan = args.gemm_plan
 
     # ---- roofline leg: the same steps again with HIP events around every GEMM launch (on the launch stream) ----
-    n_reg = [b.shape[0] for b in model._last_aux["sel_idx"]]
+    n_reg = [b.shape[0] for b in model._last_aux["sel_idx"]] if job.rows else [100]
     fl = flops_per_image(cfg, sum(n_reg) / len(n_reg), P)
     model.decode_graph = False  # HIP events cannot bracket launches inside a replayed graph: time the same kernels eagerly
     ops.prof_enable(True)
@@ -259,6 +421,7 @@ def main():
         step(args.warmup + i)
     torch.cuda.synchronize()
     ops.prof_enable(False)
+    model.decode_graph = True
     recs = ops.prof_read_launches()
     if args.gemm_breakdown and rank == 0:
         agg = {}
@@ -307,12 +470,17 @@ def main():
         "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong" if strong else "weak",
         "vs_baseline": None,
         "dtype": args.dtype, "data": "synthetic",
+        "rccl_ranks": rccl_ranks,  # all-reduce of ones over the process group: the ranks that actually took part
+        "exchange": {"collective": "one all_gather_into_tensor per step" if use_dist else "none (single process)",
+                     "row_f32": {"head": head_w, "pred_boxes": ROW_BOXES, "n_regions": 1},
+                     "rows_gathered": int(gathered.shape[0]), "regions_gathered": exchanged_regions},
         "config": {"workload": "configs[2]: full Groma-7B forward (DINOv2-L + DDETR 300 proposals -> NMS 100 regions + "
                                "region encoder + Vicuna-7B prefill, logits for all positions), random-init weights"
                                if args.config == "7b" else "tiny parity architecture (NOT the headline workload)",
                    "images_per_gpu": job.rows, "images_per_forward_call": min(args.batch, job.rows),
                    "global_batch": job.global_batch, "prompt_tokens": P,
                    "llm_seq_len": fl["L"], "regions_per_image": sum(n_reg) / len(n_reg),
+                   "gemm_plan": args.gemm_plan,
                    "parallelism": f"dp{world} (image batch sharded, full replica per GPU)"},
         "roofline": {"bound": "mfma", "kernel": kname,
                      "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
@@ -344,6 +512,11 @@ def main():
                            "bytes_per_launch": gv_bytes / max(len(gv), 1),
                            "kernel_time_share_of_step": (gv_ms / args.steps) / (elapsed / args.steps * 1e3)}
     if rank == 0:
+        if world == 1 and not args.no_extras and not gen and not fp8:
+            try:
+                out["extras"] = extras_block(model, cfg, args, dev, P)
+            except Exception as e:  # an extra never takes the headline down
+                out["extras"] = {"error": f"{type(e).__name__}: {e}"}
         if world == 1 and not args.no_cpu_baseline and not gen:
             try:
                 out["cpu_baseline"] = cpu_baseline(args.config, full_reps=args.cpu_baseline_reps)

@@ -39,6 +39,16 @@ def init(backend=None, device=None, single_process=False):
     return dist
 
 
+def count_ranks(device):
+    """all-reduce of ones over the default group: how many ranks actually take part (1 without a process group)"""
+    import torch.distributed as dist
+    if not dist.is_initialized():
+        return 1
+    t = torch.ones((1,), dtype=torch.float32, device=device)
+    dist.all_reduce(t)
+    return int(round(float(t.item())))
+
+
 def all_gather_rows(local, counts=None):
     """All-gather a [b_local, ...] tensor along dim 0 (ragged shard sizes allowed via `counts` = per-rank rows).
     One collective; KB-scale messages -> latency-bound on xGMI, not link-bound."""

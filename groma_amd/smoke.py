@@ -1,4 +1,10 @@
-"""__graft_entry__.smoke(): one tiny invocation of the hot path on cuda:0, checked against the oracle."""
+"""__graft_entry__.smoke(): one small invocation of the hot path on cuda:0, checked against the oracle.
+
+Groma-7B WIDTH at reduced depth (config.groma_7b_width: every GEMM / conv / attention shape of the benchmark -- ViT 1024 x 16
+heads, 1024-channel pyramid, 27 648-deep per-ROI conv, LLaMA 4096 / 11 008 / 32 heads, 32 114-wide head, 6+6 DDETR -- with 3 ViT
+layers, 1 fusion round, 1 LLaMA layer), one image: the fp32 CPU oracle finishes in seconds."""
+import os
+
 import torch
 
 
@@ -8,7 +14,8 @@ def run_smoke():
     from groma_amd.groma import GromaModel
     from oracle import groma_oracle as O
 
-    cfg = config.groma_tiny(box_score_thres=0.0)
+    torch.set_num_threads(max(1, min(64, os.cpu_count() or 8)))
+    cfg = config.groma_7b_width(box_score_thres=0.0)
     sd = synth.make_state_dict(cfg, 0)
     model = GromaModel.from_state_dict(cfg, sd, "cuda:0")
     tk = constants.SyntheticTokenizer()
@@ -17,14 +24,17 @@ def run_smoke():
     torch.manual_seed(3)
     out = model.forward(input_ids=ids.clone(), images=images, return_dict=True)
     torch.cuda.synchronize()
-    hs = tuple(model._ws.get(f"vit_h{i}", (1, model.vit.T, model.vit.D), torch.float32).cpu() for i in range(4))
+    hs = tuple(h.float().cpu() for h in model._last_aux["hidden4"])
     tok = dict(pad_token_id=model.pad_token_id, img_token_id=model.img_token_id, reg_token_id=model.reg_token_id,
                refer_box_token_id=model.refer_box_token_id, refer_feat_token_id=model.refer_feat_token_id,
                ground_box_token_id=model.ground_box_token_id, box_idx_token_ids=model.box_idx_token_ids)
     torch.manual_seed(3)
-    ref = O.groma_forward(sd, cfg.to_dict(), tok, ids.clone(), images, hidden_states=hs)
+    with torch.no_grad():
+        ref = O.groma_forward(sd, cfg.to_dict(), tok, ids.clone(), images, hidden_states=hs)
     assert torch.equal(model._last_aux["nms_keep"][0], ref["nms_inds"][0]), "NMS indices differ from the oracle"
+    assert torch.equal(model._last_aux["input_ids"], ref["input_ids"]), "spliced token ids differ from the oracle"
     a, b = out.logits.float().cpu(), ref["logits"]
     err = ((a - b).norm() / b.norm()).item()
-    assert err < 2e-2, f"logits relative error {err}"
-    print(f"smoke ok: logits {tuple(a.shape)} rel-L2 vs oracle {err:.2e}, N={ref['pred_boxes'][0].shape[0]} regions")
+    assert err < 1e-2, f"logits relative error {err}"
+    print(f"smoke ok (Groma-7B width, reduced depth): logits {tuple(a.shape)} rel-L2 vs fp32 oracle {err:.2e}, "
+          f"N={ref['pred_boxes'][0].shape[0]} regions, L={ref['input_ids'].shape[1]}")

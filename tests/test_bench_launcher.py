@@ -1,0 +1,61 @@
+"""bench.py as the driver invokes it -- `python bench.py --gpus N` with no launcher around it -- must start N ranks itself
+(R: the reference launches its data-parallel eval under torchrun, groma/eval/eval_rec.py:63-83,122-124).  Exercised here on CPU
+with --dry-exchange: the real launcher, torch.distributed.run rendezvous on 127.0.0.1, the gloo process group, bench's own
+ShardedJob exchange of the SURVEY-8e row (region logits | pred_boxes | N_i) and the timing contract -- everything but the model."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(args, env_extra=None, timeout=300):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(env_extra or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env, capture_output=True, text=True,
+                          timeout=timeout)
+
+
+def _json_line(stdout):
+    lines = [l for l in stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, stdout  # rank 0 prints ONE JSON line
+    return json.loads(lines[0])
+
+
+def test_bench_spawns_its_own_ranks_weak():
+    r = _run(["--gpus", "2", "--dry-exchange", "--steps", "3", "--warmup", "1", "--batch", "3"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = _json_line(r.stdout)
+    assert d["n_gpus"] == 2 and d["rccl_ranks"] == 2 and d["steps"] == 3 and d["warmup"] == 1
+    assert d["scaling"] == "weak" and d["global_batch"] == 6 and d["shards"] == [3, 3] and d["exchange_ok"]
+
+
+def test_bench_strong_shards_with_an_empty_rank():
+    """global batch 2 over 3 ranks: rank 2 owns no image and still joins every collective"""
+    r = _run(["--gpus", "3", "--dry-exchange", "--steps", "2", "--warmup", "1", "--global-batch", "2"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = _json_line(r.stdout)
+    assert d["rccl_ranks"] == 3 and d["scaling"] == "strong" and d["shards"] == [1, 1, 0] and d["exchange_ok"]
+    assert d["exchanged_regions"] == 100 + 99   # N_i of global images 0 and 1 as the synthetic rows define them
+
+
+def test_bench_refuses_inconsistent_launches():
+    # a launcher exported another world size than --gpus says
+    r = _run(["--gpus", "1", "--dry-exchange", "--steps", "1", "--warmup", "0"], {"WORLD_SIZE": "2", "RANK": "0"})
+    assert r.returncode != 0 and "WORLD_SIZE=2" in r.stderr + r.stdout
+    # no GPUs here: the real (non-dry) N-rank launch must fail loudly, not run fewer ranks
+    r = _run(["--gpus", "2", "--steps", "1", "--warmup", "0"])
+    assert r.returncode != 0 and "GPU(s) visible" in r.stderr
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
+
+
+def test_dist_init_requires_a_launcher():
+    import pytest
+    from groma_amd import dist as gdist
+    old = {k: os.environ.pop(k) for k in ("RANK", "WORLD_SIZE") if k in os.environ}
+    try:
+        with pytest.raises(RuntimeError):
+            gdist.init("gloo")
+    finally:
+        os.environ.update(old)
