@@ -35,6 +35,12 @@ def _trace(name, t):
     return t
 
 
+def _trace_q8(tag, x8, sx):
+    """e4m3 operand of a GEMM: the quantised rows and their scales (tests/test_fp8_width_gpu.py feeds exactly these to the oracle)"""
+    if TRACE is not None and tag:
+        TRACE[tag + ".q8"], TRACE[tag + ".s8"] = x8.detach().clone(), sx.detach().clone()
+
+
 class Workspace:
     """Scratch arenas, one per buffer NAME, grown geometrically and handed out as a view of the first prod(shape)
     elements -- so ragged request shapes (L = P + 256 + 2*N_regions changes with every image, R = sum N_i) do not
@@ -119,15 +125,17 @@ class VitEngine:
             """LayerNorm -> GEMM (bf16 operands, or e4m3 operands with dynamic per-row activation scales)"""
             if fp8:
                 x8, sx = ops.norm_fp8(x_f32, ln_g, ln_b, self.eps, False)
+                _trace_q8(tag, x8, sx)
                 return ops.gemm(x8, wt[0], a_scale=sx, w_scale=wt[1], **kw)
             x = ops.layernorm(x_f32, ln_g, ln_b, self.eps, out_bf16=True, out=ws.get("vit_x", (M, D), BF16))
             if tag:
                 _trace(tag, x)
             return ops.gemm(x, wt[0], **kw)
 
-        def lin_bf16(x_bf16, wt, **kw):
+        def lin_bf16(x_bf16, wt, tag=None, **kw):
             if fp8:
                 x8, sx = ops.quant_rows_fp8(x_bf16)
+                _trace_q8(tag, x8, sx)
                 return ops.gemm(x8, wt[0], a_scale=sx, w_scale=wt[1], **kw)
             return ops.gemm(x_bf16, wt[0], **kw)
 
@@ -143,11 +151,11 @@ class VitEngine:
                                     fused=dict(B=bs, H=H, Lq=T, hd=hd))
             else:
                 ctx = ops.attention(q, k, vt, Skv=T, causal=False, out=ws.get("vit_ctx", (M, D), BF16))
-            lin_bf16(ctx, L["wo"], bias=L["bo"], scale=L["ls1"], resid=h, out=mid, out_f32=True)
+            lin_bf16(ctx, L["wo"], tag="vit0.ctx" if t0 else None, bias=L["bo"], scale=L["ls1"], resid=h, out=mid, out_f32=True)
             y = lin(mid, L["ln2_g"], L["ln2_b"], L["w1"], tag="vit0.ln2" if t0 else None, bias=L["b1"], act=1,
                     out=ws.get("vit_y", (M, L["w1"][0].shape[0]), BF16))
             hn = out_buf(i + 1)
-            lin_bf16(y, L["w2"], bias=L["b2"], scale=L["ls2"], resid=mid, out=hn, out_f32=True)
+            lin_bf16(y, L["w2"], tag="vit0.fc1" if t0 else None, bias=L["b2"], scale=L["ls2"], resid=mid, out=hn, out_f32=True)
             if t0:
                 _trace("vit0.qkv", qkv), _trace("vit0.ctx", ctx), _trace("vit0.mid", mid), _trace("vit0.fc1", y), _trace("vit0.out", hn)
             h = hn
@@ -390,15 +398,17 @@ class LlamaEngine:
             """RMSNorm -> GEMM (bf16 operands, or e4m3 operands with dynamic per-row activation scales)"""
             if fp8:
                 x8, sx = ops.norm_fp8(x_f32, gain, None, self.eps, True)
+                _trace_q8(tag, x8, sx)
                 return ops.gemm(x8, wt[0], a_scale=sx, w_scale=wt[1], **kw)
             x = ops.rmsnorm(x_f32, gain, self.eps, out=buf("llm_x", (M, T), BF16))
             if tag:
                 _trace(tag, x)
             return ops.gemm(x, wt[0], **kw)
 
-        def lin_bf16(x_bf16, wt, **kw):
+        def lin_bf16(x_bf16, wt, tag=None, **kw):
             if fp8:
                 x8, sx = ops.quant_rows_fp8(x_bf16)
+                _trace_q8(tag, x8, sx)
                 return ops.gemm(x8, wt[0], a_scale=sx, w_scale=wt[1], **kw)
             return ops.gemm(x_bf16, wt[0], **kw)
 
@@ -416,13 +426,17 @@ class LlamaEngine:
                                     **att_kw)
             else:
                 ctx = ops.attention(q, cache.k[i], cache.vt[i], **att_kw)
-            lin_bf16(ctx, Lw["wo"], resid=h, out=h, out_f32=True)
             if t0:
-                _trace("llm0.qkv", qkv), _trace("llm0.ctx", ctx), _trace("llm0.h_attn", h)
+                _trace("llm0.qkv", qkv), _trace("llm0.ctx", ctx)
+            lin_bf16(ctx, Lw["wo"], tag="llm0.ctx" if t0 else None, resid=h, out=h, out_f32=True)
+            if t0:
+                _trace("llm0.h_attn", h)
             y = lin(h, Lw["n2"], Lw["wgu"], tag="llm0.n2" if t0 else None, act=3, out=buf("llm_y", (M, self.I), BF16))
-            lin_bf16(y, Lw["wd"], resid=h, out=h, out_f32=True)
             if t0:
-                _trace("llm0.act", y), _trace("llm0.h_out", h)
+                _trace("llm0.act", y)
+            lin_bf16(y, Lw["wd"], tag="llm0.act" if t0 else None, resid=h, out=h, out_f32=True)
+            if t0:
+                _trace("llm0.h_out", h)
         if not dyn:
             cache.seq_len = past + L
         hn = ops.rmsnorm(h, w["norm"], self.eps, out=buf("llm_x", (M, T), BF16))

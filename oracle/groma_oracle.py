@@ -47,7 +47,7 @@ class rounding:
     """with rounding("bf16"): ...   -- evaluate the oracle with bf16-rounded operands (None = pure fp32)."""
 
     def __init__(self, mode):
-        assert mode in (None, "bf16")
+        assert mode in (None, "bf16", "e4m3")
         self.mode = mode
 
     def __enter__(self):
@@ -59,6 +59,44 @@ class rounding:
 
 def _r(x):
     return x if _ROUND[0] is None else x.to(torch.bfloat16).to(torch.float32)
+
+
+# "e4m3" mode (BASELINE configs[4]): everything of the bf16 mode, plus the DINOv2 / LLaMA linears evaluated with OCP e4m3
+# operands exactly as the device's fp8 path forms them (groma_amd/csrc/fp8.hip, groma_amd/weights.py q8):
+#   activations: per-ROW dynamic scale s = max(|x|, 1e-20) / 448, q = e4m3_rne(x * (1 / s))   (fp32 reciprocal, then multiply)
+#   weights:     per-OUTPUT-CHANNEL scale s = max(|w|, 1e-20) / 448, q = e4m3_rne(w / s)      (quantised once at load)
+#   product:     fp32 accumulation of the exact e4m3 products, then * w_scale[n] * a_scale[m], then the fp32 epilogue.
+# A normalisation output is quantised straight from fp32 (the fused norm -> e4m3 kernel); a stored activation (attention
+# context, GELU / SwiGLU output) is a bf16 tensor that is then row-quantised.  lm_head, bridge, patch embedding and the region
+# encoder keep bf16 operands in this mode (as on the device).
+E4M3 = torch.float8_e4m3fn
+
+
+def quant_rows_e4m3(x):
+    """-> (q as fp32 values on the e4m3 grid, scale [rows, 1]) with x ~= q * scale"""
+    s = x.abs().amax(dim=-1, keepdim=True).clamp_min(1e-20) / 448.0
+    return (x * (1.0 / s)).to(E4M3).to(torch.float32), s
+
+
+def quant_weight_e4m3(w):
+    s = w.abs().amax(dim=1).clamp_min(1e-20) / 448.0
+    return (w / s[:, None]).to(E4M3).to(torch.float32), s
+
+
+def _lin8(x, w, b=None):
+    """e4m3 GEMM of the device: x fp32 (already the tensor the quantiser sees) [.., K], w fp32 [N, K]"""
+    xq, sx = quant_rows_e4m3(x)
+    wq, sw = quant_weight_e4m3(w)
+    y = F.linear(xq, wq) * sw * sx
+    return y if b is None else y + b
+
+
+def _linA(x, sd, name, bias=True, src="act"):
+    """a DINOv2 / LLaMA linear: fp32 | bf16 operands | e4m3 operands, by the active mode.  src = "norm": x is a normalisation
+    output (quantised from fp32 in e4m3 mode); "act": x is a stored bf16 activation."""
+    if _ROUND[0] == "e4m3":
+        return _lin8(x if src == "norm" else _r(x), sd[name + ".weight"], sd.get(name + ".bias") if bias else None)
+    return _lin16(x, sd, name, bias)
 
 
 def _lin16(x, sd, name, bias=True):
@@ -164,13 +202,13 @@ def vit_forward(sd, cfg, images, prefix="perceiver.vis_encoder."):
     for i in range(vc["num_hidden_layers"]):
         p = f"{prefix}encoder.layer.{i}."
         y = _ln(x, sd, p + "norm1", eps)
-        q = _r(_lin16(y, sd, p + "attention.attention.query")).view(bs, -1, heads, hd).transpose(1, 2)
-        k = _r(_lin16(y, sd, p + "attention.attention.key")).view(bs, -1, heads, hd).transpose(1, 2)
-        v = _r(_lin16(y, sd, p + "attention.attention.value")).view(bs, -1, heads, hd).transpose(1, 2)
+        q = _r(_linA(y, sd, p + "attention.attention.query", src="norm")).view(bs, -1, heads, hd).transpose(1, 2)
+        k = _r(_linA(y, sd, p + "attention.attention.key", src="norm")).view(bs, -1, heads, hd).transpose(1, 2)
+        v = _r(_linA(y, sd, p + "attention.attention.value", src="norm")).view(bs, -1, heads, hd).transpose(1, 2)
         ctx = _softmax_pv(q @ k.transpose(-1, -2) / math.sqrt(hd), v).transpose(1, 2).reshape(bs, -1, D)
-        x = x + sd[p + "layer_scale1.lambda1"] * _lin16(ctx, sd, p + "attention.output.dense")
+        x = x + sd[p + "layer_scale1.lambda1"] * _linA(ctx, sd, p + "attention.output.dense")
         y = _ln(x, sd, p + "norm2", eps)
-        y = _lin16(F.gelu(_lin16(y, sd, p + "mlp.fc1")), sd, p + "mlp.fc2")
+        y = _linA(F.gelu(_linA(y, sd, p + "mlp.fc1", src="norm")), sd, p + "mlp.fc2")
         x = x + sd[p + "layer_scale2.lambda1"] * y
         hidden.append(x)
     return tuple(hidden)
@@ -514,9 +552,9 @@ def llama_forward(sd, cfg, inputs_embeds, attention_mask, past=None, prefix="llm
     for i in range(lc["num_hidden_layers"]):
         p = f"{prefix}layers.{i}."
         x = rms(h, sd[p + "input_layernorm.weight"])
-        q = _r(_lin16(x, sd, p + "self_attn.q_proj", False)).view(bs, L, H, hd).transpose(1, 2)
-        k = _r(_lin16(x, sd, p + "self_attn.k_proj", False)).view(bs, L, H, hd).transpose(1, 2)
-        v = _r(_lin16(x, sd, p + "self_attn.v_proj", False)).view(bs, L, H, hd).transpose(1, 2)
+        q = _r(_linA(x, sd, p + "self_attn.q_proj", False, src="norm")).view(bs, L, H, hd).transpose(1, 2)
+        k = _r(_linA(x, sd, p + "self_attn.k_proj", False, src="norm")).view(bs, L, H, hd).transpose(1, 2)
+        v = _r(_linA(x, sd, p + "self_attn.v_proj", False, src="norm")).view(bs, L, H, hd).transpose(1, 2)
         q = _r(q * cos + _rot_half(q) * sin)
         k = _r(k * cos + _rot_half(k) * sin)
         if past is not None:
@@ -526,10 +564,10 @@ def llama_forward(sd, cfg, inputs_embeds, attention_mask, past=None, prefix="llm
         att = q @ k.transpose(2, 3) / math.sqrt(hd) + mask
         att = torch.max(att, torch.tensor(fmin))
         y = _softmax_pv(att, v).transpose(1, 2).reshape(bs, L, D)
-        h = h + _lin16(y, sd, p + "self_attn.o_proj", False)
+        h = h + _linA(y, sd, p + "self_attn.o_proj", False)
         x = rms(h, sd[p + "post_attention_layernorm.weight"])
-        x = _lin16(F.silu(_lin16(x, sd, p + "mlp.gate_proj", False)) * _lin16(x, sd, p + "mlp.up_proj", False),
-                   sd, p + "mlp.down_proj", False)
+        x = _linA(F.silu(_linA(x, sd, p + "mlp.gate_proj", False, src="norm")) * _linA(x, sd, p + "mlp.up_proj", False, src="norm"),
+                  sd, p + "mlp.down_proj", False)
         h = h + x
         if layer_hook is not None:
             layer_hook(i, h)

@@ -1,9 +1,12 @@
-"""Groma-7B at its real DEPTH on the MI355X against the fp32 CPU oracle (tests/diag/fulldepth_parity.py: 24 ViT layers, 6+6
-DDETR, 5 fusion rounds, 100 regions, 32 LLaMA layers, logits for all 582 positions; per-layer weights of the deep stacks
-aliased to one materialised layer each so the host state is 3 GB).  ~35 s, most of it the oracle on the host cores.
-Measured (profiles/r02_fulldepth_parity.txt): ViT states 4.7e-3, region tokens 5.7e-3, logits 1.6e-2 relative L2 after 32
-layers of bf16 operands -- repeated application of the SAME layer compounds the rounding, so this is an upper bound for
-distinct layers -- with identical top-300 ids, NMS ids, spliced ids, and identical arg-max on every clear-margin position."""
+"""Groma-7B at its real DEPTH with DISTINCT per-layer weights on the MI355X against the CPU oracle, fp32 and bf16-rounded
+(tests/diag/fulldepth_parity.py: 24 ViT layers, 6+6 DDETR, 5 fusion rounds, 100 regions, 32 LLaMA layers, logits for all 582
+positions; every parameter drawn per name on the device and served to the oracle through a lazy state dict).  ~1.5 minutes,
+most of it the two oracle passes on the host cores.  R: groma/model/groma.py:202-427 end to end.
+
+Asserted: index-valued results identical (top-300 ids, NMS ids, spliced ids); the device is no further from the fp32 oracle
+than 1.5x what the bf16 format itself costs at this depth (bf16-rounded oracle <-> fp32 oracle), stage by stage; the
+bf16-rounded oracle is the closer reference; arg-max identical on every clear-margin position.
+Measured numbers: profiles/r03_fulldepth_distinct.txt."""
 import importlib.util
 import os
 
@@ -12,14 +15,19 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-def test_full_depth_forward_vs_fp32_oracle(dev):
+def test_full_depth_distinct_weights_vs_both_oracles(dev):
     here = os.path.dirname(os.path.abspath(__file__))
     spec = importlib.util.spec_from_file_location("fulldepth_parity", os.path.join(here, "diag", "fulldepth_parity.py"))
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     r = mod.run()
     assert r["topk_equal"] and r["nms_equal"] and r["ids_equal"] and r["L"] == 582
-    assert max(r["vit"]) < 1e-2                      # 24 layers deep (measured 4.8e-3)
-    assert r["image_tokens"] < 1e-2 and r["region_tokens"] < 1.5e-2
-    assert r["logits"] < 4e-2                        # 32 layers deep (measured 1.6e-2)
-    assert r["argmax_agree"] > 0.9 and r["argmax_agree_clear"] == 1.0
+    for name in ("image_tokens", "region_tokens", "k0", "k31", "logits", "region_logits"):
+        d32, d16, fmt = r[name]
+        assert d32 <= 1.5 * fmt, (name, r[name])      # no worse than the format's own distance (x1.5)
+        assert d16 <= d32 * 1.05, (name, r[name])     # and the bf16-rounded oracle is the closer one (or as close)
+    for d32, d16, fmt in r["vit"][1:]:
+        assert d32 <= 1.5 * fmt and d32 < 1e-2
+    assert r["logits"][0] < 4e-2                       # 32 layers deep (aliased-layer run of round 2: 1.6e-2)
+    assert r["argmax_agree_clear"] == 1.0
+    assert r["argmax_agree"] >= r["argmax_agree_bf16_oracle"] - 0.05
