@@ -23,6 +23,29 @@ def _ru(x, m):
     return (x + m - 1) // m * m
 
 
+def normal_mode(fn):
+    """Run an entry point of the boundary with autograd off and torch.inference_mode DISABLED, whatever the caller set.
+    The reference's callers wrap generate() in `with torch.inference_mode():` (groma/eval/eval_rec.py:92, run_groma.py:82,
+    serve/model_worker.py:256).  This path keeps persistent device state across calls -- workspace arenas, KV / decode arenas,
+    the device-resident loop counters of the captured decode graph -- and a tensor allocated under inference mode could never
+    be updated in place by a later call made outside it.  Inside, every tensor is an ordinary no-grad tensor; results handed
+    back are ordinary tensors too (usable inside or outside the caller's inference-mode block)."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapped(*a, **kw):
+        with torch.inference_mode(False), torch.no_grad():
+            return fn(*a, **kw)
+    return wrapped
+
+
+def inplace_copy(dst, src):
+    """dst.copy_(src) for a tensor the CALLER owns (the reference mutates its input_ids, groma.py:295,307): an inference
+    tensor may only be written under inference mode"""
+    with torch.inference_mode(dst.is_inference()):
+        dst.copy_(src)
+
+
 # Parity instrumentation: set engine.TRACE = {} and the next forward stores a copy of every intermediate that crosses a
 # kernel boundary in the FIRST layer of each stage (tests/test_fullwidth_parity_gpu.py feeds each kernel's actual input to
 # the oracle's version of that one operation).  None (the default) = no copies, no overhead.

@@ -184,6 +184,7 @@ class GromaModel:
         self.generation_config.pad_token_id = tokenizer.pad_token_id
         return
 
+    @engine.normal_mode
     def get_input_embeddings(self, input_ids):  # groma/model/groma.py:165-174
         bs, L = input_ids.shape
         return self.llm.embed(input_ids.to(self.device)).view(bs, L, -1)
@@ -203,6 +204,7 @@ class GromaModel:
         return model_inputs
 
     # ------------------------------------------------------------------ stages
+    @engine.normal_mode
     def perceive(self, images, refer_boxes=None, ground_boxes=None, debug=None):
         """Steps A-E (groma.py:218-280): ViT -> proposer -> NMS -> shuffle.  Returns (hidden4, selected_boxes list of
         device f32 [N_i,4], aux dict)."""
@@ -211,6 +213,7 @@ class GromaModel:
         selected, aux = self.propose(hidden4, refer_boxes, ground_boxes, debug)
         return hidden4, selected, aux
 
+    @engine.normal_mode
     def propose(self, hidden4, refer_boxes=None, ground_boxes=None, debug=None, seeds=None):
         """Steps C-E: DDETR proposer -> fused scores -> on-device NMS -> host randperm (one D2H of <1 KB/image)."""
         cfg = self.config
@@ -318,6 +321,7 @@ class GromaModel:
         return out, out.ne(self.pad_token_id)
 
     # ------------------------------------------------------------------ forward
+    @engine.normal_mode
     def forward(self, input_ids=None, inputs_embeds=None, labels=None, attention_mask=None, images=None,
                 refer_boxes=None, ground_boxes=None, past_key_values=None, use_cache=False, output_attentions=False,
                 output_hidden_states=False, return_dict=False, _last_logits_only=False, _reserve=0, _cache=None,
@@ -328,7 +332,7 @@ class GromaModel:
             raise NotImplementedError("output_attentions is not available from the fused attention kernel")
         dev = self.device
         vis_outputs = None
-        with torch.no_grad(), ops.gemm_plan(self.gemm_plan):
+        with ops.gemm_plan(self.gemm_plan):
             if past_key_values is None:
                 images = images.to(device=dev, dtype=F32).contiguous()
                 hidden4 = self.vit.forward(images)
@@ -348,6 +352,9 @@ class GromaModel:
                 main.wait_stream(side)
                 bs = len(selected_boxes)
                 ids_h = input_ids.cpu()
+                writeback = input_ids.is_cuda
+                if not input_ids.is_cuda and input_ids.is_inference():  # a CPU tensor the caller made under inference mode:
+                    ids_h, writeback = ids_h.clone(), True              # edit a copy, write it back under that mode
                 # replace <refer_box>/<ground_box> placeholders by matched <r_k> ids (groma.py:283-309), in place
                 refer_box_inds = []
                 need_boxes = any((self.refer_box_token_id in ids_h[i]) or (self.ground_box_token_id in ids_h[i]) for i in range(bs))
@@ -367,10 +374,11 @@ class GromaModel:
                         mask = ids_h[i] == self.ground_box_token_id
                         ids_h[i].masked_scatter_(mask, box_ids[matched])
                         if labels is not None:
-                            labels[i].masked_scatter_(mask.to(labels.device), box_ids[matched].to(labels.device))
+                            with torch.inference_mode(labels.is_inference()):
+                                labels[i].masked_scatter_(mask.to(labels.device), box_ids[matched].to(labels.device))
                 assert len(refer_box_inds) == bs
-                if input_ids.is_cuda and need_boxes:
-                    input_ids.copy_(ids_h)  # the reference mutates the caller's input_ids (groma.py:295,307)
+                if writeback and need_boxes:
+                    engine.inplace_copy(input_ids, ids_h)  # the reference mutates the caller's input_ids (groma.py:295,307)
                 # region tokens (groma.py:312-315)
                 n_reg = [b.shape[0] for b in selected_boxes]
                 boxes_cat = torch.cat(selected_boxes).contiguous()
@@ -503,6 +511,7 @@ class GromaModel:
         return GenerateOutput(sequences=seqs, hidden_states=hs, past_key_values=dec.cache)
 
     # ------------------------------------------------------------------ generate (HF 4.32 greedy_search semantics)
+    @engine.normal_mode
     def generate(self, *a, **kw):
         with ops.gemm_plan(self.gemm_plan):
             return self._generate(*a, **kw)

@@ -1,6 +1,9 @@
-"""Build oracle/_ref/libmmcv_ref.so from the reference's own CPU sources (TEST INFRASTRUCTURE ONLY).
-Recipe: g++ directly on four reference files + our shim; no reference build system, nothing copied.
-Usage: python oracle/build_ref.py /root/reference"""
+"""Build oracle/_ref/ from the reference's own sources where they lie (TEST INFRASTRUCTURE ONLY; outputs are git-ignored):
+  * libmmcv_ref.so  -- g++ directly on four reference CPU files (nms, roi_align) + our shim; no reference build system;
+  * eval_rec.pyc, eval_lvis.pyc -- the reference's evaluation scripts (groma/eval/eval_rec.py, eval_lvis.py) byte-compiled by
+    py_compile, so that tests/test_reference_eval_scripts_gpu.py can execute the reference's OWN eval_model() loop -- unchanged --
+    against groma_amd.GromaModel on the GPU box, where /root/reference does not exist.
+Nothing is copied into the repository.  Usage: python oracle/build_ref.py /root/reference"""
 import os
 import subprocess
 import sys
@@ -32,6 +35,15 @@ def main(ref):
     for o in objs + [shim_o]:
         os.remove(o)
     print(lib)
+    compile_eval_scripts(ref, out_dir)
+
+
+def compile_eval_scripts(ref, out_dir):
+    import py_compile
+    for name in ("eval_rec", "eval_lvis"):
+        src = os.path.join(ref, "groma", "eval", name + ".py")
+        if os.path.exists(src):
+            print(py_compile.compile(src, cfile=os.path.join(out_dir, name + ".pyc"), doraise=True))
 
 
 if __name__ == "__main__":

@@ -356,3 +356,39 @@ def test_generate_nine_rows_graph_equals_eager_and_survives_a_larger_prefill(set
     P = id9.shape[1]
     ncmp = util.assert_greedy_tokens_match(eager[:, P:], ref["sequences"][:, P:], ref["margins"], MIN_MARGIN, "9 rows")
     assert ncmp >= 6
+
+
+def test_calls_under_inference_mode_then_outside(setup):
+    """The reference's callers wrap generate() / forward() in torch.inference_mode() (R: groma/eval/eval_rec.py:92,
+    groma/eval/run_groma.py:82, groma/serve/model_worker.py:256).  Persistent device state (arenas, decode graph counters) must
+    stay usable when later calls come from OUTSIDE inference mode, results must be identical either way, and the in-place
+    <refer_box> rewrite of the caller's input_ids (R: groma/model/groma.py:295) must work on an inference tensor."""
+    cfg, sd, tk, model, images, ids = setup
+    from groma_amd import config as gconfig
+    from groma_amd.groma import GromaModel
+    m = util.device_model(cfg, sd)   # a fresh model: its first allocations happen under inference mode
+    m.generation_config.eos_token_id = None
+    with torch.inference_mode():
+        torch.manual_seed(9)
+        a = m.generate(ids.clone().cuda(), images=images.cuda(), max_new_tokens=5, return_dict_in_generate=True, output_hidden_states=True)
+        seq_a = a.sequences.clone()
+    torch.manual_seed(9)
+    b = m.generate(ids.clone().cuda(), images=images.cuda(), max_new_tokens=5, return_dict_in_generate=True, output_hidden_states=True)
+    assert torch.equal(seq_a.cpu(), b.sequences.cpu())
+    with torch.inference_mode():
+        torch.manual_seed(9)
+        c = m.generate(ids.clone().cuda(), images=images.cuda(), max_new_tokens=5)
+    assert torch.equal(c.cpu(), b.sequences.cpu())
+    # refer-box rewrite into the caller's (inference) input_ids
+    rid = ids[:1].clone()
+    rid[0, 40] = tk.refer_box_token_id
+    rb = [torch.tensor([[0.5, 0.5, 0.2, 0.2]])]
+    with torch.inference_mode():
+        dev_ids = rid.clone().cuda()
+        torch.manual_seed(3)
+        m.forward(input_ids=dev_ids, images=images[:1].cuda(), refer_boxes=rb, return_dict=True)
+        assert int(dev_ids[0, 40]) in tk.box_idx_token_ids
+        cpu_ids = rid.clone()
+        torch.manual_seed(3)
+        m.forward(input_ids=cpu_ids, images=images[:1], refer_boxes=rb, return_dict=True)
+        assert int(cpu_ids[0, 40]) == int(dev_ids[0, 40])
