@@ -124,7 +124,8 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16_kernel(GemmArgs p) {
   if (p.act == 3) ec4.load(p, n0 + (tid & 7) * 16);
   else if (!p.out_f32 && p.splits == 1) ec2.load(p, n0 + (tid & 15) * 8);
   else ec1.load(p, n0 + (tid & 31) * 4);
-  epi_dispatch<BN, NTHREADS, BM, false>(p, smem, tid, n0, z, ec4, ec2, ec1, [](int sr) { return sr; }, [&](int sr) { return m0 + sr; });
+  epi_dispatch<BN, NTHREADS, BM, false>(p, smem, tid, n0, z, ec4, ec2, ec1, [](int sr) { return sr; }, [&](int sr) { return m0 + sr; },
+                                        m0 + BM <= p.M && n0 + BN <= p.N && p.c_group == 0 && p.resid_mod == 0);
 }
 
 // split-K reduce + epilogue: one thread per 4 consecutive n

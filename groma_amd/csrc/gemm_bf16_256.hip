@@ -21,6 +21,8 @@
 //    of the DMA wait/issue.
 //  * LDS image: 128-B rows, 16-B chunk position = k-chunk ^ (row & 7): written lane-linearly by the DMA with the
 //    XOR applied to the per-lane SOURCE address, mirrored on the ds_read_b128 side (conflict-free).
+#include <type_traits>
+
 #include "gemm_common.h"
 
 #define T256 256
@@ -75,6 +77,52 @@ extern "C" int gr_diag_clk(unsigned long long* out) {
 #define PH_MARK(i)
 #define PH_FLUSH
 #endif
+
+// One tile's epilogue for ONE output mode (chosen once per tile, outside the passes): only that mode's per-thread column
+// constants are live while the accumulators still occupy half the register file.  With the mode dispatch INSIDE each pass all
+// three EpiCols sets stayed live across the passes and the allocator spilled address registers; every reload is a
+// scratch_load, i.e. a VMEM op the compiler must wait for with `s_waitcnt vmcnt(0)` -- which, vmcnt being one in-order
+// counter, also waited for the previous row's global store to COMPLETE (~850 clk each): the stores of a pass were serialised
+// (measured 3000-4800 clk per 64-row pass for 4 store instructions per wave).  q and FULL are compile-time, so accumulator
+// indices are constants and an interior tile's pass is a guard-free straight-line block.
+enum { EM_SPLITK = 0, EM_SWIGLU = 1, EM_BF16 = 2, EM_BF16_RESID = 3, EM_F32 = 4, EM_F32_RESID = 5 };
+template <int MODE>
+struct EpiModeCols {
+  static constexpr int W4 = MODE == EM_SWIGLU ? 4 : (MODE == EM_BF16 || MODE == EM_BF16_RESID) ? 2 : 1;
+};
+template <int MODE, bool FULL>
+__device__ __forceinline__ void epi_tile256(const GemmArgs& p, char* smem, f32x4 (&acc)[8][4], int tid, int wm, int wn, int fr,
+                                            int fg, int m0, int n0, int z) {
+  constexpr int W4 = EpiModeCols<MODE>::W4;
+  constexpr bool DEQ = G256_FP8 != 0;
+  constexpr int TPR = T256 / (4 * W4);        // threads per staged row
+  constexpr int NR = 64 * TPR / NT;           // staged rows per thread and pass
+  EpiCols<W4> ec;
+  if constexpr (MODE != EM_SPLITK) ec.load(p, n0 + (tid % TPR) * 4 * W4);
+  auto pass = [&](auto qc) {
+    constexpr int q = decltype(qc)::value;
+    char* buf = smem + (q & 1) * STAGE_BYTES;
+#pragma unroll
+    for (int e = 0; e < 2; ++e)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) stage_write4<T256>(buf, wm * 32 + e * 16 + fr, wn * 16 + j * 4 + fg, acc[2 * q + e][j]);
+    __syncthreads();
+    CLK_MARK(3 + 2 * q)
+    // staged row sr of this pass -> tile row (sr>>5)*128 + q*32 + (sr&31)
+    auto rm = [&](int it) { return it * (NT / TPR) + tid / TPR; };
+    auto mm = [&](int it) { const int sr = it * (NT / TPR) + tid / TPR; return m0 + (sr >> 5) * 128 + q * 32 + (sr & 31); };
+    const int c4 = (tid % TPR) * W4;
+    if constexpr (MODE == EM_SPLITK) epi_rows_splitk<T256, NR, FULL>(p, buf, c4, n0, z, rm, mm);
+    else if constexpr (MODE == EM_SWIGLU) epi_rows_swiglu<T256, NR, DEQ, FULL>(p, buf, c4, n0, ec, rm, mm);
+    else epi_rows<T256, W4, NR, (MODE == EM_F32 || MODE == EM_F32_RESID), (MODE == EM_BF16_RESID || MODE == EM_F32_RESID), DEQ, FULL>(
+        p, buf, c4, n0, ec, rm, mm);
+    CLK_MARK(4 + 2 * q)
+  };
+  pass(std::integral_constant<int, 0>{});
+  pass(std::integral_constant<int, 1>{});
+  pass(std::integral_constant<int, 2>{});
+  pass(std::integral_constant<int, 3>{});
+}
 
 __global__ __launch_bounds__(NT) void G256_KERNEL(GemmArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -277,26 +325,28 @@ __global__ __launch_bounds__(NT) void G256_KERNEL(GemmArgs p) {
   // ---- epilogue through LDS in 4 passes of 64 rows (2 m-tiles per wave), double-buffered over the two stages ----
   __syncthreads();
   CLK_MARK(1)
-  EpiCols<4> ec4;
-  EpiCols<2> ec2;
-  EpiCols<1> ec1;
-  if (p.act == 3) ec4.load(p, n0 + (tid & 15) * 16);
-  else if (!p.out_f32 && p.splits == 1) ec2.load(p, n0 + (tid & 31) * 8);
-  else ec1.load(p, n0 + (tid & 63) * 4);
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    char* buf = smem + (q & 1) * STAGE_BYTES;
-#pragma unroll
-    for (int e = 0; e < 2; ++e)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) stage_write4<T256>(buf, wm * 32 + e * 16 + fr, wn * 16 + j * 4 + fg, acc[2 * q + e][j]);
-    __syncthreads();
-    CLK_MARK(3 + 2 * q)
-    // staged row sr -> tile row (sr>>5)*128 + q*32 + (sr&31)
-    // staged row sr of this pass -> tile row (sr>>5)*128 + q*32 + (sr&31)
-    epi_dispatch<T256, NT, 64, (G256_FP8 != 0)>(p, buf, tid, n0, z, ec4, ec2, ec1, [](int sr) { return sr; },
-                               [&](int sr) { return m0 + (sr >> 5) * 128 + q * 32 + (sr & 31); });
-    CLK_MARK(4 + 2 * q)
+  {
+    // tile-uniform: interior tile of a plain row-major output -> guard-free, division-free straight-line passes
+    const bool full = m0 + T256 <= p.M && n0 + T256 <= p.N && p.c_group == 0 && p.resid_mod == 0;
+#define EPI_GO(MODE)                                                                                          \
+  do {                                                                                                        \
+    if (full) epi_tile256<MODE, true>(p, smem, acc, tid, wm, wn, fr, fg, m0, n0, z);                          \
+    else {                                                                                                    \
+      epi_tile256<MODE, false>(p, smem, acc, tid, wm, wn, fr, fg, m0, n0, z);                                 \
+      __builtin_amdgcn_s_waitcnt(0x0F70); /* vmcnt(0): see below */                                           \
+    }                                                                                                         \
+  } while (0)
+    if (p.splits > 1) EPI_GO(EM_SPLITK);
+    else if (p.act == 3) EPI_GO(EM_SWIGLU);
+    else if (!p.out_f32) { if (p.resid) EPI_GO(EM_BF16_RESID); else EPI_GO(EM_BF16); }
+    else { if (p.resid) EPI_GO(EM_F32_RESID); else EPI_GO(EM_F32); }
+#undef EPI_GO
+    // The vmcnt(0) after an EDGE tile's guarded epilogue is for the compiler's wait-count pass: its guarded loads (residual
+    // rows under `m < M`) leave "maybe pending" VGPR writes on some paths, the pass carries that state around the
+    // persistent-loop back-edge into the K loop's header and puts an `s_waitcnt vmcnt(0)` THERE -- inside the K loop, in
+    // front of the fragment reads, draining the LDS-DMA queue on every K-tile of every tile (seen in the ISA: +11 % K-tile
+    // time).  An interior tile's straight-line epilogue consumes every load it issues, so it needs no such wait and its
+    // stores keep draining under the next tile's first DMAs.
   }
   }  // persistent tile loop
   CLK_MARK(2)

@@ -236,12 +236,20 @@ __device__ __forceinline__ void epi_from_stage(const GemmArgs& p, const char* ba
 #else
 #define EPI_ST(ptr, val) (*(ptr) = (val))
 #endif
-template <int COLS, int W4, int NIT, bool F32OUT, bool RESID, bool DEQ, class SR, class MR>
+// FULL = the tile lies entirely inside M x N and the launch uses neither the output-row remap (c_group) nor the residual-row
+// broadcast (resid_mod) -- tile-uniform, decided once per tile: every row / column guard and the integer divisions of the
+// remaps disappear at compile time, row addresses are base + constant * ld, and a pass is ONE straight-line block.  That is what lets the compiler count its waits: vmcnt
+// is an in-order counter shared by loads and stores, and with a data-dependent `if (m >= M) continue;` between the loads
+// at the top and their uses, hipcc's wait insertion merges the branch states conservatively and emits `s_waitcnt vmcnt(0)`
+// in front of every row -- each 16-B store then had to COMPLETE (~850 clk round trip) before the next row's LDS read was
+// consumed: 4 rows x ~850 clk = the "3300 clk per 64-row pass" of round 1/2, 8.5 us per 256x256 tile (found in the ISA in
+// round 3; the round-2 comment that the waits were gone was wrong for every tile but none).  Edge tiles keep the guards.
+template <int COLS, int W4, int NIT, bool F32OUT, bool RESID, bool DEQ, bool FULL, class SR, class MR>
 __device__ __forceinline__ void epi_rows(const GemmArgs& p, const char* base, int c4, int n0, const EpiCols<W4>& ec, SR rm, MR mm) {
   const int n = n0 + c4 * 4;
   constexpr int NB = RESID ? (DEQ ? 1 : (NIT < 4 ? NIT : 4)) : (DEQ ? 1 : NIT);  // rows per load batch (register budget; the fp8 build is at the 256-VGPR limit)
-  auto out_row = [&](int m) -> long {
-    return p.c_group > 0 ? (long)(m / p.c_group) * p.c_group_stride + p.c_row_off + (m % p.c_group) : (long)m;
+  auto out_row = [&](int m) -> long {  // FULL also means: no output-row remap, no residual-row broadcast (plain row-major tile)
+    return (!FULL && p.c_group > 0) ? (long)(m / p.c_group) * p.c_group_stride + p.c_row_off + (m % p.c_group) : (long)m;
   };
 #pragma unroll
   for (int b0 = 0; b0 < NIT; b0 += NB) {
@@ -251,24 +259,24 @@ __device__ __forceinline__ void epi_rows(const GemmArgs& p, const char* base, in
 #pragma unroll
       for (int i = 0; i < NB; ++i) {
         const int m = mm(b0 + i);
-        as[DEQ ? i : 0] = (p.a_scale && m < p.M) ? p.a_scale[m] : 1.f;
+        as[DEQ ? i : 0] = (p.a_scale && (FULL || m < p.M)) ? p.a_scale[m] : 1.f;
       }
     }
     if (RESID) {
 #pragma unroll
       for (int i = 0; i < NB; ++i) {
         const int m = mm(b0 + i);
-        const long rrow = p.resid_mod > 0 ? (long)(m % p.resid_mod) : out_row(m);
+        const long rrow = (!FULL && p.resid_mod > 0) ? (long)(m % p.resid_mod) : out_row(m);
 #pragma unroll
         for (int w = 0; w < W4; ++w)
-          r[RESID ? i : 0][w] = (m < p.M && n + 4 * w < p.N) ? *(const f32x4*)(p.resid + rrow * p.ldr + n + 4 * w)
-                                                            : (f32x4){0.f, 0.f, 0.f, 0.f};
+          r[RESID ? i : 0][w] = (FULL || (m < p.M && n + 4 * w < p.N)) ? *(const f32x4*)(p.resid + rrow * p.ldr + n + 4 * w)
+                                                                      : (f32x4){0.f, 0.f, 0.f, 0.f};
       }
     }
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
       const int m = mm(b0 + i);
-      if (m >= p.M) continue;
+      if (!FULL && m >= p.M) continue;
       const long orow = out_row(m);
       f32x4 v[W4];
 #pragma unroll
@@ -276,9 +284,12 @@ __device__ __forceinline__ void epi_rows(const GemmArgs& p, const char* base, in
         v[w] = stage_read4<COLS>(base, rm(b0 + i), c4 + w);
         if (DEQ) v[w] = v[w] * ec.wsc[w] * as[DEQ ? i : 0];
         v[w] += ec.bias[w];
-        if (p.act == 1 || p.act == 2) {
+        if (p.act == 1) {  // (one uniform branch per vector, not one per element)
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[w][e] = act_apply(v[w][e], p.act);
+          for (int e = 0; e < 4; ++e) v[w][e] = gelu_erf(v[w][e]);
+        } else if (p.act == 2) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[w][e] = fmaxf(v[w][e], 0.f);
         }
         v[w] *= ec.scale[w];
         if (RESID) v[w] += r[RESID ? i : 0][w];
@@ -286,10 +297,10 @@ __device__ __forceinline__ void epi_rows(const GemmArgs& p, const char* base, in
       if (F32OUT) {
 #pragma unroll
         for (int w = 0; w < W4; ++w)
-          if (n + 4 * w < p.N) EPI_ST((f32x4*)((float*)p.C + orow * p.ldc + n + 4 * w), v[w]);
+          if (FULL || n + 4 * w < p.N) EPI_ST((f32x4*)((float*)p.C + orow * p.ldc + n + 4 * w), v[w]);
       } else {
         bf16_t* dst = (bf16_t*)p.C + orow * p.ldc + n;
-        if (W4 == 2 && n + 8 <= p.N && (p.ldc & 7) == 0) {
+        if (W4 == 2 && (FULL || n + 8 <= p.N) && (p.ldc & 7) == 0) {
           typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
           const u32x4 pk4 = {pack2bf(v[0][0], v[0][1]), pack2bf(v[0][2], v[0][3]), pack2bf(v[W4 - 1][0], v[W4 - 1][1]),
                              pack2bf(v[W4 - 1][2], v[W4 - 1][3])};
@@ -309,7 +320,7 @@ __device__ __forceinline__ void epi_rows(const GemmArgs& p, const char* base, in
   }
 }
 // SwiGLU over interleaved (gate, up) columns: 16 fused columns -> 8 bf16 outputs per thread-row; no loads
-template <int COLS, int NIT, bool DEQ, class SR, class MR>
+template <int COLS, int NIT, bool DEQ, bool FULL, class SR, class MR>
 __device__ __forceinline__ void epi_rows_swiglu(const GemmArgs& p, const char* base, int c4, int n0, const EpiCols<4>& ec, SR rm, MR mm) {
   const int n = n0 + c4 * 4;
   float as[DEQ ? NIT : 1];
@@ -317,15 +328,15 @@ __device__ __forceinline__ void epi_rows_swiglu(const GemmArgs& p, const char* b
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
       const int m = mm(it);
-      as[DEQ ? it : 0] = (p.a_scale && m < p.M) ? p.a_scale[m] : 1.f;
+      as[DEQ ? it : 0] = (p.a_scale && (FULL || m < p.M)) ? p.a_scale[m] : 1.f;
     }
   }
 #pragma unroll
   for (int it = 0; it < NIT; ++it) {
     const int m = mm(it);
-    if (m >= p.M) continue;
+    if (!FULL && m >= p.M) continue;
     long orow = m;
-    if (p.c_group > 0) orow = (long)(m / p.c_group) * p.c_group_stride + p.c_row_off + (m % p.c_group);
+    if (!FULL && p.c_group > 0) orow = (long)(m / p.c_group) * p.c_group_stride + p.c_row_off + (m % p.c_group);
     uint32_t o[4];
 #pragma unroll
     for (int w = 0; w < 4; ++w) {
@@ -335,7 +346,7 @@ __device__ __forceinline__ void epi_rows_swiglu(const GemmArgs& p, const char* b
       o[w] = pack2bf(silu_f(x[0]) * x[1], silu_f(x[2]) * x[3]);
     }
     bf16_t* dst = (bf16_t*)p.C + orow * p.ldc + (n >> 1);
-    if (n + 16 <= p.N && (p.ldc & 7) == 0) {
+    if ((FULL || n + 16 <= p.N) && (p.ldc & 7) == 0) {
       *(uint4*)dst = make_uint4(o[0], o[1], o[2], o[3]);
     } else {
 #pragma unroll
@@ -345,38 +356,45 @@ __device__ __forceinline__ void epi_rows_swiglu(const GemmArgs& p, const char* b
   }
 }
 // split-K partial tile -> workspace [z, M, N] f32 (raw accumulators; the reduce kernel applies the epilogue)
-template <int COLS, int NIT, class SR, class MR>
+template <int COLS, int NIT, bool FULL, class SR, class MR>
 __device__ __forceinline__ void epi_rows_splitk(const GemmArgs& p, const char* base, int c4, int n0, int z, SR rm, MR mm) {
   const int n = n0 + c4 * 4;
 #pragma unroll
   for (int it = 0; it < NIT; ++it) {
     const int m = mm(it);
-    if (m < p.M && n < p.N) *(f32x4*)(p.ws + ((long)z * p.M + m) * p.N + n) = stage_read4<COLS>(base, rm(it), c4);
+    if (FULL || (m < p.M && n < p.N)) *(f32x4*)(p.ws + ((long)z * p.M + m) * p.N + n) = stage_read4<COLS>(base, rm(it), c4);
   }
 }
 // mode dispatch shared by both tile kernels: TPR1/2/4 = threads per staged row for 4/8/16 columns per thread
-template <int COLS, int NTH, int ROWS, bool DEQ, class SR, class MR>
-__device__ __forceinline__ void epi_dispatch(const GemmArgs& p, const char* base, int tid, int n0, int z, const EpiCols<4>& ec4,
-                                             const EpiCols<2>& ec2, const EpiCols<1>& ec1, SR rm, MR mm) {
+template <int COLS, int NTH, int ROWS, bool DEQ, bool FULL, class SR, class MR>
+__device__ __forceinline__ void epi_dispatch_t(const GemmArgs& p, const char* base, int tid, int n0, int z, const EpiCols<4>& ec4,
+                                               const EpiCols<2>& ec2, const EpiCols<1>& ec1, SR rm, MR mm) {
   constexpr int T4 = COLS / 16, T2 = COLS / 8, T1 = COLS / 4;          // threads per row
   constexpr int N4 = ROWS * T4 / NTH, N2 = ROWS * T2 / NTH, N1 = ROWS * T1 / NTH;  // rows per thread
   if (p.splits > 1) {
-    epi_rows_splitk<COLS, N1>(p, base, tid % T1, n0, z, [&](int it) { return rm(it * (NTH / T1) + tid / T1); },
-                              [&](int it) { return mm(it * (NTH / T1) + tid / T1); });
+    epi_rows_splitk<COLS, N1, FULL>(p, base, tid % T1, n0, z, [&](int it) { return rm(it * (NTH / T1) + tid / T1); },
+                                    [&](int it) { return mm(it * (NTH / T1) + tid / T1); });
   } else if (p.act == 3) {
-    epi_rows_swiglu<COLS, N4, DEQ>(p, base, (tid % T4) * 4, n0, ec4, [&](int it) { return rm(it * (NTH / T4) + tid / T4); },
-                              [&](int it) { return mm(it * (NTH / T4) + tid / T4); });
+    epi_rows_swiglu<COLS, N4, DEQ, FULL>(p, base, (tid % T4) * 4, n0, ec4, [&](int it) { return rm(it * (NTH / T4) + tid / T4); },
+                                         [&](int it) { return mm(it * (NTH / T4) + tid / T4); });
   } else if (!p.out_f32) {
     auto r = [&](int it) { return rm(it * (NTH / T2) + tid / T2); };
     auto m = [&](int it) { return mm(it * (NTH / T2) + tid / T2); };
-    if (p.resid) epi_rows<COLS, 2, N2, false, true, DEQ>(p, base, (tid % T2) * 2, n0, ec2, r, m);
-    else epi_rows<COLS, 2, N2, false, false, DEQ>(p, base, (tid % T2) * 2, n0, ec2, r, m);
+    if (p.resid) epi_rows<COLS, 2, N2, false, true, DEQ, FULL>(p, base, (tid % T2) * 2, n0, ec2, r, m);
+    else epi_rows<COLS, 2, N2, false, false, DEQ, FULL>(p, base, (tid % T2) * 2, n0, ec2, r, m);
   } else {
     auto r = [&](int it) { return rm(it * (NTH / T1) + tid / T1); };
     auto m = [&](int it) { return mm(it * (NTH / T1) + tid / T1); };
-    if (p.resid) epi_rows<COLS, 1, N1, true, true, DEQ>(p, base, tid % T1, n0, ec1, r, m);
-    else epi_rows<COLS, 1, N1, true, false, DEQ>(p, base, tid % T1, n0, ec1, r, m);
+    if (p.resid) epi_rows<COLS, 1, N1, true, true, DEQ, FULL>(p, base, tid % T1, n0, ec1, r, m);
+    else epi_rows<COLS, 1, N1, true, false, DEQ, FULL>(p, base, tid % T1, n0, ec1, r, m);
   }
+}
+// `full` must be tile-uniform: the tile's rows [m0, m0 + tile) and columns [n0, n0 + tile) all lie inside M x N
+template <int COLS, int NTH, int ROWS, bool DEQ, class SR, class MR>
+__device__ __forceinline__ void epi_dispatch(const GemmArgs& p, const char* base, int tid, int n0, int z, const EpiCols<4>& ec4,
+                                             const EpiCols<2>& ec2, const EpiCols<1>& ec1, SR rm, MR mm, bool full) {
+  if (full) epi_dispatch_t<COLS, NTH, ROWS, DEQ, true>(p, base, tid, n0, z, ec4, ec2, ec1, rm, mm);
+  else epi_dispatch_t<COLS, NTH, ROWS, DEQ, false>(p, base, tid, n0, z, ec4, ec2, ec1, rm, mm);
 }
 
 // skinny M<=8 streaming kernel (gemv_bf16.hip): requires p.splits == ceil(K/512) and p.ws

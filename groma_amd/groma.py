@@ -251,27 +251,50 @@ class GromaModel:
                 n_valid = torch.tensor([Q + e for e in n_extra], dtype=I32, device=dev)
             keep, n_keep = ops.nms(boxes_all, scores_all, float(cfg.nms_thres), float(cfg.box_score_thres),
                                    int(cfg.max_region_num), n_valid=n_valid)
-        # one host round trip: kept indices + scores arg-max fallback (the reference syncs at nms / len / randperm too)
-        keep_h, n_keep_h = keep.cpu(), n_keep.cpu()
-        selected, sel_idx = [], []
-        for i in range(bs):
-            nk = int(n_keep_h[i])
+        # ONE host round trip: kept indices + counts in one D2H copy (the reference syncs at nms / len / randperm too), the
+        # CPU-RNG shuffles (T4), then ONE pinned H2D copy of the flat selection and ONE device gather -- the per-image
+        # index_select / .to(device) sequence this replaces cost ~1.2 ms of idle GPU per forward in pageable synchronous copies
+        kk_h = torch.cat([keep, n_keep.to(I64)[:, None]], dim=1).cpu()
+        keep_h, n_keep_l = kk_h[:, :-1], kk_h[:, -1].tolist()
+        nmax = boxes_all.shape[1]
+        sel_idx = []
+        for i, nk in enumerate(n_keep_l):   # (a handful of host ops per image: this loop sits between the sync and the next launch)
             if nk > 0:  # groma.py:273-276 -- torch.randperm on the CPU global RNG (T4)
-                inds = keep_h[i, :nk]
                 if seeds is not None and seeds[i] is not None:
                     # serving: each request owns its shuffle seed.  A local generator yields exactly what the global RNG
                     # would after torch.manual_seed(seed), without reseeding the process-wide CPU / device generators
-                    inds = inds[torch.randperm(nk, generator=torch.Generator().manual_seed(int(seeds[i])))]
+                    perm = torch.randperm(nk, generator=torch.Generator().manual_seed(int(seeds[i])))
                 else:
-                    inds = inds[torch.randperm(nk)]
+                    perm = torch.randperm(nk)
+                inds = keep_h[i].index_select(0, perm)   # perm < nk: only kept entries are read
             else:       # groma.py:277-279
                 nv = Q + n_extra[i]
                 inds = torch.max(scores_all[i, :nv], dim=0).indices.reshape(1).cpu()
             sel_idx.append(inds)
-            selected.append(boxes_all[i].index_select(0, inds.to(dev)))
+        n_sel = [int(x.numel()) for x in sel_idx]
+        R = sum(n_sel)
+        stage = self._pinned("sel", 2 * R)
+        counts = torch.tensor(n_sel)
+        img_of = torch.repeat_interleave(torch.arange(bs), counts)
+        torch.add(torch.cat(sel_idx), img_of, alpha=nmax, out=stage[:R])
+        stage[R:2 * R] = img_of
+        sel_dev = stage[:2 * R].to(dev, non_blocking=True)
+        boxes_cat = boxes_all.reshape(bs * nmax, 4).index_select(0, sel_dev[:R])   # [R, 4], image-major
+        selected = list(boxes_cat.split(n_sel))
+        n_keep_h = n_keep_l
         aux = dict(pred_boxes=pred_boxes, scores=scores, topk_idx=topk_idx, nms_keep=[keep_h[i, :int(n_keep_h[i])] for i in range(bs)],
-                   sel_idx=sel_idx)
+                   sel_idx=sel_idx, boxes_cat=boxes_cat, img_idx=sel_dev[R:].to(F32))
         return selected, aux
+
+    def _pinned(self, name, n):
+        """a reusable page-locked int64 staging buffer (H2D copies from it are asynchronous on the stream).  One buffer per
+        use site: a site's previous copy has always completed by the time the site is reached again (every forward syncs on
+        the NMS result in between)"""
+        pool = self.__dict__.setdefault("_pin", {})
+        t = pool.get(name)
+        if t is None or t.numel() < n:
+            t = pool[name] = torch.empty((max(n, 1024),), dtype=I64).pin_memory()
+        return t
 
     def _propose_graph(self, hidden4):
         """Replay (capturing on first use) the hipGraph of the proposer chain + NMS for these input buffers.  The graph
@@ -381,21 +404,25 @@ class GromaModel:
                     engine.inplace_copy(input_ids, ids_h)  # the reference mutates the caller's input_ids (groma.py:295,307)
                 # region tokens (groma.py:312-315)
                 n_reg = [b.shape[0] for b in selected_boxes]
-                boxes_cat = torch.cat(selected_boxes).contiguous()
-                img_idx = torch.cat([torch.full((n,), float(i)) for i, n in enumerate(n_reg)]).to(dev)
-                region_features = self.region.extract(feats, S, boxes_cat, img_idx)  # f32 [R, T]
+                region_features = self.region.extract(feats, S, aux["boxes_cat"], aux["img_idx"])  # f32 [R, T]
                 n_img_tok = (self.vit.G // 2) ** 2  # image tokens: groma.py:224-237, :361 (computed on the side stream)
                 # splice placeholders, embed, inject (groma.py:317-369)
                 new_ids_h, mask_h = self._splice(ids_h, n_img_tok, n_reg)
                 if labels is not None:
                     labels = self._splice_labels(ids_h, labels.cpu(), n_img_tok, n_reg)
                 L = new_ids_h.shape[1]
-                new_ids = new_ids_h.to(dev)
-                emb = self.llm.embed(new_ids)  # f32 [bs*L, T]
                 flat = new_ids_h.reshape(-1)
-                img_rows = (flat == self.img_token_id).nonzero(as_tuple=True)[0].to(I32).to(dev)
-                reg_rows = (flat == self.reg_token_id).nonzero(as_tuple=True)[0].to(I32).to(dev)
-                assert img_rows.numel() == image_features.shape[0] and reg_rows.numel() == region_features.shape[0]
+                img_rows_h = (flat == self.img_token_id).nonzero(as_tuple=True)[0]
+                reg_rows_h = (flat == self.reg_token_id).nonzero(as_tuple=True)[0]
+                assert img_rows_h.numel() == image_features.shape[0] and reg_rows_h.numel() == region_features.shape[0]
+                # spliced ids + the two scatter-row lists in ONE pinned, asynchronous H2D copy
+                n0, n1, n2 = flat.numel(), img_rows_h.numel(), reg_rows_h.numel()
+                stage = self._pinned("ids", n0 + n1 + n2)
+                stage[:n0], stage[n0:n0 + n1], stage[n0 + n1:n0 + n1 + n2] = flat, img_rows_h, reg_rows_h
+                ids_dev = stage[:n0 + n1 + n2].to(dev, non_blocking=True)
+                new_ids = ids_dev[:n0].view(bs, L)
+                emb = self.llm.embed(new_ids)  # f32 [bs*L, T]
+                img_rows, reg_rows = ids_dev[n0:n0 + n1].to(I32), ids_dev[n0 + n1:].to(I32)
                 ops.scatter_rows(image_features, img_rows, emb)
                 ops.scatter_rows(region_features, reg_rows, emb)
                 ref_rows = (flat == self.refer_feat_token_id).nonzero(as_tuple=True)[0]
@@ -407,7 +434,6 @@ class GromaModel:
                                         if len(ind) > 0])
                     ops.scatter_rows(region_features.index_select(0, gather.to(dev)).contiguous(),
                                      ref_rows.to(I32).to(dev), emb)
-                attention_mask = mask_h.to(dev)
                 kv_len = mask_h.sum(-1).to(I32).to(dev) if not bool(mask_h.all()) else None
                 if _cache is not None:  # generate(): prefill straight into the decode arena the captured graph reads
                     cache = _cache
@@ -435,8 +461,7 @@ class GromaModel:
                     emb = self.llm.embed(input_ids[:, -1:].to(dev))
                 else:
                     emb = inputs_embeds.to(dev, F32).reshape(bs * L, -1).contiguous()
-                kv_len = None  # the reference rebuilds an all-ones mask over past+1 (groma.py:376-379, T6)
-                attention_mask = torch.ones((bs, cache.seq_len + L), device=dev)
+                kv_len = None  # the reference rebuilds an all-ones mask over past+1 (groma.py:376-379, T6): every cached key is visible
             logits, hn = self.llm.forward(emb, bs, L, cache, kv_len=kv_len, all_logits=not _last_logits_only)
 
         loss = None

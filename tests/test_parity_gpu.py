@@ -25,6 +25,23 @@ def setup(dev):
     return cfg, sd, tk, model, images, ids
 
 
+@pytest.fixture(scope="module")
+def gen_setup(dev):
+    """the same tiny model with the <r_k> rows of extra_lm_head boosted: every greedy step then has a top-2 margin far outside
+    the bf16 error band, so the token-by-token comparisons below are never decided by a near-tie (with plain random-init
+    weights several steps have margins of ~5e-3 -- inside the band -- and which side of the tie the device lands on changes
+    with any re-ordering of an fp32 sum)"""
+    cfg, sd, tk = util.tiny_setup(seed=0)
+    sd = dict(sd)
+    w = sd["extra_lm_head.weight"].clone()
+    w[w.shape[0] - 100:] *= 40.0
+    sd["extra_lm_head.weight"] = w
+    model = util.device_model(cfg, sd)
+    from groma_amd import synth
+    images, ids = synth.make_inputs(cfg, tk, bs=2, seed=1234)
+    return cfg, sd, tk, model, images, ids
+
+
 def test_vit_hidden_states(setup):
     cfg, sd, tk, model, images, ids = setup
     dev_h = model.vit.forward(images.cuda())
@@ -140,8 +157,9 @@ def _oracle_generate(setup, ids, images, n, seed, eos):
 
 
 @pytest.mark.parametrize("graph", [True, False])
-def test_generate_matches_oracle_greedy(setup, graph):
+def test_generate_matches_oracle_greedy(gen_setup, graph):
     """EVERY generated token against HF-greedy over the oracle (R: groma/eval/eval_rec.py:93-104), not just the first."""
+    setup = gen_setup
     cfg, sd, tk, model, images, ids = setup
     n = 6
     gc = model.generation_config
@@ -164,13 +182,14 @@ def test_generate_matches_oracle_greedy(setup, graph):
     ncmp = util.assert_greedy_tokens_match(g.sequences[:, P:].cpu(), ref["sequences"][:, P:], ref["margins"], MIN_MARGIN, "generate")
     print("generated", g.sequences[:, P:].tolist(), "oracle", ref["sequences"][:, P:].tolist(), "compared", ncmp,
           "margins", ref["margins"].tolist())
-    assert ncmp >= n  # at least one full row's worth of tokens was resolvable
+    assert ncmp >= n  # at least one full row's worth of tokens was resolvable (all 16 are at Groma-7B width: test_width_generate_gpu.py)
 
 
-def test_generate_ragged_right_padded_batch_matches_oracle(setup):
+def test_generate_ragged_right_padded_batch_matches_oracle(gen_setup):
     """HF greedy over a RIGHT-padded batch takes the arg-max of the last (pad) position of the shorter row and
     decodes every row at the same position with an all-ones mask (R: groma/model/groma.py:376-379).  Reproduced, not
     fixed: the device tokens must equal the oracle's on the padded row too."""
+    setup = gen_setup
     cfg, sd, tk, model, images, ids = setup
     ids = ids.clone()
     ids[1, -9:] = tk.pad_token_id
@@ -188,11 +207,12 @@ def test_generate_ragged_right_padded_batch_matches_oracle(setup):
     P = ids.shape[1]
     ncmp = util.assert_greedy_tokens_match(g.sequences[:, P:].cpu(), ref["sequences"][:, P:], ref["margins"], MIN_MARGIN, "ragged")
     print("ragged generated", g.sequences[:, P:].tolist(), "oracle", ref["sequences"][:, P:].tolist(), "compared", ncmp)
-    assert ncmp >= 2
+    assert ncmp >= n
 
 
-def test_generate_eos_padding_matches_oracle(setup):
+def test_generate_eos_padding_matches_oracle(gen_setup):
     """finished rows emit pad, the loop stops when every row is finished (HF greedy_search bookkeeping)"""
+    setup = gen_setup
     cfg, sd, tk, model, images, ids = setup
     gc = model.generation_config
     old = (gc.eos_token_id, getattr(gc, "pad_token_id", None))
@@ -320,11 +340,12 @@ def test_forward_with_hundreds_of_refer_boxes(setup):
     assert util.relerr(out.logits, ref["logits"]) < 2e-2
 
 
-def test_generate_nine_rows_graph_equals_eager_and_survives_a_larger_prefill(setup):
+def test_generate_nine_rows_graph_equals_eager_and_survives_a_larger_prefill(gen_setup):
     """More than 8 rows leave the weight-streaming decode kernels (gemv_bf16: M <= 8) for the general GEMM path.  The captured
     step must then (a) hand its logits to the sampler (round-2 regression: the sampler read a buffer only the M <= 8 path
     wrote, so every token after the first was id 0) and (b) keep addressing live memory after a LARGER prefill regrew the
     shared scratch arenas between two generate() calls."""
+    setup = gen_setup
     cfg, sd, tk, model, images, ids = setup
     from groma_amd import synth
     im9, id9 = synth.make_inputs(cfg, tk, bs=9, seed=4321)
@@ -355,7 +376,7 @@ def test_generate_nine_rows_graph_equals_eager_and_survives_a_larger_prefill(set
     ref = O.greedy_generate(sd, cfg.to_dict(), util.tok_dict(tk), id9.clone(), im9, 6, eos_token_id=-1, hidden_states=tuple(dev_h))
     P = id9.shape[1]
     ncmp = util.assert_greedy_tokens_match(eager[:, P:], ref["sequences"][:, P:], ref["margins"], MIN_MARGIN, "9 rows")
-    assert ncmp >= 6
+    assert ncmp >= 9 * 6 - 6
 
 
 def test_calls_under_inference_mode_then_outside(setup):
