@@ -45,7 +45,7 @@ struct AttnArgs {
 #ifdef G256_CLK  // diagnostic build (tests/diag/build_clk.py): per-iteration segment clocks of block 0 / wave 0
 __device__ unsigned long long att_clk[64];
 extern "C" int gr_diag_att_clk(unsigned long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(att_clk), sizeof(att_clk)); }
-#define ATT_MARK(i) if (blockIdx.x == gridDim.x - 1 && blockIdx.y == 0 && t >= 2 && t < 6) am[(t - 2) * 5 + (i)] = __builtin_readcyclecounter();
+#define ATT_MARK(i) if (blockIdx.y == 0 && blockIdx.x == 0 && t >= 2 && t < 6) am[(t - 2) * 5 + (i)] = __builtin_readcyclecounter();
 #else
 #define ATT_MARK(i)
 #endif
@@ -74,9 +74,14 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(AttnArgs p) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int fr = lane & 15, fg = lane >> 4;
-  const int bh = blockIdx.y;
+  // Block order: (batch, head) fastest, query block slowest and -- when causal -- the block with the most visible keys
+  // first, so the long blocks start in the first wave of workgroups and the short ones fill the tail of the launch
+  // (A/B on one box, tests/diag/attn_bench.py: L = 582 causal 14 x 32 heads 97.5 -> 96 us, 4 x 32 heads 34.1 -> 26.5 us;
+  // longest-first INSIDE a (batch, head) with the query block fastest was neutral-to-worse)
+  const int bh = blockIdx.x;
+  const int qb = p.causal ? (int)(gridDim.y - 1 - blockIdx.y) : (int)blockIdx.y;
   const int b = bh / p.H, h = bh - b * p.H;
-  const int q0 = blockIdx.x * (64 * QT);
+  const int q0 = qb * (64 * QT);
 
   const bf16_t* Qp = p.q_ld > 0 ? p.q + (long)b * p.Lq * p.q_ld + h * HD : p.q + (long)bh * p.Lq * HD;
   const long q_rs = p.q_ld > 0 ? p.q_ld : HD;  // row stride
@@ -305,7 +310,7 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(AttnArgs p) {
     ATT_MARK(4)
   }
 #ifdef G256_CLK
-  if (threadIdx.x == 0 && blockIdx.x == gridDim.x - 1 && blockIdx.y == 0 && HD == 128)
+  if (threadIdx.x == 0 && blockIdx.y == 0 && blockIdx.x == 0 && HD == 128)
     for (int i = 0; i < 20; ++i) att_clk[i] = am[i];
 #endif
 
@@ -341,7 +346,7 @@ extern "C" int gr_attention_bf16(const void* q, const void* k, const void* vt, v
   p.B = B; p.H = H; p.Lq = Lq; p.Skv = Skv; p.kv_stride = kv_stride;
   p.causal = causal; p.q_pos0 = q_pos0;
   p.scale_log2 = scale * 1.44269504088896340736f;
-  dim3 grid(gr_cdiv(Lq, 128), B * H);
+  dim3 grid(B * H, gr_cdiv(Lq, 128));
   static bool attr_set = false;
   if (!attr_set) {
     if (hipFuncSetAttribute((const void*)attention_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536) != hipSuccess ||
