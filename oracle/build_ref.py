@@ -1,7 +1,7 @@
 """Build oracle/_ref/ from the reference's own sources where they lie (TEST INFRASTRUCTURE ONLY; outputs are git-ignored):
   * libmmcv_ref.so  -- g++ directly on four reference CPU files (nms, roi_align) + our shim; no reference build system;
   * eval_rec.pyc, eval_lvis.pyc -- the reference's evaluation scripts (groma/eval/eval_rec.py, eval_lvis.py) byte-compiled by
-    py_compile, so that tests/test_reference_eval_scripts_gpu.py can execute the reference's OWN eval_model() loop -- unchanged --
+    py_compile, so that tests/test_00_reference_eval_scripts_gpu.py can execute the reference's OWN eval_model() loop -- unchanged --
     against groma_amd.GromaModel on the GPU box, where /root/reference does not exist.
 Nothing is copied into the repository.  Usage: python oracle/build_ref.py /root/reference"""
 import os

@@ -1,4 +1,6 @@
 """the reference's OWN evaluation loops, executed unchanged against groma_amd.GromaModel.
+(Named test_00_* so that it runs first: the reference builds DataLoaders with 4 worker processes, and forking them out of a
+process that already holds every other test module's models took 220 s instead of 20 s.)
 
 oracle/_ref/eval_rec.pyc and eval_lvis.pyc are R: groma/eval/eval_rec.py and groma/eval/eval_lvis.py byte-compiled where they lie
 by oracle/build_ref.py (py_compile; git-ignored build outputs like libmmcv_ref.so -- no reference source is in the repository,
