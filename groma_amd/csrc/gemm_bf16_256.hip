@@ -57,6 +57,15 @@ __device__ __forceinline__ f32x4 mfma_fp8x2(bf16x8 a, bf16x8 b, f32x4 c) {
 #define ESZ 2
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0)
 #endif
+#ifdef G256_ABL_NOMFMA  // timing ablation: the load segments alone (one MFMA per 16 kept so the fragments stay live)
+__device__ __forceinline__ f32x4 abl_keep(bf16x8 b, bf16x8 a, f32x4 c) {
+  asm volatile("" ::"v"(a), "v"(b));  // the fragments stay live (their LDS reads are not dead code)
+  return c;
+}
+#define ABL_MFMA(b, a, c) ((i == 0 && j == 0) ? MFMA16(b, a, c) : abl_keep(b, a, c))
+#else
+#define ABL_MFMA(b, a, c) MFMA16(b, a, c)
+#endif
 #define KT (128 / ESZ)  // K elements per K-tile (one 128-B LDS row)
 // (v_mfma_f32_32x32x16_bf16 was tried in place of 16x16x32 -- 1.22 vs 1.42 PF at 8192^3 -- and removed.)
 #define LDS_SWZ(row) ((row) & 7)
@@ -223,6 +232,9 @@ __global__ __launch_bounds__(NT) void G256_KERNEL(GemmArgs p) {
 
   auto issue_at = [&](int h, int tile, long koff) {  // one half-tile of K-tile `tile` into stage tile&1
     if (tile >= nt) return;
+#ifdef G256_ABL_NODMA  // timing ablation (tests/diag): only the prologue's two K-tiles are ever staged; results are garbage
+    if (tile >= 2) return;
+#endif
     char* st = smem + (tile & 1) * STAGE_BYTES;
     glds16(src[h][0] + koff * ESZ, st + ldsoff[h][0]);
     glds16(src[h][1] + koff * ESZ, st + ldsoff[h][1]);
@@ -279,7 +291,7 @@ __global__ __launch_bounds__(NT) void G256_KERNEL(GemmArgs p) {
   _Pragma("unroll") for (int kk = 0; kk < 2; ++kk)                                                        \
     _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                         \
       _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                       \
-        acc[I0 + i][j] = MFMA16(bfr[j][kk], af[i][kk], acc[I0 + i][j]);                                   \
+        acc[I0 + i][j] = ABL_MFMA(bfr[j][kk], af[i][kk], acc[I0 + i][j]);                                 \
   __builtin_amdgcn_s_setprio(0);                                                                          \
   PH_MARK(2 * (P) + 1)                                                                                    \
   __builtin_amdgcn_sched_barrier(0);                                                                      \
@@ -289,6 +301,10 @@ __global__ __launch_bounds__(NT) void G256_KERNEL(GemmArgs p) {
     const char* st = smem + (t & 1) * STAGE_BYTES;
     const bool steady = t + 2 < nt;
     // ===== X
+#ifdef G256_ABL_NOREAD  // timing ablation: fragments are read for K-tile 0 only
+    if (t == 0)
+#endif
+    {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       bfr[j][0] = *(const bf16x8*)(st + b_lane + j * 2048 + off0);
@@ -299,16 +315,22 @@ __global__ __launch_bounds__(NT) void G256_KERNEL(GemmArgs p) {
       af[i][0] = *(const bf16x8*)(st + a_lane + i * 2048 + off0);
       af[i][1] = *(const bf16x8*)(st + a_lane + i * 2048 + (off0 ^ 64));
     }
+    }
     __builtin_amdgcn_sched_barrier(0);
     WAIT_VM(6);
     issue_at(HT_A1, t + 1, aoff1);
     DRAIN_READS
     PHASE32(0, 0)
     // ===== Y
+#ifdef G256_ABL_NOREAD
+    if (t == 0)
+#endif
+    {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       af[i][0] = *(const bf16x8*)(st + a_lane + (4 + i) * 2048 + off0);
       af[i][1] = *(const bf16x8*)(st + a_lane + (4 + i) * 2048 + (off0 ^ 64));
+    }
     }
     __builtin_amdgcn_sched_barrier(0);
     WAIT_VM(2);
