@@ -138,6 +138,7 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(AttnArgs p) {
   const int blk_limit = p.causal ? min(kvmax, q_pos0 + blk_last + 1) : kvmax;
   const int wav_limit = p.causal ? min(kvmax, q_pos0 + wav_last + 1) : kvmax;
   const int ntiles = (blk_limit + KV - 1) / KV;
+  const bool wave_has_rows = q0 + wave * (16 * QT) < p.Lq;
   const int wav_first = min(q0 + wave * (16 * QT), p.Lq - 1);
   const int wav_min_limit = p.causal ? min(kvmax, q_pos0 + wav_first + 1) : kvmax;  // min over the wave's rows
 
@@ -188,7 +189,9 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(AttnArgs p) {
     __syncthreads();  // tile t landed for every wave; everyone finished reading the other buffer
     ATT_MARK(1)
     if (t + 1 < ntiles) stage(t + 1);
-    if (kv0 >= wav_limit) continue;  // wave-uniform: every key of this tile is masked for all of this wave's rows
+    // wave-uniform skips: every key of this tile is masked for all of this wave's rows, or the wave has no query row at all
+    // (the last query block of T = 1025 holds one row: three of its four waves only help staging the tiles)
+    if (kv0 >= wav_limit || !wave_has_rows) continue;
     const char* ksm = smem + (t & 1) * STAGE;
     const char* vsm = ksm + KTILE;
 
