@@ -353,6 +353,8 @@ def main():
                          "(4 images per GPU at 8 ranks).  0 (default) = weak scaling, --batch images on every rank")
     ap.add_argument("--gemm-plan", default="throughput", choices=["throughput", "latency"],
                     help="split-K plan class of the headline measurement (ops.plan_splits): a function of the layer shape only")
+    ap.add_argument("--no-prefill-graphs", action="store_true",
+                    help="launch the ViT / LLaMA prefill layers eagerly instead of replaying their captured hipGraphs (A/B)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-traffic", action="store_true",
                     help="skip the live rocprofv3 PMC passes for roofline.traffic (the committed profiles/ summary is reported instead)")
@@ -383,8 +385,9 @@ def main():
     dev = torch.device("cuda", local_rank)
     use_dist = world > 1 or args.force_dist
 
-    from groma_amd import config as gconfig, constants, dist as gdist, ops, synth
+    from groma_amd import config as gconfig, constants, dist as gdist, engine, ops, synth
     from groma_amd.groma import GromaModel
+    engine.GraphPool.enabled = not args.no_prefill_graphs
     if use_dist:
         gdist.init("nccl", dev, single_process=(world == 1))  # RCCL over xGMI; rendezvous on 127.0.0.1 unless the launcher says otherwise
     rccl_ranks = gdist.count_ranks(dev)  # all-reduce of ones: proves how many ranks took part (1 without a process group)
@@ -415,12 +418,16 @@ def main():
     # ---- roofline leg: the same steps again with HIP events around every GEMM launch (on the launch stream) ----
     n_reg = [b.shape[0] for b in model._last_aux["sel_idx"]] if job.rows else [100]
     fl = flops_per_image(cfg, sum(n_reg) / len(n_reg), P)
-    model.decode_graph = False  # HIP events cannot bracket launches inside a replayed graph: time the same kernels eagerly
+    # HIP events cannot bracket launches inside a replayed graph (the hook sits in the launch functions): time the same
+    # kernels eagerly
+    model.decode_graph = False
+    engine.GraphPool.enabled = False
     ops.prof_enable(True)
     for i in range(args.steps):
         step(args.warmup + i)
     torch.cuda.synchronize()
     ops.prof_enable(False)
+    engine.GraphPool.enabled = not args.no_prefill_graphs
     model.decode_graph = True
     recs = ops.prof_read_launches()
     if args.gemm_breakdown and rank == 0:
@@ -480,7 +487,7 @@ def main():
                    "images_per_gpu": job.rows, "images_per_forward_call": min(args.batch, job.rows),
                    "global_batch": job.global_batch, "prompt_tokens": P,
                    "llm_seq_len": fl["L"], "regions_per_image": sum(n_reg) / len(n_reg),
-                   "gemm_plan": args.gemm_plan,
+                   "gemm_plan": args.gemm_plan, "prefill_graphs": not args.no_prefill_graphs,
                    "parallelism": f"dp{world} (image batch sharded, full replica per GPU)"},
         "roofline": {"bound": "mfma", "kernel": kname,
                      "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,

@@ -7,6 +7,7 @@ RegionEngine     groma/model/roi_align.py:97-327                               a
 LlamaEngine      HF LlamaModel + heads, groma.py:389-402                       a19-a22
 Residual streams are fp32 in HBM; GEMM operands bf16 (fp32 accumulate); the proposer is fp32 end to end.
 """
+import collections
 import math
 
 import torch
@@ -107,6 +108,59 @@ class Workspace:
         return sum(t.numel() * t.element_size() for t in list(self._arena.values()) + list(self._exact.values()))
 
 
+class GraphPool:
+    """Captured hipGraphs of the shape-static launch sequences of a forward (the 24 ViT layers, the 32 LLaMA prefill layers).
+
+    A launch sequence is a pure function of what is baked into its kernel arguments: buffer addresses and scalars.  The
+    caller folds ALL of them into `key` (every scratch / cache / input address, the shape, the GEMM plan), so a graph is
+    only ever replayed onto exactly the memory the eager launches would have used -- an arena that was regrown, or a new KV
+    cache, simply produces a new key.  A key is captured the third time it is seen (one-off shapes of an eval loop stay
+    eager; a capture costs about one eager pass) and the pool keeps the `cap` most recently used graphs; an evicted key
+    starts counting again, so a loop cycling through more shapes than `cap` captures at most once per 3 * cap calls.
+
+    Why: the kernels are identical either way, but eagerly launched kernels show a box-dependent 0-7 us dispatch gap between
+    consecutive kernels (profiles/r03_timeline_b14.txt: 436 gaps = 3 ms of a 145 ms step on some boxes, none on others);
+    nodes of a replayed graph start back to back on every box, and ~700 host launches per step disappear."""
+
+    enabled = True
+
+    CAPTURE_AT = 3
+
+    def __init__(self, cap=16):
+        self.cap, self._graphs, self._seen = cap, collections.OrderedDict(), collections.OrderedDict()
+        self.replays = self.captures = 0
+
+    def run(self, key, launch):
+        if not GraphPool.enabled or TRACE is not None or torch.cuda.is_current_stream_capturing():
+            launch()
+            return
+        g = self._graphs.get(key)
+        if g is not None:
+            self._graphs.move_to_end(key)
+            g.replay()
+            self.replays += 1
+            return
+        n = self._seen.pop(key, 0) + 1
+        if n < GraphPool.CAPTURE_AT:
+            self._seen[key] = n
+            if len(self._seen) > 256:
+                self._seen.popitem(last=False)
+            launch()
+            return
+        torch.cuda.synchronize()  # nothing of this forward (side stream) may overlap the capture
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            launch()
+        self._graphs[key] = g
+        self.captures += 1
+        if len(self._graphs) > self.cap:
+            self._graphs.popitem(last=False)
+        g.replay()
+
+    def clear(self):
+        self._graphs.clear(), self._seen.clear()
+
+
 # ------------------------------------------------------------------------------------------------ DINOv2
 class VitEngine:
     def __init__(self, w, cfg, ws):
@@ -117,32 +171,43 @@ class VitEngine:
         self.G = w["grid"]
         self.T = 1 + self.G * self.G
         self.keep = 4  # hidden states the path consumes: -1..-4 (groma.py:224,240,312)
+        self.graphs = GraphPool()
 
     def forward(self, images):
-        """images f32 [bs,3,S,S] -> list of the last `keep` hidden states, each f32 [bs,T,D] (pre final-LN, T7)."""
+        """images f32 [bs,3,S,S] -> list of the last `keep` hidden states, each f32 [bs,T,D] (pre final-LN, T7).
+        bf16 models: the launch sequence is replayed from a captured hipGraph once a batch shape repeats (GraphPool)."""
         w, ws = self.w, self.ws
         bs = images.shape[0]
         D, T, G, H, hd = self.D, self.T, self.G, self.H, self.hd
         M = bs * T
         nl = len(w["layers"])
-        a = ops.patchify(images, self.P, w["Kpad"])
+        fp8 = w["fp8"]
+        Tp = _ru(T, 64)
+        I = w["layers"][0]["w1"][0].shape[0]
+        # every buffer the launches address, taken up front: the zero-padding bookkeeping of k / vt runs on every call
+        # (replayed or not) and the addresses key the graph
+        ops._chk(images, F32, "images")
+        graph = not fp8 and TRACE is None and GraphPool.enabled
+        if graph:  # the caller's tensor moves from call to call: stage it
+            img = ws.get("vit_img", images.shape, F32)
+            img.copy_(images)
+        else:
+            img = images
+        a = ws.get("vit_patch", (bs * G * G, w["Kpad"]), BF16)
         kept = [ws.get(f"vit_h{i}", (bs, T, D), F32) for i in range(self.keep)]
         scratch = [ws.get(f"vit_s{i}", (bs, T, D), F32) for i in range(2)]
         mid = ws.get("vit_mid", (bs, T, D), F32)
-
-        def out_buf(layer_out_index):  # hidden_states index (0 = embeddings ... nl = last layer)
-            k = layer_out_index - (nl + 1 - self.keep)
-            return kept[k] if k >= 0 else scratch[layer_out_index & 1]
-
-        h = out_buf(0)
-        ops.fill_rows(w["cls_pos0"], h, bs, T * D)
-        ops.gemm(a, w["patch_w"], bias=w["patch_b"], resid=w["pos_patch"], resid_mod=G * G, out=h, out_f32=True,
-                 row_map=(G * G, T, 1))
-        Tp = _ru(T, 64)
-        q = ws.get("vit_q", (bs, H, T, hd), BF16)
+        q = None if Q_IN_PLACE else ws.get("vit_q", (bs, H, T, hd), BF16)
         k = ws.get("vit_k", (bs, H, Tp, hd), BF16, zero=True)
         vt = ws.get("vit_vt", (bs, H, hd, Tp), BF16, zero=True)
-        fp8 = w["fp8"]
+        x_b = ws.get("vit_x", (M, D), BF16)
+        qkv_b = ws.get("vit_qkv", (M, 3 * D), BF16)
+        ctx_b = ws.get("vit_ctx", (M, D), BF16)
+        y_b = ws.get("vit_y", (M, I), BF16)
+
+        def out_buf(layer_out_index):  # hidden_states index (0 = embeddings ... nl = last layer)
+            j = layer_out_index - (nl + 1 - self.keep)
+            return kept[j] if j >= 0 else scratch[layer_out_index & 1]
 
         def lin(x_f32, ln_g, ln_b, wt, tag=None, **kw):
             """LayerNorm -> GEMM (bf16 operands, or e4m3 operands with dynamic per-row activation scales)"""
@@ -150,7 +215,7 @@ class VitEngine:
                 x8, sx = ops.norm_fp8(x_f32, ln_g, ln_b, self.eps, False)
                 _trace_q8(tag, x8, sx)
                 return ops.gemm(x8, wt[0], a_scale=sx, w_scale=wt[1], **kw)
-            x = ops.layernorm(x_f32, ln_g, ln_b, self.eps, out_bf16=True, out=ws.get("vit_x", (M, D), BF16))
+            x = ops.layernorm(x_f32, ln_g, ln_b, self.eps, out_bf16=True, out=x_b)
             if tag:
                 _trace(tag, x)
             return ops.gemm(x, wt[0], **kw)
@@ -162,26 +227,38 @@ class VitEngine:
                 return ops.gemm(x8, wt[0], a_scale=sx, w_scale=wt[1], **kw)
             return ops.gemm(x_bf16, wt[0], **kw)
 
-        for i, L in enumerate(w["layers"]):
-            t0 = TRACE is not None and i == 0
-            if t0:
-                _trace("vit0.h_in", h)
-            qkv = lin(h, L["ln1_g"], L["ln1_b"], L["wqkv"], tag="vit0.ln1" if t0 else None, bias=L["bqkv"],
-                      out=ws.get("vit_qkv", (M, 3 * D), BF16))
-            ops.qkv_split(qkv, None if Q_IN_PLACE else q, k, vt, B=bs, H=H, L=T, hd=hd)
-            if Q_IN_PLACE:  # attention reads q straight from the fused projection
-                ctx = ops.attention(qkv, k, vt, Skv=T, causal=False, out=ws.get("vit_ctx", (M, D), BF16),
-                                    fused=dict(B=bs, H=H, Lq=T, hd=hd))
-            else:
-                ctx = ops.attention(q, k, vt, Skv=T, causal=False, out=ws.get("vit_ctx", (M, D), BF16))
-            lin_bf16(ctx, L["wo"], tag="vit0.ctx" if t0 else None, bias=L["bo"], scale=L["ls1"], resid=h, out=mid, out_f32=True)
-            y = lin(mid, L["ln2_g"], L["ln2_b"], L["w1"], tag="vit0.ln2" if t0 else None, bias=L["b1"], act=1,
-                    out=ws.get("vit_y", (M, L["w1"][0].shape[0]), BF16))
-            hn = out_buf(i + 1)
-            lin_bf16(y, L["w2"], tag="vit0.fc1" if t0 else None, bias=L["b2"], scale=L["ls2"], resid=mid, out=hn, out_f32=True)
-            if t0:
-                _trace("vit0.qkv", qkv), _trace("vit0.ctx", ctx), _trace("vit0.mid", mid), _trace("vit0.fc1", y), _trace("vit0.out", hn)
-            h = hn
+        def launch():
+            ops.patchify(img, self.P, w["Kpad"], out=a)
+            h = out_buf(0)
+            ops.fill_rows(w["cls_pos0"], h, bs, T * D)
+            ops.gemm(a, w["patch_w"], bias=w["patch_b"], resid=w["pos_patch"], resid_mod=G * G, out=h, out_f32=True,
+                     row_map=(G * G, T, 1))
+            for i, L in enumerate(w["layers"]):
+                t0 = TRACE is not None and i == 0
+                if t0:
+                    _trace("vit0.h_in", h)
+                qkv = lin(h, L["ln1_g"], L["ln1_b"], L["wqkv"], tag="vit0.ln1" if t0 else None, bias=L["bqkv"], out=qkv_b)
+                ops.qkv_split(qkv, q, k, vt, B=bs, H=H, L=T, hd=hd)
+                if Q_IN_PLACE:  # attention reads q straight from the fused projection
+                    ctx = ops.attention(qkv, k, vt, Skv=T, causal=False, out=ctx_b, fused=dict(B=bs, H=H, Lq=T, hd=hd))
+                else:
+                    ctx = ops.attention(q, k, vt, Skv=T, causal=False, out=ctx_b)
+                lin_bf16(ctx, L["wo"], tag="vit0.ctx" if t0 else None, bias=L["bo"], scale=L["ls1"], resid=h, out=mid,
+                         out_f32=True)
+                y = lin(mid, L["ln2_g"], L["ln2_b"], L["w1"], tag="vit0.ln2" if t0 else None, bias=L["b1"], act=1, out=y_b)
+                hn = out_buf(i + 1)
+                lin_bf16(y, L["w2"], tag="vit0.fc1" if t0 else None, bias=L["b2"], scale=L["ls2"], resid=mid, out=hn,
+                         out_f32=True)
+                if t0:
+                    _trace("vit0.qkv", qkv), _trace("vit0.ctx", ctx), _trace("vit0.mid", mid), _trace("vit0.fc1", y)
+                    _trace("vit0.out", hn)
+                h = hn
+
+        if graph:
+            bufs = [img, a, mid, k, vt, x_b, qkv_b, ctx_b, y_b] + kept + scratch + ([] if q is None else [q])
+            self.graphs.run(("vit", bs, ops._PLAN[0]) + tuple(t.data_ptr() for t in bufs), launch)
+        else:
+            launch()
         first = nl + 1 - self.keep
         return [out_buf(j) for j in range(max(first, 0), nl + 1)]
 
@@ -352,6 +429,13 @@ class KVCache:
         self.k = [torch.zeros((bs, H, smax, hd), dtype=BF16, device=device) for _ in range(n_layers)]
         self.vt = [torch.zeros((bs, H, hd, smax), dtype=BF16, device=device) for _ in range(n_layers)]
         self.seq_len, self.smax, self.bs = 0, smax, bs
+        self._addr = None
+
+    def addresses(self):
+        """every layer's K / V^T address (+ capacity): part of the key of a captured prefill graph"""
+        if self._addr is None:
+            self._addr = (self.smax,) + tuple(t.data_ptr() for t in self.k) + tuple(t.data_ptr() for t in self.vt)
+        return self._addr
 
     def __len__(self):
         return len(self.k)
@@ -373,7 +457,7 @@ class KVCache:
             v = torch.zeros(tuple(self.vt[l].shape[:3]) + (smax,), dtype=BF16, device=self.k[l].device)
             v[..., : self.smax] = self.vt[l]
             self.k[l], self.vt[l] = k, v
-        self.smax = smax
+        self.smax, self._addr = smax, None
 
 
 class LlamaEngine:
@@ -384,9 +468,10 @@ class LlamaEngine:
         self.hd = self.T // self.H
         self.V, self.Vpad = w["V"], w["Vpad"]
         self.V0 = lc.vocab_size
+        self.graphs = GraphPool()
 
-    def embed(self, ids):
-        return ops.embed_gather(ids.reshape(-1).contiguous(), self.w["embed"], self.w["new_embed"])
+    def embed(self, ids, out=None):
+        return ops.embed_gather(ids.reshape(-1).contiguous(), self.w["embed"], self.w["new_embed"], out=out)
 
     def new_cache(self, bs, smax, device):
         return KVCache(len(self.w["layers"]), bs, self.H, self.hd, _ru(smax, 64), device)
@@ -416,6 +501,15 @@ class LlamaEngine:
 
         q = None if Q_IN_PLACE else buf("llm_q", (bs, H, L, hd), BF16)
         fp8 = w["fp8"]
+        x_b, qkv_b = buf("llm_x", (M, T), BF16), buf("llm_qkv", (M, 3 * T), BF16)
+        ctx_b, y_b = buf("llm_ctx", (M, T), BF16), buf("llm_y", (M, self.I), BF16)
+        # a prefill whose shape and memory repeat is replayed from a captured hipGraph (GraphPool): everything the launches
+        # bake in goes into the key; the ragged-row lengths are staged into a buffer of our own
+        graph = not dec and not fp8 and TRACE is None and GraphPool.enabled
+        if graph and kv_len is not None:
+            kvl = ws.get("llm_kvlen", (bs,), I32)
+            kvl.copy_(kv_len)
+            kv_len = kvl
 
         def lin(x_f32, gain, wt, tag=None, **kw):
             """RMSNorm -> GEMM (bf16 operands, or e4m3 operands with dynamic per-row activation scales)"""
@@ -423,7 +517,7 @@ class LlamaEngine:
                 x8, sx = ops.norm_fp8(x_f32, gain, None, self.eps, True)
                 _trace_q8(tag, x8, sx)
                 return ops.gemm(x8, wt[0], a_scale=sx, w_scale=wt[1], **kw)
-            x = ops.rmsnorm(x_f32, gain, self.eps, out=buf("llm_x", (M, T), BF16))
+            x = ops.rmsnorm(x_f32, gain, self.eps, out=x_b)
             if tag:
                 _trace(tag, x)
             return ops.gemm(x, wt[0], **kw)
@@ -435,34 +529,42 @@ class LlamaEngine:
                 return ops.gemm(x8, wt[0], a_scale=sx, w_scale=wt[1], **kw)
             return ops.gemm(x_bf16, wt[0], **kw)
 
-        for i, Lw in enumerate(w["layers"]):
-            t0 = TRACE is not None and i == 0
-            if t0:
-                _trace("llm0.h_in", h)
-            qkv = lin(h, Lw["n1"], Lw["wqkv"], tag="llm0.n1" if t0 else None, out=buf("llm_qkv", (M, 3 * T), BF16))
-            ops.qkv_split(qkv, None if Q_IN_PLACE else q, cache.k[i], cache.vt[i], B=bs, H=H, L=L, hd=hd, pos0=past,
-                          cos=w["cos"], sin=w["sin"], pos_dev=pos_dev, pos_stride=pos_stride)
-            att_kw = dict(Skv=cache.smax if dyn else past + L, causal=True, q_pos0=past, kv_len=kv_len,
-                          out=buf("llm_ctx", (M, T), BF16), pos_dev=pos_dev, pos_stride=pos_stride)
-            if Q_IN_PLACE:  # q is read (and rotated) in place: no packed q copy, no round trip
-                ctx = ops.attention(qkv, cache.k[i], cache.vt[i], fused=dict(B=bs, H=H, Lq=L, hd=hd, cos=w["cos"], sin=w["sin"]),
-                                    **att_kw)
-            else:
-                ctx = ops.attention(q, cache.k[i], cache.vt[i], **att_kw)
-            if t0:
-                _trace("llm0.qkv", qkv), _trace("llm0.ctx", ctx)
-            lin_bf16(ctx, Lw["wo"], tag="llm0.ctx" if t0 else None, resid=h, out=h, out_f32=True)
-            if t0:
-                _trace("llm0.h_attn", h)
-            y = lin(h, Lw["n2"], Lw["wgu"], tag="llm0.n2" if t0 else None, act=3, out=buf("llm_y", (M, self.I), BF16))
-            if t0:
-                _trace("llm0.act", y)
-            lin_bf16(y, Lw["wd"], tag="llm0.act" if t0 else None, resid=h, out=h, out_f32=True)
-            if t0:
-                _trace("llm0.h_out", h)
+        def launch():
+            for i, Lw in enumerate(w["layers"]):
+                t0 = TRACE is not None and i == 0
+                if t0:
+                    _trace("llm0.h_in", h)
+                qkv = lin(h, Lw["n1"], Lw["wqkv"], tag="llm0.n1" if t0 else None, out=qkv_b)
+                ops.qkv_split(qkv, q, cache.k[i], cache.vt[i], B=bs, H=H, L=L, hd=hd, pos0=past,
+                              cos=w["cos"], sin=w["sin"], pos_dev=pos_dev, pos_stride=pos_stride)
+                att_kw = dict(Skv=cache.smax if dyn else past + L, causal=True, q_pos0=past, kv_len=kv_len,
+                              out=ctx_b, pos_dev=pos_dev, pos_stride=pos_stride)
+                if Q_IN_PLACE:  # q is read (and rotated) in place: no packed q copy, no round trip
+                    ctx = ops.attention(qkv, cache.k[i], cache.vt[i],
+                                        fused=dict(B=bs, H=H, Lq=L, hd=hd, cos=w["cos"], sin=w["sin"]), **att_kw)
+                else:
+                    ctx = ops.attention(q, cache.k[i], cache.vt[i], **att_kw)
+                if t0:
+                    _trace("llm0.qkv", qkv), _trace("llm0.ctx", ctx)
+                lin_bf16(ctx, Lw["wo"], tag="llm0.ctx" if t0 else None, resid=h, out=h, out_f32=True)
+                if t0:
+                    _trace("llm0.h_attn", h)
+                y = lin(h, Lw["n2"], Lw["wgu"], tag="llm0.n2" if t0 else None, act=3, out=y_b)
+                if t0:
+                    _trace("llm0.act", y)
+                lin_bf16(y, Lw["wd"], tag="llm0.act" if t0 else None, resid=h, out=h, out_f32=True)
+                if t0:
+                    _trace("llm0.h_out", h)
+
+        if graph:
+            bufs = [h, x_b, qkv_b, ctx_b, y_b] + ([] if q is None else [q]) + ([] if kv_len is None else [kv_len])
+            self.graphs.run(("llm", bs, L, past, kv_len is None, ops._PLAN[0]) + tuple(t.data_ptr() for t in bufs)
+                            + cache.addresses(), launch)
+        else:
+            launch()
         if not dyn:
             cache.seq_len = past + L
-        hn = ops.rmsnorm(h, w["norm"], self.eps, out=buf("llm_x", (M, T), BF16))
+        hn = ops.rmsnorm(h, w["norm"], self.eps, out=x_b)
         if len(w["layers"]) == 1:
             _trace("llm.final_norm", hn)
         if L == 1:  # decode step: the sampler (GreedyDecoder._step, serving) reads this buffer

@@ -421,7 +421,8 @@ class GromaModel:
                 stage[:n0], stage[n0:n0 + n1], stage[n0 + n1:n0 + n1 + n2] = flat, img_rows_h, reg_rows_h
                 ids_dev = stage[:n0 + n1 + n2].to(dev, non_blocking=True)
                 new_ids = ids_dev[:n0].view(bs, L)
-                emb = self.llm.embed(new_ids)  # f32 [bs*L, T]
+                # f32 [bs*L, T], in an arena of our own: the residual stream's address keys the captured prefill graph
+                emb = self.llm.embed(new_ids, out=self._ws.get("llm_h", (bs * L, self.llm.T), F32))
                 img_rows, reg_rows = ids_dev[n0:n0 + n1].to(I32), ids_dev[n0 + n1:].to(I32)
                 ops.scatter_rows(image_features, img_rows, emb)
                 ops.scatter_rows(region_features, reg_rows, emb)

@@ -94,8 +94,8 @@ def _split_ws(splits, M, N, device):
     n = splits * M * N
     t = _SPLIT_WS.get(key)
     if t is None or t.numel() < n:
-        if t is not None:
-            torch.cuda.synchronize(device)
+        if t is not None and not torch.cuda.is_current_stream_capturing():
+            torch.cuda.synchronize(device)  # (inside a capture the graph's own pool orders the reuse)
         t = _SPLIT_WS[key] = torch.empty((max(n, 0 if t is None else t.numel() * 3 // 2),), dtype=F32, device=device)
     return t[:n].view(splits, M, N)
 
@@ -312,12 +312,14 @@ def qkv_split(qkv, q, k, vt, *, B, H, L, hd, pos0=0, cos=None, sin=None, pos_dev
                                 _p(pos_dev), pos_stride, _stream()), "gr_qkv_split")
 
 
-def patchify(images, P, Kpad):
+def patchify(images, P, Kpad, out=None):
     lib = _lib.load()
     _chk(images, F32, "images")
     B, _, S, _ = images.shape
     G = S // P
-    out = torch.empty((B * G * G, Kpad), dtype=BF16, device=images.device)
+    if out is None:
+        out = torch.empty((B * G * G, Kpad), dtype=BF16, device=images.device)
+    _chk(out, BF16, "out")
     _lib.check(lib.gr_patchify(_p(images), _p(out), B, S, P, Kpad, _stream()), "gr_patchify")
     return out
 

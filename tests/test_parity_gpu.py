@@ -413,3 +413,41 @@ def test_calls_under_inference_mode_then_outside(setup):
         torch.manual_seed(3)
         m.forward(input_ids=cpu_ids, images=images[:1], refer_boxes=rb, return_dict=True)
         assert int(cpu_ids[0, 40]) == int(dev_ids[0, 40])
+
+
+def test_prefill_graphs_equal_eager(setup):
+    """The ViT layers and the LLaMA prefill layers are replayed from captured hipGraphs once a shape repeats
+    (engine.GraphPool).  Replayed results must be bitwise those of the eager launches -- for new pixel values in the caller's
+    (moving) image tensor, for new ragged row lengths staged into the graph's own buffer, and after another shape has used
+    (and re-zeroed) the shared arenas in between."""
+    cfg, sd, tk, model, images, ids = setup
+    from groma_amd import engine, synth
+    images_b, _ = synth.make_inputs(cfg, tk, bs=2, seed=77)
+    ids_s6, ids_s9 = ids.clone(), ids.clone()
+    ids_s6[1, -6:] = model.pad_token_id  # right-padded rows: ragged lengths reach the attention kernel through kv_len
+    ids_s9[1, -9:] = model.pad_token_id
+
+    def run(img, i=ids, n=2):
+        torch.manual_seed(5)  # the region shuffle
+        return model.forward(input_ids=i[:n].clone(), images=img[:n].cuda(), return_dict=True).logits.clone()
+
+    engine.GraphPool.enabled = False
+    try:
+        ea, eb, e6, e9, e1 = run(images), run(images_b), run(images, ids_s6), run(images, ids_s9), run(images, n=1)
+    finally:
+        engine.GraphPool.enabled = True
+    model.vit.graphs.clear(), model.llm.graphs.clear()
+    v0, l0 = model.vit.graphs.replays, model.llm.graphs.replays
+    assert torch.equal(run(images), ea)            # first and second sight: eager
+    assert torch.equal(run(images), ea)
+    assert torch.equal(run(images), ea)            # third: captured + replayed
+    assert torch.equal(run(images), ea)            # replay
+    assert torch.equal(run(images_b), eb)          # same shapes, new pixels (and whatever L the new boxes give)
+    assert torch.equal(run(images, n=1), e1)       # another shape through the same arenas
+    for _ in range(3):
+        assert torch.equal(run(images, ids_s6), e6)
+        assert torch.equal(run(images, ids_s9), e9)    # same shapes as s6 when row 0 is the longest: new lengths, same graph
+    assert torch.equal(run(images), ea)            # back to the first shape: its graph is still valid
+    assert model.vit.graphs.replays > v0 + 3 and model.llm.graphs.replays > l0
+    print("vit graphs", model.vit.graphs.captures, model.vit.graphs.replays, "llm graphs", model.llm.graphs.captures,
+          model.llm.graphs.replays)
