@@ -314,7 +314,7 @@ def extras_block(model, cfg, args, dev, P):
     eos = model.generation_config.eos_token_id
     model.generation_config.eos_token_id = None
     try:
-        g = line(model, 4, True, steps=3, warmup=1)
+        g = line(model, 4, True, steps=3, warmup=3)
     finally:
         model.generation_config.eos_token_id = eos
     g["new_tokens"] = args.new_tokens
@@ -322,7 +322,7 @@ def extras_block(model, cfg, args, dev, P):
     ex["generate_4_images_per_call"] = g
     m8 = GromaModel.from_synthetic(cfg, seed=0, device=dev, fp8=True)
     m8.init_special_token_id(constants.SyntheticTokenizer())
-    f8 = line(m8, args.batch, False, steps=5, warmup=2)
+    f8 = line(m8, args.batch, False, steps=5, warmup=3)
     f8["dtype"] = "fp8 (OCP e4m3 operands for the DINOv2 / LLaMA linears, f32 accumulate; lm_head and region convs bf16)"
     ex["forward_fp8"] = f8
     del m8
@@ -334,7 +334,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=3,
+                    help="untimed steps (3 or more: a prefill graph is captured the third time its shape is seen)")
     ap.add_argument("--batch", type=int, default=14, help="images per GPU per step (14*582 = 8148 rows ~ 32 GEMM row-tiles of 256)")
     ap.add_argument("--config", default="7b", choices=["7b", "tiny"])
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp8"],
