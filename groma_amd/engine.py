@@ -431,12 +431,6 @@ class KVCache:
         self.seq_len, self.smax, self.bs = 0, smax, bs
         self._addr = None
 
-    def addresses(self):
-        """every layer's K / V^T address (+ capacity): part of the key of a captured prefill graph"""
-        if self._addr is None:
-            self._addr = (self.smax,) + tuple(t.data_ptr() for t in self.k) + tuple(t.data_ptr() for t in self.vt)
-        return self._addr
-
     def __len__(self):
         return len(self.k)
 
@@ -458,6 +452,15 @@ class KVCache:
             v[..., : self.smax] = self.vt[l]
             self.k[l], self.vt[l] = k, v
         self.smax, self._addr = smax, None
+
+
+def cache_addresses(cache):
+    """every layer's K / V^T address (+ capacity) of a KVCache-like object (KVCache, serving's row view): part of the key of a
+    captured prefill graph.  Memoised on the object; KVCache.grow() drops the memo."""
+    a = getattr(cache, "_addr", None)
+    if a is None:
+        a = cache._addr = (cache.smax,) + tuple(t.data_ptr() for t in cache.k) + tuple(t.data_ptr() for t in cache.vt)
+    return a
 
 
 class LlamaEngine:
@@ -559,7 +562,7 @@ class LlamaEngine:
         if graph:
             bufs = [h, x_b, qkv_b, ctx_b, y_b] + ([] if q is None else [q]) + ([] if kv_len is None else [kv_len])
             self.graphs.run(("llm", bs, L, past, kv_len is None, ops._PLAN[0]) + tuple(t.data_ptr() for t in bufs)
-                            + cache.addresses(), launch)
+                            + cache_addresses(cache), launch)
         else:
             launch()
         if not dyn:
