@@ -311,6 +311,7 @@ def extras_block(model, cfg, args, dev, P):
     ex["forward_1_image_per_call"] = line(model, 1, False)
     ex["forward_1_image_per_call_latency_plan"] = line(model, 1, False, plan="latency")
     ex["forward_4_images_per_call"] = line(model, 4, False)
+    ex["forward_4_images_per_call_latency_plan"] = line(model, 4, False, plan="latency")
     eos = model.generation_config.eos_token_id
     model.generation_config.eos_token_id = None
     try:
