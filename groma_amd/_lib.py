@@ -1,4 +1,4 @@
-"""ctypes binding of libgroma_hip.so (include/groma_hip.h).
+"""ctypes binding of libgroma_hip.so / libgroma_hip_f16.so (include/groma_hip.h: one ABI, two 16-bit operand types).
 
 The product path has NO fallback: if the HIP library is missing or an op returns non-zero we raise.
 (The reference raises RuntimeError from TORCH_CHECK inside mmcv `_ext`; same error class here.)
@@ -10,6 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # The one library the product loads.  (Measurement scripts under tests/diag that A/B another build assign
 # `groma_amd._lib.LIB_PATH = ...` before the first load -- tests/diag/_variant.py; the product reads no environment switch.)
 LIB_PATH = os.path.join(_HERE, "csrc", "libgroma_hip.so")
+LIB_PATH_F16 = os.path.join(_HERE, "csrc", "libgroma_hip_f16.so")
 
 c_void_p = ctypes.c_void_p
 c_int = ctypes.c_int
@@ -39,6 +40,7 @@ class GemmDesc(ctypes.Structure):
 _P, _I, _L, _F = c_void_p, c_int, c_long, c_float
 SIGNATURES = {
     "gr_abi_version": [],
+    "gr_operand_type": [],
     "gr_prof_enable": [_I],
     "gr_prof_read": [_P, _P, _P],
     "gr_prof_read_launches": [_L, _P, _P, _P],
@@ -85,27 +87,41 @@ SIGNATURES = {
     "gr_roi_align_pack": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _I, _I, _I, _I, _P],
 }
 
-_lib = None
+_lib = None       # the bf16 build (kept under this name: tests monkeypatch it)
+_lib_f16 = None
+PRECISION = ["bf16"]  # the active 16-bit operand type: "bf16" | "fp16" (ops.precision() switches it around a model's calls)
 
 
-def load():
-    """Load the shared object and type every exported symbol.  Raises if anything is missing."""
-    global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.exists(LIB_PATH):
+def _open(path, operand):
+    if not os.path.exists(path):
         raise RuntimeError(
-            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            f"{path} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(groma_amd has no CPU / eager fallback by design)")
-    lib = ctypes.CDLL(LIB_PATH)
+    lib = ctypes.CDLL(path)
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
         fn.argtypes = argtypes
         fn.restype = c_long if name == "gr_nms_workspace_bytes" else c_int
-    if lib.gr_abi_version() != 5:
-        raise RuntimeError("libgroma_hip.so ABI version mismatch")
-    _lib = lib
+    if lib.gr_abi_version() != 6:
+        raise RuntimeError(f"{os.path.basename(path)} ABI version mismatch")
+    if lib.gr_operand_type() != operand:
+        raise RuntimeError(f"{os.path.basename(path)} was built for another 16-bit operand type")
     return lib
+
+
+def load(precision=None):
+    """The library of the active (or given) operand type, loaded and typed on first use.  Raises if anything is missing."""
+    global _lib, _lib_f16
+    precision = precision or PRECISION[0]
+    if precision == "bf16":
+        if _lib is None:
+            _lib = _open(LIB_PATH, 0)
+        return _lib
+    if precision == "fp16":
+        if _lib_f16 is None:
+            _lib_f16 = _open(LIB_PATH_F16, 1)
+        return _lib_f16
+    raise ValueError(f"unknown precision {precision!r}")
 
 
 def check(rc, what):

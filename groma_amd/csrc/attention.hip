@@ -223,7 +223,7 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(AttnArgs p) {
       for (int e = 0; e < GK; ++e) {
         const int step = g * GK + e, j = step / (HD / 32), kk = step % (HD / 32);
 #pragma unroll
-        for (int u = 0; u < QT; ++u) s[u][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfr[g & 1][e], qf[u][kk], s[u][j], 0, 0, 0);
+        for (int u = 0; u < QT; ++u) s[u][j] = GR_MFMA_16x16x32(kfr[g & 1][e], qf[u][kk], s[u][j]);
       }
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -306,7 +306,7 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(AttnArgs p) {
       for (int e = 0; e < GV; ++e) {
         const int step = g * GV + e, tt = step / (HD / 16), n = step % (HD / 16);
 #pragma unroll
-        for (int u = 0; u < QT; ++u) o[u][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vfr[g & 1][e], pb[u][tt].v, o[u][n], 0, 0, 0);
+        for (int u = 0; u < QT; ++u) o[u][n] = GR_MFMA_16x16x32(vfr[g & 1][e], pb[u][tt].v, o[u][n]);
       }
       __builtin_amdgcn_sched_barrier(0);
     }

@@ -1,5 +1,6 @@
-"""Build libgroma_hip.so (gfx950) in-tree with hipcc.  No cmake, no torch extension machinery:
-the library is a plain C-ABI shared object (include/groma_hip.h) loaded through ctypes."""
+"""Build libgroma_hip.so and libgroma_hip_f16.so (gfx950) in-tree with hipcc.  No cmake, no torch extension machinery:
+each library is a plain C-ABI shared object (include/groma_hip.h) loaded through ctypes.  The two are the same sources and the
+same ABI; they differ in the 16-bit operand type the kernels are compiled for (bfloat16 / IEEE half, -DGR_F16: gr_common.h)."""
 import os
 import subprocess
 import sys
@@ -24,6 +25,8 @@ SOURCES = {
     "roi_align.hip": ["-ffp-contract=off"],
 }
 LIB = os.path.join(HERE, "libgroma_hip.so")
+LIB_F16 = os.path.join(HERE, "libgroma_hip_f16.so")
+VARIANTS = [("", [], LIB), ("_f16", ["-DGR_F16=1"], LIB_F16)]
 COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 
 
@@ -37,13 +40,17 @@ def _stale(target, deps):
 def build(force=False, verbose=True):
     hdrs = [os.path.join(HERE, "gr_common.h"), os.path.join(HERE, "gemm_common.h"), os.path.join(HERE, "gemm_bf16_256.hip"), os.path.join(HERE, "..", "..", "include", "groma_hip.h"),
             os.path.abspath(__file__)]
-    objs, jobs = [], []
-    for src, extra in SOURCES.items():
-        s = os.path.join(HERE, src)
-        o = os.path.join(HERE, src.replace(".hip", ".o"))
-        objs.append(o)
-        if force or _stale(o, [s] + hdrs):
-            jobs.append(["hipcc"] + COMMON + extra + ["-c", s, "-o", o])
+    jobs, links = [], []
+    for suffix, defs, lib in VARIANTS:
+        objs, dirty = [], False
+        for src, extra in SOURCES.items():
+            s = os.path.join(HERE, src)
+            o = os.path.join(HERE, src.replace(".hip", suffix + ".o"))
+            objs.append(o)
+            if force or _stale(o, [s] + hdrs):
+                jobs.append(["hipcc"] + COMMON + defs + extra + ["-c", s, "-o", o])
+                dirty = True
+        links.append((lib, objs, dirty))
 
     def run(cmd):
         if verbose:
@@ -54,13 +61,15 @@ def build(force=False, verbose=True):
         if verbose and r.stderr.strip():
             print(r.stderr, file=sys.stderr)
 
-    with ThreadPoolExecutor(max_workers=min(8, max(1, len(jobs)))) as ex:
+    with ThreadPoolExecutor(max_workers=min(os.cpu_count() or 8, 16, max(1, len(jobs)))) as ex:
         list(ex.map(run, jobs))
-    if force or jobs or _stale(LIB, objs):
-        run(["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs)
+    for lib, objs, dirty in links:
+        if force or dirty or _stale(lib, objs):
+            run(["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs)
     return LIB
 
 
 if __name__ == "__main__":
     build(force="--force" in sys.argv)
     print(LIB)
+    print(LIB_F16)

@@ -107,7 +107,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16_kernel(GemmArgs p) {
       for (int j = 0; j < 4; ++j)
 #pragma unroll
         for (int i = 0; i < 4; ++i)
-          acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[j][i], 0, 0, 0);
+          acc[j][i] = GR_MFMA_16x16x32(wf[j], af[i], acc[j][i]);
     }
   }
 
@@ -171,6 +171,11 @@ struct ProfRec { hipEvent_t a, b; double flops; int M, N, K, tag; };
 static std::vector<ProfRec> g_prof;
 
 extern "C" int gr_abi_version(void) { return GROMA_HIP_ABI_VERSION; }
+#ifdef GR_F16
+extern "C" int gr_operand_type(void) { return GR_OPERAND_F16; }
+#else
+extern "C" int gr_operand_type(void) { return GR_OPERAND_BF16; }
+#endif
 extern "C" int gr_prof_enable(int on) {
   g_prof_on = on != 0;
   return GR_OK;

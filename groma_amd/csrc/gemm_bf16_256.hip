@@ -55,7 +55,7 @@ __device__ __forceinline__ f32x4 mfma_fp8x2(bf16x8 a, bf16x8 b, f32x4 c) {
 #define G256_KERNEL gemm_bf16_256_kernel
 #define G256_LAUNCH gr_launch_gemm256
 #define ESZ 2
-#define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0)
+#define MFMA16(a, b, c) GR_MFMA_16x16x32(a, b, c)
 #endif
 #ifdef G256_ABL_NOMFMA  // timing ablation: the load segments alone (one MFMA per 16 kept so the fragments stay live)
 __device__ __forceinline__ f32x4 abl_keep(bf16x8 b, bf16x8 a, f32x4 c) {

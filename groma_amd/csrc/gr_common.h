@@ -13,6 +13,25 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 #define GR_OK 0
 #define GR_EINVAL 22
 
+// The 16-bit operand type of the library is a BUILD choice: libgroma_hip.so carries bfloat16 (the reference's training /
+// benchmark dtype), libgroma_hip_f16.so -- the same sources compiled with -DGR_F16, the same C ABI -- carries IEEE half, the
+// dtype the reference's own inference entry points autocast to (R: groma/eval/run_groma.py:82, serve/model_worker.py:256).
+// MFMA runs both at the same rate; half has 3 more mantissa bits.  Every kernel converts through the three helpers below and
+// multiplies through GR_MFMA_16x16x32, so `bf16_t` reads "the library's 16-bit storage type" everywhere else.
+#ifdef GR_F16
+typedef __attribute__((ext_vector_type(2))) _Float16 h16x2_hw;
+typedef __attribute__((ext_vector_type(8))) _Float16 h16x8_hw;
+// f32 -> f16 round-to-nearest-even (v_cvt_f16_f32), saturating at +-65504 instead of producing inf (one v_med3_f32)
+__device__ __forceinline__ float sat_h16(float f) { return __builtin_amdgcn_fmed3f(f, -65504.0f, 65504.0f); }
+__device__ __forceinline__ bf16_t f2bf(float f) { return __builtin_bit_cast(bf16_t, (_Float16)sat_h16(f)); }
+__device__ __forceinline__ float bf2f(bf16_t h) { return (float)__builtin_bit_cast(_Float16, h); }
+__device__ __forceinline__ uint32_t pack2bf(float a, float b) {
+  const h16x2_hw v = {(_Float16)sat_h16(a), (_Float16)sat_h16(b)};
+  return __builtin_bit_cast(uint32_t, v);
+}
+#define GR_MFMA_16x16x32(a, b, c) \
+  __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h16x8_hw, a), __builtin_bit_cast(h16x8_hw, b), c, 0, 0, 0)
+#else
 // f32 -> bf16, round-to-nearest-even (same rule as torch .to(bfloat16)): the __bf16 casts lower to ONE
 // v_cvt_pk_bf16_f32 per pair on gfx950 (the bit-twiddling form costs ~7 VALU ops per element).
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_hw;
@@ -25,6 +44,8 @@ __device__ __forceinline__ uint32_t pack2bf(float a, float b) {
   const bf16x2_hw v = {(__bf16)a, (__bf16)b};
   return __builtin_bit_cast(uint32_t, v);
 }
+#define GR_MFMA_16x16x32(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0)
+#endif
 
 // erf via Abramowitz-Stegun 7.1.26 (|abs err| <= 1.5e-7, i.e. fp32-roundoff class): ~14 VALU ops instead of the
 // ~60 of ocml erff -- the exact-erf GELU (HF "gelu") epilogue of the ViT fc1 / bridge GEMMs is VALU-visible otherwise.

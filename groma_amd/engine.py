@@ -14,7 +14,8 @@ import torch
 
 from . import ops
 
-BF16, F32, I32, I64 = torch.bfloat16, torch.float32, torch.int32, torch.int64
+F32, I32, I64 = torch.float32, torch.int32, torch.int64
+H16 = ops.H16  # dtype of the active 16-bit operand type (bf16 / fp16: ops.precision)
 
 
 Q_IN_PLACE = True  # prefill attention reads q (and applies RoPE) straight from the fused QKV projection
@@ -38,6 +39,20 @@ def normal_mode(fn):
         with torch.inference_mode(False), torch.no_grad():
             return fn(*a, **kw)
     return wrapped
+
+
+def model_entry(precision_of):
+    """normal_mode + the model's 16-bit operand type active (ops.precision) for the duration of the call.
+    precision_of(self, *args, **kwargs) -> "bf16" | "fp16"."""
+    import functools
+
+    def deco(fn):
+        @functools.wraps(fn)
+        def wrapped(self, *a, **kw):
+            with torch.inference_mode(False), torch.no_grad(), ops.precision(precision_of(self, *a, **kw)):
+                return fn(self, *a, **kw)
+        return wrapped
+    return deco
 
 
 def inplace_copy(dst, src):
@@ -193,17 +208,17 @@ class VitEngine:
             img.copy_(images)
         else:
             img = images
-        a = ws.get("vit_patch", (bs * G * G, w["Kpad"]), BF16)
+        a = ws.get("vit_patch", (bs * G * G, w["Kpad"]), H16())
         kept = [ws.get(f"vit_h{i}", (bs, T, D), F32) for i in range(self.keep)]
         scratch = [ws.get(f"vit_s{i}", (bs, T, D), F32) for i in range(2)]
         mid = ws.get("vit_mid", (bs, T, D), F32)
-        q = None if Q_IN_PLACE else ws.get("vit_q", (bs, H, T, hd), BF16)
-        k = ws.get("vit_k", (bs, H, Tp, hd), BF16, zero=True)
-        vt = ws.get("vit_vt", (bs, H, hd, Tp), BF16, zero=True)
-        x_b = ws.get("vit_x", (M, D), BF16)
-        qkv_b = ws.get("vit_qkv", (M, 3 * D), BF16)
-        ctx_b = ws.get("vit_ctx", (M, D), BF16)
-        y_b = ws.get("vit_y", (M, I), BF16)
+        q = None if Q_IN_PLACE else ws.get("vit_q", (bs, H, T, hd), H16())
+        k = ws.get("vit_k", (bs, H, Tp, hd), H16(), zero=True)
+        vt = ws.get("vit_vt", (bs, H, hd, Tp), H16(), zero=True)
+        x_b = ws.get("vit_x", (M, D), H16())
+        qkv_b = ws.get("vit_qkv", (M, 3 * D), H16())
+        ctx_b = ws.get("vit_ctx", (M, D), H16())
+        y_b = ws.get("vit_y", (M, I), H16())
 
         def out_buf(layer_out_index):  # hidden_states index (0 = embeddings ... nl = last layer)
             j = layer_out_index - (nl + 1 - self.keep)
@@ -368,15 +383,15 @@ class RegionEngine:
         for l in range(3):
             a = _trace(f"reg.up{l}", ops.upsample_coord_pack(hidden3[l], G, S[l], w["Cpad"]))
             maps.append(_trace(f"reg.in{l}", ops.gemm(a, w["in_w"][l], bias=w["in_b"][l],
-                                                      out=ws.get(f"reg_in{l}", (bs * S[l] * S[l], D), BF16))))
+                                                      out=ws.get(f"reg_in{l}", (bs * S[l] * S[l], D), H16()))))
         for r in range(rc.num_fuse):
             new_maps, new_coef = [], []
             for l in range(3):
                 top, dow = min(l + 1, 2), max(l - 1, 0)
-                pad = ws.get(f"reg_pad{l}", (bs, S[l] + 2, S[l] + 2, D), BF16, zero=True)
+                pad = ws.get(f"reg_pad{l}", (bs, S[l] + 2, S[l] + 2, D), H16(), zero=True)
                 ops.fuse_shuffle((maps[l], sums[l], S[l]), (maps[top], sums[top], S[top]), (maps[dow], sums[dow], S[dow]),
                                  pad, imgs=bs, C=D, shuffle=True, pad=1)
-                out = ws.get(f"reg_conv{l}_{r & 1}", (bs * S[l] * S[l], D), BF16)
+                out = ws.get(f"reg_conv{l}_{r & 1}", (bs * S[l] * S[l], D), H16())
                 ops.gemm(pad, w["fuse"][r]["w"], conv=(bs, S[l], S[l], D, 0), out=out)
                 if r == 0:
                     _trace(f"reg.pad{l}", pad), _trace(f"reg.conv{l}", out)
@@ -386,7 +401,7 @@ class RegionEngine:
             maps, sums = new_maps, new_coef
         feats = []
         for l in range(3):
-            f = ws.get(f"reg_feat{l}", (bs, S[l], S[l], D), BF16)
+            f = ws.get(f"reg_feat{l}", (bs, S[l], S[l], D), H16())
             ops.fuse_shuffle((maps[l], sums[l], S[l]), None, None, f, imgs=bs, C=D, shuffle=False, pad=0)
             if rc.num_fuse == 1:  # then maps[l] is the traced round-0 conv output: feat = ReLU(GN(conv))
                 _trace(f"reg.feat{l}", f)
@@ -399,12 +414,12 @@ class RegionEngine:
         R = boxes.shape[0]
         P = rc.roi_size
         rois = torch.cat([img_idx[:, None], boxes * float(self.img)], dim=1).contiguous()  # (idx, "x1,y1,x2,y2") -- T1
-        tiles = ws.get("reg_tiles", (3, R, P + 2, P + 2, D), BF16, zero=True)
+        tiles = ws.get("reg_tiles", (3, R, P + 2, P + 2, D), H16(), zero=True)
         for l in range(3):
             ops.roi_align_pack(feats[l], rois, tiles[l], C=D, H=S[l], W=S[l], ph=P, pw=P,
                                spatial_scale=1.0 / self.STRIDES[l], sampling_ratio=2, aligned=True, pad=1)
         pc = ops.gemm(tiles, w["pconv_w"], bias=w["pconv_b"], act=2, conv=(R, P, P, D, R * (P + 2) * (P + 2) * D),
-                      out=ws.get("reg_pc", (R * P * P, D), BF16))
+                      out=ws.get("reg_pc", (R * P * P, D), H16()))
         _trace("reg.rois", rois), _trace("reg.tiles", tiles), _trace("reg.pc", pc)
         # pos_embedd(rois) on the UNSCALED cxcywh boxes (roi_align.py:278)
         b16 = torch.zeros((R, 16), dtype=F32, device=boxes.device)
@@ -426,8 +441,8 @@ class KVCache:
     tuple view: cache[l][0].shape == [bs, H, S, hd] (groma/model/groma.py:377-378, groma/serve/model_worker.py:298)."""
 
     def __init__(self, n_layers, bs, H, hd, smax, device):
-        self.k = [torch.zeros((bs, H, smax, hd), dtype=BF16, device=device) for _ in range(n_layers)]
-        self.vt = [torch.zeros((bs, H, hd, smax), dtype=BF16, device=device) for _ in range(n_layers)]
+        self.k = [torch.zeros((bs, H, smax, hd), dtype=H16(), device=device) for _ in range(n_layers)]
+        self.vt = [torch.zeros((bs, H, hd, smax), dtype=H16(), device=device) for _ in range(n_layers)]
         self.seq_len, self.smax, self.bs = 0, smax, bs
         self._addr = None
 
@@ -445,10 +460,10 @@ class KVCache:
         if smax <= self.smax:
             return
         for l in range(len(self.k)):
-            k = torch.zeros((self.bs,) + tuple(self.k[l].shape[1:2]) + (smax, self.k[l].shape[3]), dtype=BF16,
+            k = torch.zeros((self.bs,) + tuple(self.k[l].shape[1:2]) + (smax, self.k[l].shape[3]), dtype=self.k[l].dtype,
                             device=self.k[l].device)
             k[:, :, : self.smax] = self.k[l]
-            v = torch.zeros(tuple(self.vt[l].shape[:3]) + (smax,), dtype=BF16, device=self.k[l].device)
+            v = torch.zeros(tuple(self.vt[l].shape[:3]) + (smax,), dtype=self.vt[l].dtype, device=self.k[l].device)
             v[..., : self.smax] = self.vt[l]
             self.k[l], self.vt[l] = k, v
         self.smax, self._addr = smax, None
@@ -502,10 +517,10 @@ class LlamaEngine:
         def buf(name, shape, dtype):
             return ws.get(name + "_dec", shape, dtype, exact=True) if dec else ws.get(name, shape, dtype)
 
-        q = None if Q_IN_PLACE else buf("llm_q", (bs, H, L, hd), BF16)
+        q = None if Q_IN_PLACE else buf("llm_q", (bs, H, L, hd), H16())
         fp8 = w["fp8"]
-        x_b, qkv_b = buf("llm_x", (M, T), BF16), buf("llm_qkv", (M, 3 * T), BF16)
-        ctx_b, y_b = buf("llm_ctx", (M, T), BF16), buf("llm_y", (M, self.I), BF16)
+        x_b, qkv_b = buf("llm_x", (M, T), H16()), buf("llm_qkv", (M, 3 * T), H16())
+        ctx_b, y_b = buf("llm_ctx", (M, T), H16()), buf("llm_y", (M, self.I), H16())
         # a prefill whose shape and memory repeat is replayed from a captured hipGraph (GraphPool): everything the launches
         # bake in goes into the key; the ragged-row lengths are staged into a buffer of our own
         graph = not dec and not fp8 and TRACE is None and GraphPool.enabled
@@ -592,10 +607,10 @@ class LlamaEngine:
         (csrc/decode.hip): 9 launches per layer instead of 13, and a one-block-per-(row, head) attention."""
         w, ws, T, H, hd = self.w, self.ws, self.T, self.H, self.hd
         dyn = pos_dev is not None
-        x = ws.get("dec_x", (bs, T), BF16, exact=True)
-        q = ws.get("dec_q", (bs, H, 1, hd), BF16, exact=True)
-        ctx = ws.get("dec_ctx", (bs, T), BF16, exact=True)
-        y = ws.get("dec_y", (bs, self.I), BF16, exact=True)
+        x = ws.get("dec_x", (bs, T), H16(), exact=True)
+        q = ws.get("dec_q", (bs, H, 1, hd), H16(), exact=True)
+        ctx = ws.get("dec_ctx", (bs, T), H16(), exact=True)
+        y = ws.get("dec_y", (bs, self.I), H16(), exact=True)
         part, splits = None, 0
         for i, Lw in enumerate(w["layers"]):
             t0 = TRACE is not None and i == 0

@@ -60,11 +60,21 @@ def _box_iou(b1, b2):  # torchvision.ops.box_iou on a handful of host-side boxes
     return inter / (a1[:, None] + a2 - inter)
 
 
+_entry = engine.model_entry(lambda self, *a, **kw: self.precision)  # every boundary entry point: see engine.normal_mode / ops.precision
+
+
 class GromaModel:
     config_class = GromaConfig
 
-    def __init__(self, config: GromaConfig, source=None, device="cuda", fp8=False):
+    def __init__(self, config: GromaConfig, source=None, device="cuda", fp8=False, precision="bf16"):
         self.config = config
+        # 16-bit operand type of the GEMM / attention kernels and of every 16-bit buffer (KV cache, feature maps):
+        # "bf16" (libgroma_hip.so: BASELINE's benchmark dtype) or "fp16" (libgroma_hip_f16.so: what the reference's inference
+        # scripts autocast to, R: groma/eval/run_groma.py:82; same MFMA rate, 3 more mantissa bits).  Accumulation, residual
+        # streams, norms and the proposer are fp32 either way.
+        if precision not in ("bf16", "fp16"):
+            raise ValueError(f"precision must be 'bf16' or 'fp16', got {precision!r}")
+        self.precision = precision
         self.decode_graph = True  # generate(): replay one captured hipGraph per token (False = eager per-kernel launches)
         # proposer chain (input_proj -> DDETR encoder x6 -> two-stage top-300 -> decoder x6 -> heads -> score fusion -> NMS,
         # ~330 launches of fp32 kernels that are launch-latency-bound) captured once per batch size and replayed
@@ -93,6 +103,10 @@ class GromaModel:
 
     # ------------------------------------------------------------------ construction / loading
     def _load(self, source):
+        with ops.precision(self.precision):
+            self._load_packed(source)
+
+    def _load_packed(self, source):
         ops._lib.load()  # fail loudly if the HIP library is missing
         cfg = self.config
         self._ws = engine.Workspace(self.device)
@@ -117,22 +131,25 @@ class GromaModel:
         return c
 
     @classmethod
-    def from_state_dict(cls, config, state_dict, device="cuda", fp8=False):
-        return cls(config, weights.Source.from_state_dict(state_dict, torch.device(device)), device, fp8=fp8)
+    def from_state_dict(cls, config, state_dict, device="cuda", fp8=False, precision="bf16"):
+        return cls(config, weights.Source.from_state_dict(state_dict, torch.device(device)), device, fp8=fp8, precision=precision)
 
     @classmethod
-    def from_synthetic(cls, config, seed=0, device="cuda", fp8=False):
+    def from_synthetic(cls, config, seed=0, device="cuda", fp8=False, precision="bf16"):
         """Random-init weights of the configured architecture, generated on the device (benchmark path)."""
-        return cls(config, weights.Source.synthetic(config, seed, torch.device(device)), device, fp8=fp8)
+        return cls(config, weights.Source.synthetic(config, seed, torch.device(device)), device, fp8=fp8, precision=precision)
 
     @classmethod
     def from_pretrained(cls, path, torch_dtype=None, device="cuda", **kw):
         """Reads a reference checkpoint directory: config.json + *.safetensors / pytorch_model*.bin shards with the
-        reference's parameter names (groma/eval/eval_rec.py:69).  Weights are repacked to bf16 device layouts."""
+        reference's parameter names (groma/eval/eval_rec.py:69).  Weights are repacked to 16-bit device layouts:
+        torch_dtype=torch.float16 (what groma/eval/run_groma.py and the model worker pass) selects the fp16 operand build,
+        anything else bf16; `precision="bf16" | "fp16"` overrides."""
         if torch_dtype not in (None, "auto", torch.float32, torch.float16, torch.bfloat16):
-            raise NotImplementedError(f"torch_dtype={torch_dtype}: the MI355X path computes in bf16 (fp32 accumulate)")
-        # torch_dtype only states how the CALLER would have held the weights (fp32 in eval_rec.py:69, fp16 in run_groma.py):
-        # they are always repacked to bf16 GEMM operands + fp32 norms / biases / proposer
+            raise NotImplementedError(f"torch_dtype={torch_dtype}: the MI355X path computes with bf16 or fp16 operands (fp32 accumulate)")
+        # torch_dtype states how the CALLER would have held the weights (fp32 in eval_rec.py:69, fp16 in run_groma.py): norms,
+        # biases and the proposer stay fp32, the GEMM operands take the 16-bit type
+        precision = kw.get("precision") or ("fp16" if torch_dtype == torch.float16 else "bf16")
         for unsupported in ("load_in_8bit", "load_in_4bit", "quantization_config"):
             if kw.get(unsupported):
                 raise NotImplementedError(f"{unsupported} is not supported by the MI355X path (bf16 / fp32 only)")
@@ -148,7 +165,7 @@ class GromaModel:
                 sd.update(torch.load(f, map_location="cpu"))
         if not sd:
             raise FileNotFoundError(f"no weight shards under {path}")
-        return cls.from_state_dict(config, sd, device, fp8=bool(kw.get("fp8", False)))
+        return cls.from_state_dict(config, sd, device, fp8=bool(kw.get("fp8", False)), precision=precision)
 
     def _same_device(self, device):
         if device is None:
@@ -184,7 +201,7 @@ class GromaModel:
         self.generation_config.pad_token_id = tokenizer.pad_token_id
         return
 
-    @engine.normal_mode
+    @_entry
     def get_input_embeddings(self, input_ids):  # groma/model/groma.py:165-174
         bs, L = input_ids.shape
         return self.llm.embed(input_ids.to(self.device)).view(bs, L, -1)
@@ -204,7 +221,7 @@ class GromaModel:
         return model_inputs
 
     # ------------------------------------------------------------------ stages
-    @engine.normal_mode
+    @_entry
     def perceive(self, images, refer_boxes=None, ground_boxes=None, debug=None):
         """Steps A-E (groma.py:218-280): ViT -> proposer -> NMS -> shuffle.  Returns (hidden4, selected_boxes list of
         device f32 [N_i,4], aux dict)."""
@@ -213,7 +230,7 @@ class GromaModel:
         selected, aux = self.propose(hidden4, refer_boxes, ground_boxes, debug)
         return hidden4, selected, aux
 
-    @engine.normal_mode
+    @_entry
     def propose(self, hidden4, refer_boxes=None, ground_boxes=None, debug=None, seeds=None):
         """Steps C-E: DDETR proposer -> fused scores -> on-device NMS -> host randperm (one D2H of <1 KB/image)."""
         cfg = self.config
@@ -344,7 +361,7 @@ class GromaModel:
         return out, out.ne(self.pad_token_id)
 
     # ------------------------------------------------------------------ forward
-    @engine.normal_mode
+    @_entry
     def forward(self, input_ids=None, inputs_embeds=None, labels=None, attention_mask=None, images=None,
                 refer_boxes=None, ground_boxes=None, past_key_values=None, use_cache=False, output_attentions=False,
                 output_hidden_states=False, return_dict=False, _last_logits_only=False, _reserve=0, _cache=None,
@@ -537,7 +554,7 @@ class GromaModel:
         return GenerateOutput(sequences=seqs, hidden_states=hs, past_key_values=dec.cache)
 
     # ------------------------------------------------------------------ generate (HF 4.32 greedy_search semantics)
-    @engine.normal_mode
+    @_entry
     def generate(self, *a, **kw):
         with ops.gemm_plan(self.gemm_plan):
             return self._generate(*a, **kw)

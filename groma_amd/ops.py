@@ -10,8 +10,30 @@ import torch
 from . import _lib
 from ._lib import GemmDesc
 
-BF16, F32, I32, I64 = torch.bfloat16, torch.float32, torch.int32, torch.int64
+F32, I32, I64 = torch.float32, torch.int32, torch.int64
 FP8 = torch.float8_e4m3fn  # OCP e4m3 (gfx950 native)
+
+
+def H16():
+    """torch dtype of the active 16-bit operand type: bfloat16 (libgroma_hip.so) or float16 (libgroma_hip_f16.so)"""
+    return torch.float16 if _lib.PRECISION[0] == "fp16" else torch.bfloat16
+
+
+class precision:
+    """with ops.precision("fp16"): ...  -- the kernels launched inside come from the library built for that 16-bit operand type
+    and the wrappers allocate / expect the matching torch dtype (re-entrant, restores on exit).  A GromaModel is built for one
+    precision and wraps its entry points in this; "bf16" is the process default."""
+
+    def __init__(self, p):
+        if p not in ("bf16", "fp16"):
+            raise ValueError(f"unknown precision {p!r}")
+        self.p = p
+
+    def __enter__(self):
+        self.prev, _lib.PRECISION[0] = _lib.PRECISION[0], self.p
+
+    def __exit__(self, *a):
+        _lib.PRECISION[0] = self.prev
 
 
 def _stream():
@@ -112,7 +134,7 @@ def gemm(a, w, *, out=None, bias=None, scale=None, resid=None, act=0, out_f32=Fa
         if w_scale is None:
             raise ValueError("fp8 gemm needs w_scale")
     else:
-        _chk(a, BF16, "a"); _chk(w, BF16, "w")
+        _chk(a, H16(), "a"); _chk(w, H16(), "w")
     N, K = w.shape
     d = GemmDesc()
     d.fp8 = int(fp8)
@@ -137,8 +159,8 @@ def gemm(a, w, *, out=None, bias=None, scale=None, resid=None, act=0, out_f32=Fa
         splits = plan_splits(N, K)
     n_out = N // 2 if act == 3 else N
     if out is None:
-        out = torch.empty((M, n_out), dtype=F32 if out_f32 else BF16, device=a.device)
-    _chk(out, F32 if out_f32 else BF16, "out")
+        out = torch.empty((M, n_out), dtype=F32 if out_f32 else H16(), device=a.device)
+    _chk(out, F32 if out_f32 else H16(), "out")
     if splits > 1 and ws is None:
         ws = _split_ws(splits, M, N, a.device)
     d.A, d.W, d.C = a.data_ptr(), w.data_ptr(), out.data_ptr()
@@ -164,13 +186,13 @@ def gemv_partials(a, w, M=None, a_parts=None):
     reduction is left to a fused consumer (decode_reduce_norm / decode_qkv_rope).
     a_parts = (parts, nsplit, hd, M): the operand is the un-merged output of decode_attention(nsplit > 1)."""
     lib = _lib.load()
-    _chk(w, BF16, "w")
+    _chk(w, H16(), "w")
     N, K = w.shape
     if a_parts is not None:
         parts, nsplit, hd, M = a_parts
         _chk(parts, F32, "a_parts")
     else:
-        _chk(a, BF16, "a")
+        _chk(a, H16(), "a")
     if M is None:
         M = a.numel() // a.shape[-1]
     splits = (K + 511) // 512
@@ -187,7 +209,7 @@ def gemv_partials(a, w, M=None, a_parts=None):
 
 def decode_reduce_norm(part, splits, h, gamma, x, eps):
     lib = _lib.load()
-    _chk(h, F32, "h"); _chk(x, BF16, "x")
+    _chk(h, F32, "h"); _chk(x, H16(), "x")
     N = h.shape[-1]
     _lib.check(lib.gr_decode_reduce_norm(_p(part), splits, _p(h), _p(gamma), _p(x), h.numel() // N, N, eps, _stream()),
                "gr_decode_reduce_norm")
@@ -210,7 +232,7 @@ def decode_attention(q, k, vt, out, *, Smax, q_pos0=0, kv_len=None, scale=None, 
     nsplit None = enough key slices per (row, head) to put a block on every CU.  With nsplit > 1 `out` is NOT written:
     the return value is (parts, nsplit, hd, B) for gemv_partials(..., a_parts=...) (the o-proj merges the slices)."""
     lib = _lib.load()
-    _chk(q, BF16, "q"); _chk(k, BF16, "k"); _chk(vt, BF16, "vt"); _chk(out, BF16, "out")
+    _chk(q, H16(), "q"); _chk(k, H16(), "k"); _chk(vt, H16(), "vt"); _chk(out, H16(), "out")
     B, H, _, hd = q.shape
     if scale is None:
         scale = hd ** -0.5
@@ -258,7 +280,7 @@ def layernorm(x, gamma, beta, eps, *, add=None, out_bf16=False, relu_in=False, o
     C = x.shape[-1]
     rows = x.numel() // C
     if out is None:
-        out = torch.empty(x.shape, dtype=BF16 if out_bf16 else F32, device=x.device)
+        out = torch.empty(x.shape, dtype=H16() if out_bf16 else F32, device=x.device)
     _lib.check(lib.gr_layernorm(_p(x), _p(add), _p(gamma), _p(beta), _p(out), rows, C, C, C, eps, int(out_bf16),
                                 int(relu_in), _stream()), "gr_layernorm")
     return out
@@ -270,7 +292,7 @@ def rmsnorm(x, gamma, eps, *, out_bf16=True, out=None):
     C = x.shape[-1]
     rows = x.numel() // C
     if out is None:
-        out = torch.empty(x.shape, dtype=BF16 if out_bf16 else F32, device=x.device)
+        out = torch.empty(x.shape, dtype=H16() if out_bf16 else F32, device=x.device)
     _lib.check(lib.gr_rmsnorm(_p(x), _p(gamma), _p(out), rows, C, C, C, eps, int(out_bf16), _stream()), "gr_rmsnorm")
     return out
 
@@ -280,7 +302,7 @@ def attention(q, k, vt, *, Skv, causal, q_pos0=0, kv_len=None, scale=None, out=N
     """q [B,H,Lq,hd]; k [B,H,kv_stride,hd]; vt [B,H,hd,kv_stride] -> [B*Lq, H*hd].
     pos_dev (i32 device tensor): row b attends keys [0, pos_dev[b*pos_stride] + Lq) -- device-resident decode position."""
     lib = _lib.load()
-    _chk(q, BF16, "q"); _chk(k, BF16, "k"); _chk(vt, BF16, "vt")
+    _chk(q, H16(), "q"); _chk(k, H16(), "k"); _chk(vt, H16(), "vt")
     q_ld, cos, sin = 0, None, None
     if fused is not None:  # q = the fused projection buffer [B*Lq, ld]; fused = dict(B, H, Lq, hd, cos=None, sin=None)
         B, H, Lq, hd = fused["B"], fused["H"], fused["Lq"], fused["hd"]
@@ -291,7 +313,7 @@ def attention(q, k, vt, *, Skv, causal, q_pos0=0, kv_len=None, scale=None, out=N
     if scale is None:
         scale = hd ** -0.5
     if out is None:
-        out = torch.empty((B * Lq, H * hd), dtype=BF16, device=q.device)
+        out = torch.empty((B * Lq, H * hd), dtype=H16(), device=q.device)
     if kv_len is not None:
         _chk(kv_len, I32, "kv_len")
     if pos_dev is not None:
@@ -305,7 +327,7 @@ def attention(q, k, vt, *, Skv, causal, q_pos0=0, kv_len=None, scale=None, out=N
 def qkv_split(qkv, q, k, vt, *, B, H, L, hd, pos0=0, cos=None, sin=None, pos_dev=None, pos_stride=0):
     """q=None: only k / v^T are written (attention(fused=...) reads q from qkv)"""
     lib = _lib.load()
-    _chk(qkv, BF16, "qkv")
+    _chk(qkv, H16(), "qkv")
     if pos_dev is not None:
         _chk(pos_dev, I32, "pos_dev")
     _lib.check(lib.gr_qkv_split(_p(qkv), _p(q), _p(k), _p(vt), _p(cos), _p(sin), B, H, L, hd, pos0, k.shape[2],
@@ -318,8 +340,8 @@ def patchify(images, P, Kpad, out=None):
     B, _, S, _ = images.shape
     G = S // P
     if out is None:
-        out = torch.empty((B * G * G, Kpad), dtype=BF16, device=images.device)
-    _chk(out, BF16, "out")
+        out = torch.empty((B * G * G, Kpad), dtype=H16(), device=images.device)
+    _chk(out, H16(), "out")
     _lib.check(lib.gr_patchify(_p(images), _p(out), B, S, P, Kpad, _stream()), "gr_patchify")
     return out
 
@@ -340,7 +362,7 @@ def mean4_tokens(h0, h1, h2, h3):
 def s2d_pack(h, G):
     lib = _lib.load()
     B, T, C = h.shape
-    out = torch.empty((B * (G // 2) ** 2, 4 * C), dtype=BF16, device=h.device)
+    out = torch.empty((B * (G // 2) ** 2, 4 * C), dtype=H16(), device=h.device)
     _lib.check(lib.gr_s2d_pack(_p(h), _p(out), B, G, C, _stream()), "gr_s2d_pack")
     return out
 
@@ -348,7 +370,7 @@ def s2d_pack(h, G):
 def upsample_coord_pack(h, G, Ho, Cpad):
     lib = _lib.load()
     B, T, C = h.shape
-    out = torch.empty((B * Ho * Ho, Cpad), dtype=BF16, device=h.device)
+    out = torch.empty((B * Ho * Ho, Cpad), dtype=H16(), device=h.device)
     _lib.check(lib.gr_upsample_coord_pack(_p(h), _p(out), B, G, Ho, C, Cpad, _stream()), "gr_upsample_coord_pack")
     return out
 
@@ -377,7 +399,7 @@ def fuse_shuffle(tar, top, down, out, *, imgs, C, shuffle, pad):
 def cast_bf16(a, b=None):
     lib = _lib.load()
     _chk(a, F32, "a")
-    out = torch.empty(a.shape, dtype=BF16, device=a.device)
+    out = torch.empty(a.shape, dtype=H16(), device=a.device)
     _lib.check(lib.gr_cast_f32_bf16(_p(a), _p(b), _p(out), a.numel(), _stream()), "gr_cast_f32_bf16")
     return out
 
@@ -577,7 +599,7 @@ def roi_align_forward(input, rois, output, argmax_y, argmax_x, aligned_height, a
 def roi_align_pack(feat_nhwc, rois, out, *, C, H, W, ph, pw, spatial_scale, sampling_ratio, aligned=True, pad=1,
                    out_f32=False):
     lib = _lib.load()
-    _chk(feat_nhwc, BF16, "feat"); _chk(rois, F32, "rois")
+    _chk(feat_nhwc, H16(), "feat"); _chk(rois, F32, "rois")
     _lib.check(lib.gr_roi_align_pack(_p(feat_nhwc), _p(rois), _p(out), rois.shape[0], C, H, W, ph, pw, spatial_scale,
                                      sampling_ratio, int(aligned), pad, int(out_f32), _stream()), "gr_roi_align_pack")
     return out

@@ -101,7 +101,7 @@ class _RowView:
 
 
 class ContinuousBatcher:
-    @engine.normal_mode
+    @engine.model_entry(lambda self, *a, **kw: (a[0] if a else kw["model"]).precision)
     def __init__(self, model, max_rows=8, max_len=1024, use_graph=True):
         if max_rows < 1 or max_rows > 8:
             raise ValueError("max_rows must be in 1..8 (decode GEMV row block)")
@@ -243,7 +243,7 @@ class ContinuousBatcher:
             r.slot = None
 
     # ------------------------------------------------------------------ scheduler tick
-    @engine.normal_mode
+    @engine.model_entry(lambda self, *a, **kw: self.model.precision)
     def step(self):
         """Admit what fits, then advance every occupied row by one token.  Returns [(rid, token, done), ...]."""
         if self.use_graph and self.graph is None:

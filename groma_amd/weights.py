@@ -9,7 +9,9 @@ import math
 import torch
 import torch.nn.functional as F
 
-BF16, F32 = torch.bfloat16, torch.float32
+from .ops import H16  # dtype of the active 16-bit operand type (the model being built sets ops.precision around packing)
+
+F32 = torch.float32
 
 
 def _ru(x, m):
@@ -51,7 +53,7 @@ class Source:
 
 
 def bf(t):
-    return t.to(BF16).contiguous()
+    return t.to(H16()).contiguous()
 
 
 FP8 = torch.float8_e4m3fn
@@ -254,9 +256,9 @@ def pack_llm(W, cfg, fp8=False):
     out["norm"] = W("llm.model.norm.weight")
     V = lc.vocab_size + cfg.num_new_token
     Vp = _ru(V, 128)
-    head = torch.zeros((Vp, T), dtype=BF16, device=W.device)
-    head[: lc.vocab_size] = W("llm.lm_head.weight").to(BF16)
-    head[lc.vocab_size: V] = W("extra_lm_head.weight").to(BF16)
+    head = torch.zeros((Vp, T), dtype=H16(), device=W.device)
+    head[: lc.vocab_size] = W("llm.lm_head.weight").to(H16())
+    head[lc.vocab_size: V] = W("extra_lm_head.weight").to(H16())
     out["head"], out["V"], out["Vpad"] = head, V, Vp
     hd = T // lc.num_attention_heads
     inv = 1.0 / (lc.rope_theta ** (torch.arange(0, hd, 2, dtype=F32) / hd))

@@ -12,6 +12,12 @@
  *     launch (the reference raises RuntimeError via TORCH_CHECK; the Python host maps non-zero to
  *     RuntimeError the same way).
  * bf16 tensors are raw uint16 bit patterns; "f32" = IEEE binary32.  All row-major.
+ *
+ * Two builds of this ABI exist, from the same sources: libgroma_hip.so, whose 16-bit operand type is bfloat16, and
+ * libgroma_hip_f16.so (-DGR_F16), whose 16-bit operand type is IEEE binary16 -- the dtype the reference's own inference entry
+ * points autocast to (groma/eval/run_groma.py:82, groma/serve/model_worker.py:256).  In the second build every parameter this
+ * header calls "bf16" holds half bit patterns (conversions saturate at +-65504); names and signatures are identical, and
+ * gr_operand_type() tells a host which build it has loaded.
  */
 #ifndef GROMA_HIP_H
 #define GROMA_HIP_H
@@ -26,8 +32,12 @@ extern "C" {
 typedef struct ihipStream_t* hipStream_t;
 #endif
 
-#define GROMA_HIP_ABI_VERSION 5
+#define GROMA_HIP_ABI_VERSION 6
 int gr_abi_version(void);
+#define GR_OPERAND_BF16 0
+#define GR_OPERAND_F16 1
+/* the 16-bit operand type this build of the library was compiled for */
+int gr_operand_type(void);
 /* kernel timing hook used by bench.py: when enabled, every gr_gemm_bf16 launch is bracketed by HIP
  * events on its own stream; gr_prof_read drains them (sync) and returns total ms + launch count. */
 int gr_prof_enable(int on);

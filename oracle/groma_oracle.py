@@ -44,10 +44,11 @@ _ROUND = [None]
 
 
 class rounding:
-    """with rounding("bf16"): ...   -- evaluate the oracle with bf16-rounded operands (None = pure fp32)."""
+    """with rounding("bf16"): ...   -- evaluate the oracle with bf16-rounded operands (None = pure fp32).
+    "fp16": the same rounding points with IEEE half (the fp16 operand build of the device library, libgroma_hip_f16.so)."""
 
     def __init__(self, mode):
-        assert mode in (None, "bf16", "e4m3")
+        assert mode in (None, "bf16", "e4m3", "fp16")
         self.mode = mode
 
     def __enter__(self):
@@ -58,7 +59,9 @@ class rounding:
 
 
 def _r(x):
-    return x if _ROUND[0] is None else x.to(torch.bfloat16).to(torch.float32)
+    if _ROUND[0] is None:
+        return x
+    return x.to(torch.float16 if _ROUND[0] == "fp16" else torch.bfloat16).to(torch.float32)
 
 
 # "e4m3" mode (BASELINE configs[4]): everything of the bf16 mode, plus the DINOv2 / LLaMA linears evaluated with OCP e4m3

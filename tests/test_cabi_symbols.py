@@ -18,11 +18,13 @@ def test_header_symbols_are_exported_and_typed():
     from groma_amd import _lib
     names = _declared()
     assert len(names) >= 25
-    lib = ctypes.CDLL(_lib.LIB_PATH)
-    for n in names:
-        assert hasattr(lib, n), f"{n} declared in include/groma_hip.h but not exported"
+    for path in (_lib.LIB_PATH, _lib.LIB_PATH_F16):   # the two builds of the one ABI (bf16 / fp16 operands)
+        lib = ctypes.CDLL(path)
+        for n in names:
+            assert hasattr(lib, n), f"{n} declared in include/groma_hip.h but not exported by {path}"
     assert set(names) == set(_lib.SIGNATURES), "ctypes signature table out of sync with the header"
-    assert _lib.load().gr_abi_version() == 5
+    assert _lib.load().gr_abi_version() == 6 and _lib.load().gr_operand_type() == 0
+    assert _lib.load("fp16").gr_abi_version() == 6 and _lib.load("fp16").gr_operand_type() == 1
 
 
 def test_bad_arguments_are_rejected_without_a_gpu():
