@@ -296,7 +296,7 @@ def measure(model, cfg, args, dev, rank, job, P, gen, batch, plan="throughput", 
 def extras_block(model, cfg, args, dev, P):
     """Secondary lines measured in the SAME run, after (outside) the headline's timed region, N = 1 only: the small-batch
     forward (SURVEY 8d configs[2] at 1 and 4 images per call), configs[3]'s per-GPU share (greedy generate, 4 images, 32 new
-    tokens) and configs[4] (e4m3 operands).  Each is its own ShardedJob.timed() with its own warm-up."""
+    tokens), configs[4] (e4m3 operands) and the fp16 operand build.  Each is its own ShardedJob.timed() with its own warm-up."""
     from groma_amd import constants, dist as gdist
     from groma_amd.groma import GromaModel
     ex = {}
@@ -328,6 +328,13 @@ def extras_block(model, cfg, args, dev, P):
     ex["forward_fp8"] = f8
     del m8
     torch.cuda.empty_cache()
+    m16 = GromaModel.from_synthetic(cfg, seed=0, device=dev, precision="fp16")
+    m16.init_special_token_id(constants.SyntheticTokenizer())
+    f16 = line(m16, args.batch, False, steps=5, warmup=3)
+    f16["dtype"] = "fp16 (IEEE half operands through libgroma_hip_f16.so, f32 accumulate: the reference's inference autocast dtype)"
+    ex["forward_fp16"] = f16
+    del m16
+    torch.cuda.empty_cache()
     return ex
 
 
@@ -339,9 +346,10 @@ def main():
                     help="untimed steps (3 or more: a prefill graph is captured the third time its shape is seen)")
     ap.add_argument("--batch", type=int, default=14, help="images per GPU per step (14*582 = 8148 rows ~ 32 GEMM row-tiles of 256)")
     ap.add_argument("--config", default="7b", choices=["7b", "tiny"])
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp8"],
-                    help="GEMM operand type of the DINOv2/LLaMA linears.  bf16 is the headline (the reference's precision); "
-                         "fp8 = OCP e4m3 operands + f32 accumulate (BASELINE configs[4] extension, reported as dtype fp8)")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16", "fp8"],
+                    help="GEMM operand type of the DINOv2/LLaMA linears.  bf16 is the headline (BASELINE's precision); fp16 = the "
+                         "IEEE-half build of the same kernels (libgroma_hip_f16.so: the reference's own inference autocast dtype, "
+                         "same MFMA rate); fp8 = OCP e4m3 operands + f32 accumulate (BASELINE configs[4] extension)")
     ap.add_argument("--mode", default="forward", choices=["forward", "generate"],
                     help="forward = the headline prefill metric (BASELINE configs[2]); generate = configs[3]: greedy decoding "
                          "of --new-tokens tokens per image at --batch images per GPU (use --batch 4), HBM-bound decode steps")
@@ -398,7 +406,9 @@ def main():
 
     cfg = gconfig.groma_7b(box_score_thres=0.0) if args.config == "7b" else gconfig.groma_tiny(box_score_thres=0.0)
     fp8 = args.dtype == "fp8"
-    model = GromaModel.from_synthetic(cfg, seed=0, device=dev, fp8=fp8)
+    precision = "fp16" if args.dtype == "fp16" else "bf16"
+    ops._lib.PRECISION[0] = precision  # process default = the headline model's library (the HIP-event hook below is per library)
+    model = GromaModel.from_synthetic(cfg, seed=0, device=dev, fp8=fp8, precision=precision)
     model.init_special_token_id(constants.SyntheticTokenizer())
     P = 128
     gen = args.mode == "generate"
@@ -521,7 +531,7 @@ def main():
                            "bytes_per_launch": gv_bytes / max(len(gv), 1),
                            "kernel_time_share_of_step": (gv_ms / args.steps) / (elapsed / args.steps * 1e3)}
     if rank == 0:
-        if world == 1 and not args.no_extras and not gen and not fp8:
+        if world == 1 and not args.no_extras and not gen and args.dtype == "bf16":
             try:
                 out["extras"] = extras_block(model, cfg, args, dev, P)
             except Exception as e:  # an extra never takes the headline down

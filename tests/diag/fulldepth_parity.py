@@ -42,21 +42,23 @@ class LazyDeviceStateDict:
         return self[k] if k in self._names else default
 
 
-def run(seed=0):
-    """-> dict of the measured numbers (also printed)"""
+def run(seed=0, precision="bf16"):
+    """-> dict of the measured numbers (also printed).  precision: the 16-bit operand type of the device model AND of the
+    rounded oracle it is compared with ("bf16" | "fp16")"""
     torch.set_num_threads(min(64, os.cpu_count() or 8))
     full = gconfig.groma_7b(box_score_thres=0.0)
     dev = torch.device("cuda")
     tk = util.TokenIds()
     images, ids = synth.make_inputs(full, tk, 1, seed=1234)
     t = time.time()
-    model = GromaModel.from_synthetic(full, seed=seed, device=dev)
+    model = GromaModel.from_synthetic(full, seed=seed, device=dev, precision=precision)
     model.init_special_token_id(constants.SyntheticTokenizer())
     sd = LazyDeviceStateDict(full, seed, dev)
     # spot check: the lazy dict serves exactly what the device model packed (distinct per layer)
     a, b = sd["llm.model.layers.0.mlp.down_proj.weight"], sd["llm.model.layers.31.mlp.down_proj.weight"]
-    assert not torch.equal(a, b) and torch.equal(a.to(torch.bfloat16), model.llm.w["layers"][0]["wd"][0].cpu())
-    assert torch.equal(b.to(torch.bfloat16), model.llm.w["layers"][31]["wd"][0].cpu())
+    h16 = torch.float16 if precision == "fp16" else torch.bfloat16
+    assert not torch.equal(a, b) and torch.equal(a.to(h16), model.llm.w["layers"][0]["wd"][0].cpu())
+    assert torch.equal(b.to(h16), model.llm.w["layers"][31]["wd"][0].cpu())
     print(f"device model (distinct per-layer weights) packed in {time.time() - t:.1f} s")
     rel = util.relerr
     cd = full.to_dict()
@@ -66,14 +68,14 @@ def run(seed=0):
         aux = model._last_aux
         dev_h = [h.float().cpu() for h in aux["hidden4"]]
         ref, ref_v = {}, {}
-        for mode in (None, "bf16"):
+        for mode in (None, precision):
             t = time.time()
             with O.rounding(mode):
                 ref_v[mode] = O.vit_forward(sd, cd, images)[-4:]
                 torch.manual_seed(77)
                 ref[mode] = O.groma_forward(sd, cd, util.tok_dict(tk), ids.clone(), images, hidden_states=tuple(dev_h))
-            print(f"oracle ({'fp32' if mode is None else 'bf16-rounded'}): 24-layer ViT + proposer + region encoder + 32-layer LLaMA in {time.time() - t:.1f} s")
-    r32, r16 = ref[None], ref["bf16"]
+            print(f"oracle ({'fp32' if mode is None else precision + '-rounded'}): 24-layer ViT + proposer + region encoder + 32-layer LLaMA in {time.time() - t:.1f} s")
+    r32, r16 = ref[None], ref[precision]
     eq = dict(topk_equal=torch.equal(aux["topk_idx"].cpu().long(), r32["det"]["topk_idx"]),
               nms_equal=torch.equal(aux["nms_keep"][0], r32["nms_inds"][0]),
               ids_equal=torch.equal(aux["input_ids"], r32["input_ids"]) and torch.equal(r16["input_ids"], r32["input_ids"]))
@@ -83,12 +85,12 @@ def run(seed=0):
 
     def three(name, d, f):
         a, b, c = rel(d, f(r32)), rel(d, f(r16)), rel(f(r16), f(r32))
-        print(f"{name:42s} device<->fp32 {a:.3e} | device<->bf16-rounded {b:.3e} | bf16-rounded<->fp32 {c:.3e} | ratio {a / c:.2f}")
+        print(f"{name:42s} device<->fp32 {a:.3e} | device<->{precision}-rounded {b:.3e} | {precision}-rounded<->fp32 {c:.3e} | ratio {a / c:.2f}")
         return a, b, c
     res = {}
-    res["vit"] = [(rel(a, b), rel(a, c), rel(c, b)) for a, b, c in zip(dev_h, ref_v[None], ref_v["bf16"])]
+    res["vit"] = [(rel(a, b), rel(a, c), rel(c, b)) for a, b, c in zip(dev_h, ref_v[None], ref_v[precision])]
     for i, (a, b, c) in enumerate(res["vit"]):
-        print(f"{'ViT state ' + str(21 + i) + ' layers deep':42s} device<->fp32 {a:.3e} | device<->bf16-rounded {b:.3e} | bf16-rounded<->fp32 {c:.3e} | ratio {a / c:.2f}")
+        print(f"{'ViT state ' + str(21 + i) + ' layers deep':42s} device<->fp32 {a:.3e} | device<->{precision}-rounded {b:.3e} | {precision}-rounded<->fp32 {c:.3e} | ratio {a / c:.2f}")
     res["image_tokens"] = three("image tokens (s2d + bridge)", vis["image_features"], lambda r: r["image_features"])
     res["region_tokens"] = three("region tokens (5 fusion rounds + RoI)", vis["region_features"], lambda r: r["region_features"])
     res["k0"] = three("K cache layer 0", out.past_key_values[0][0], lambda r: r["past"][0][0])
@@ -103,7 +105,7 @@ def run(seed=0):
     agree = (lg_d.argmax(-1) == lg_r.argmax(-1))
     agree16 = (r16["logits"].argmax(-1) == lg_r.argmax(-1))
     print(f"logits max abs err {err:.3e} (max |logit| {lg_r.abs().max().item():.2f}); arg-max equal to the fp32 oracle's at {agree.float().mean().item():.3f} of "
-          f"positions (bf16-rounded oracle: {agree16.float().mean().item():.3f}), at {agree[clear].float().mean().item() if clear.any() else float('nan'):.3f} of the "
+          f"positions ({precision}-rounded oracle: {agree16.float().mean().item():.3f}), at {agree[clear].float().mean().item() if clear.any() else float('nan'):.3f} of the "
           f"{clear.float().mean().item():.3f} clear-margin positions")
     print(f"host bytes served by the lazy state dict: {sd.bytes_served / 1e9:.1f} GB")
     res.update(eq, argmax_agree=agree.float().mean().item(), argmax_agree_bf16_oracle=agree16.float().mean().item(),
@@ -112,4 +114,4 @@ def run(seed=0):
 
 
 if __name__ == "__main__":
-    run()
+    run(precision=sys.argv[1] if len(sys.argv) > 1 else "bf16")
