@@ -221,3 +221,26 @@ def test_gemm_plan_is_a_function_of_the_layer_shape_only():
     import pytest
     with pytest.raises(ValueError):
         ops.gemm_plan("auto")
+
+
+def test_precision_context_selects_library_and_dtype():
+    """ops.precision(): the 16-bit operand type is a (library, torch dtype) pair switched together, re-entrant, restored on exit"""
+    import pytest
+    from groma_amd import _lib, config, ops
+    from groma_amd.groma import GromaModel
+    assert ops.H16() == torch.bfloat16 and _lib.load() is _lib.load("bf16")
+    with ops.precision("fp16"):
+        assert ops.H16() == torch.float16 and _lib.load() is _lib.load("fp16")
+        with ops.precision("bf16"):
+            assert ops.H16() == torch.bfloat16
+        assert ops.H16() == torch.float16
+        with pytest.raises(RuntimeError):
+            with ops.precision("bf16"):
+                raise RuntimeError("x")
+        assert ops.H16() == torch.float16
+    assert ops.H16() == torch.bfloat16
+    with pytest.raises(ValueError):
+        ops.precision("fp8")
+    with pytest.raises(ValueError):
+        GromaModel(config.groma_tiny(), precision="half")
+    assert GromaModel(config.groma_tiny(), precision="fp16").precision == "fp16"
