@@ -273,10 +273,10 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(AttnArgs p) {
         // P^T as the B operand; k-slot (fg,e) <-> key 32*tt + fg*8 + e (standard contiguous slot)
 #pragma unroll
         for (int tt = 0; tt < 2; ++tt) {
-          pb[u][tt].w[0] = pack2bf(s[u][2 * tt][0], s[u][2 * tt][1]);
-          pb[u][tt].w[1] = pack2bf(s[u][2 * tt][2], s[u][2 * tt][3]);
-          pb[u][tt].w[2] = pack2bf(s[u][2 * tt + 1][0], s[u][2 * tt + 1][1]);
-          pb[u][tt].w[3] = pack2bf(s[u][2 * tt + 1][2], s[u][2 * tt + 1][3]);
+          pb[u][tt].w[0] = pack2bf_unit(s[u][2 * tt][0], s[u][2 * tt][1]);
+          pb[u][tt].w[1] = pack2bf_unit(s[u][2 * tt][2], s[u][2 * tt][3]);
+          pb[u][tt].w[2] = pack2bf_unit(s[u][2 * tt + 1][0], s[u][2 * tt + 1][1]);
+          pb[u][tt].w[3] = pack2bf_unit(s[u][2 * tt + 1][2], s[u][2 * tt + 1][3]);
         }
       }
     };

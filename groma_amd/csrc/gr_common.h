@@ -29,6 +29,11 @@ __device__ __forceinline__ uint32_t pack2bf(float a, float b) {
   const h16x2_hw v = {(_Float16)sat_h16(a), (_Float16)sat_h16(b)};
   return __builtin_bit_cast(uint32_t, v);
 }
+// for values known to lie in [0, 1] (soft-max probabilities): no saturation needed
+__device__ __forceinline__ uint32_t pack2bf_unit(float a, float b) {
+  const h16x2_hw v = {(_Float16)a, (_Float16)b};
+  return __builtin_bit_cast(uint32_t, v);
+}
 #define GR_MFMA_16x16x32(a, b, c) \
   __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h16x8_hw, a), __builtin_bit_cast(h16x8_hw, b), c, 0, 0, 0)
 #else
@@ -44,6 +49,7 @@ __device__ __forceinline__ uint32_t pack2bf(float a, float b) {
   const bf16x2_hw v = {(__bf16)a, (__bf16)b};
   return __builtin_bit_cast(uint32_t, v);
 }
+__device__ __forceinline__ uint32_t pack2bf_unit(float a, float b) { return pack2bf(a, b); }
 #define GR_MFMA_16x16x32(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0)
 #endif
 
