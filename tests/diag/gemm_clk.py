@@ -1,17 +1,23 @@
-"""Run with GROMA_HIP_LIB=tests/diag/libgroma_hip_clk.so: shader clock + per-tile phase times of the 256x256 GEMM."""
+"""Run with GROMA_HIP_LIB=tests/diag/libgroma_hip_clk.so: shader clock + per-tile phase times of the 256x256 GEMM.
+GROMA_CLK_PRECISION=fp16 GROMA_HIP_LIB=tests/diag/libgroma_hip_clk_f16.so: the same for the IEEE-half build."""
 import ctypes, os, sys
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__))); import _variant; _variant.use_env()
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__))); import _variant
 import torch
 from groma_amd import ops, _lib
+F16 = os.environ.get("GROMA_CLK_PRECISION") == "fp16"
+if F16:
+    _lib.LIB_PATH_F16, _lib.PRECISION[0] = os.path.abspath(os.environ["GROMA_HIP_LIB"]), "fp16"
+else:
+    _variant.use_env()
 
 lib = _lib.load()
 lib.gr_diag_clk.argtypes = [ctypes.c_void_p]
 buf = (ctypes.c_ulonglong * 40)()
 for (M, N, K) in [(256, 256, 2048), (256, 256, 8192), (256, 2048, 4096), (2048, 2048, 8192), (8192, 8192, 8192)]:
-    a = (torch.randn((M, K), device="cuda") * 0.5).bfloat16()
-    w = (torch.randn((N, K), device="cuda") * 0.5).bfloat16()
-    out = torch.empty((M, N), device="cuda", dtype=torch.bfloat16)
+    a = (torch.randn((M, K), device="cuda") * 0.5).to(ops.H16())
+    w = (torch.randn((N, K), device="cuda") * 0.5).to(ops.H16())
+    out = torch.empty((M, N), device="cuda", dtype=ops.H16())
     for _ in range(3):
         ops.gemm(a, w, out=out, tile=256)
     torch.cuda.synchronize()
