@@ -244,3 +244,83 @@ def test_precision_context_selects_library_and_dtype():
     with pytest.raises(ValueError):
         GromaModel(config.groma_tiny(), precision="half")
     assert GromaModel(config.groma_tiny(), precision="fp16").precision == "fp16"
+
+
+def test_graph_pool_policy(monkeypatch):
+    """engine.GraphPool without a GPU (the graph objects are faked): eager on the first two sightings of a key, capture + replay on
+    the third, replay afterwards; the pool keeps `cap` graphs and an evicted key starts counting again; disabled / traced runs
+    launch eagerly and leave the pool alone."""
+    import contextlib
+    from groma_amd import engine
+
+    log = []
+
+    class FakeGraph:
+        def __init__(self):
+            self.fn = None
+
+        def replay(self):
+            log.append("replay")
+            if self.fn is not None:
+                self.fn()
+
+    @contextlib.contextmanager
+    def fake_capture(g):
+        log.append("capture")
+        g.capturing = True
+        yield
+        g.capturing = False
+
+    monkeypatch.setattr(torch.cuda, "CUDAGraph", FakeGraph)
+    monkeypatch.setattr(torch.cuda, "graph", fake_capture)
+    monkeypatch.setattr(torch.cuda, "synchronize", lambda *a, **k: None)
+    monkeypatch.setattr(torch.cuda, "is_current_stream_capturing", lambda: False)
+    pool = engine.GraphPool(cap=2)
+    runs = []
+
+    def mk(tag):
+        def launch():
+            runs.append(tag)
+        return launch
+
+    # the fake "graph" records nothing, so give replay something to call: wrap run() the way the real capture would
+    real_run = pool.run
+
+    def run(key, launch):
+        real_run(key, launch)
+        g = pool._graphs.get(key)
+        if g is not None and g.fn is None:
+            g.fn = launch
+    for i in range(5):
+        run("a", mk("a"))
+    # sightings 1, 2: eager; 3: captured (launch runs once under the fake capture) then replayed; 4, 5: replayed
+    assert log == ["capture", "replay", "replay", "replay"] and pool.captures == 1 and pool.replays == 2
+    assert runs.count("a") == 2 + 1 + 2          # (the real capture records instead of running; the first replay of the fake is empty)
+    for k in ("b", "c"):
+        for _ in range(3):
+            run(k, mk(k))
+    assert pool.captures == 3 and list(pool._graphs) == ["b", "c"]      # "a" was evicted (cap = 2, least recently used)
+    log.clear()
+    run("a", mk("a"))
+    assert log == [] and "a" not in pool._graphs                         # counts from one again
+    run("b", mk("b"))
+    assert log == ["replay"]
+    # disabled / traced: eager, no bookkeeping
+    monkeypatch.setattr(engine.GraphPool, "enabled", False)
+    n = len(runs)
+    run("b", mk("b"))
+    assert len(runs) == n + 1 and log == ["replay"]
+    monkeypatch.setattr(engine.GraphPool, "enabled", True)
+    monkeypatch.setattr(engine, "TRACE", {})
+    run("b", mk("b"))
+    assert log == ["replay"]
+    monkeypatch.setattr(engine, "TRACE", None)
+    # a key is everything baked into the launches: cache_addresses() changes when a cache grows
+    class C:
+        pass
+    c = C()
+    c.smax, c.k, c.vt = 64, [torch.zeros(4)], [torch.zeros(4)]
+    a0 = engine.cache_addresses(c)
+    assert engine.cache_addresses(c) is a0
+    c._addr, c.smax = None, 128
+    assert engine.cache_addresses(c) != a0
