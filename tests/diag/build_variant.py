@@ -1,18 +1,21 @@
-"""Build the product library with extra -D flags into tests/diag/<name>.so (A/B experiments in ONE gpurun call via
-GROMA_HIP_LIB=...).  usage: python tests/diag/build_variant.py name -DFOO=1 -DBAR=2"""
+"""Build a named variant of the product library for a one-box A/B: the product objects, with gemm_bf16_256.hip (and whatever else
+is listed) recompiled with extra -D flags.   python tests/diag/build_variant.py <name> -DFLAG [-DFLAG2 ...]  ->  tests/diag/<name>.so
+(load it with GROMA_HIP_LIB=tests/diag/<name>.so in the tests/diag scripts; never used by tests/ or bench.py)"""
 import os, subprocess, sys, tempfile
-from concurrent.futures import ThreadPoolExecutor
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 from groma_amd.csrc import build as B
-name, defs = sys.argv[1], sys.argv[2:]
-out = os.path.join(os.path.dirname(os.path.abspath(__file__)), name + ".so")
+
+name, flags = sys.argv[1], sys.argv[2:]
+B.build(verbose=False)
+here = os.path.dirname(os.path.abspath(__file__))
 tmp = tempfile.mkdtemp()
-jobs, objs = [], []
+objs = []
 for src, extra in B.SOURCES.items():
-    o = os.path.join(tmp, src.replace(".hip", ".o"))
+    o = os.path.join(B.HERE, src.replace(".hip", ".o"))
+    if src in ("gemm_bf16_256.hip", "gemm_bf16.hip"):   # gemm_bf16.hip includes the 256 kernel's launch path
+        o = os.path.join(tmp, src.replace(".hip", ".o"))
+        subprocess.check_call(["hipcc"] + B.COMMON + extra + flags + ["-c", os.path.join(B.HERE, src), "-o", o])
     objs.append(o)
-    jobs.append(["hipcc"] + B.COMMON + extra + defs + ["-c", os.path.join(B.HERE, src), "-o", o])
-with ThreadPoolExecutor(8) as ex:
-    list(ex.map(subprocess.check_call, jobs))
+out = os.path.join(here, name + ".so")
 subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs)
 print(out)
