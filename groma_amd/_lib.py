@@ -1,16 +1,19 @@
-"""ctypes binding of libgroma_hip.so / libgroma_hip_f16.so (include/groma_hip.h: one ABI, two 16-bit operand types).
+"""ctypes binding of libgroma_hip.so / libgroma_hip_f16.so / libgroma_hip_ref.so (include/groma_hip.h: one ABI, three operand
+storage types -- bfloat16, IEEE half, and (hi, lo) pairs of halves for the reference-precision path).
 
 The product path has NO fallback: if the HIP library is missing or an op returns non-zero we raise.
 (The reference raises RuntimeError from TORCH_CHECK inside mmcv `_ext`; same error class here.)
 """
 import ctypes
 import os
+import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # The one library the product loads.  (Measurement scripts under tests/diag that A/B another build assign
 # `groma_amd._lib.LIB_PATH = ...` before the first load -- tests/diag/_variant.py; the product reads no environment switch.)
 LIB_PATH = os.path.join(_HERE, "csrc", "libgroma_hip.so")
 LIB_PATH_F16 = os.path.join(_HERE, "csrc", "libgroma_hip_f16.so")
+LIB_PATH_REF = os.path.join(_HERE, "csrc", "libgroma_hip_ref.so")
 
 c_void_p = ctypes.c_void_p
 c_int = ctypes.c_int
@@ -89,7 +92,27 @@ SIGNATURES = {
 
 _lib = None       # the bf16 build (kept under this name: tests monkeypatch it)
 _lib_f16 = None
-PRECISION = ["bf16"]  # the active 16-bit operand type: "bf16" | "fp16" (ops.precision() switches it around a model's calls)
+_lib_ref = None
+
+
+class ThreadSlot:
+    """A one-element list whose element is PER THREAD (slot[0] reads / writes the calling thread's value; a thread that never
+    wrote sees the default).  The reference's model worker serves from threads (R: groma/serve/model_worker.py): the active operand
+    type and GEMM plan are switched by context managers around a model's entry points, and two models of different precision
+    used from two threads must not see each other's switch."""
+
+    def __init__(self, default):
+        self._default, self._tl = default, threading.local()
+
+    def __getitem__(self, i):
+        return getattr(self._tl, "v", self._default)
+
+    def __setitem__(self, i, v):
+        self._tl.v = v
+
+
+# the active operand storage type: "bf16" | "fp16" | "ref" (ops.precision() switches it around a model's calls)
+PRECISION = ThreadSlot("bf16")
 
 
 def _open(path, operand):
@@ -111,7 +134,7 @@ def _open(path, operand):
 
 def load(precision=None):
     """The library of the active (or given) operand type, loaded and typed on first use.  Raises if anything is missing."""
-    global _lib, _lib_f16
+    global _lib, _lib_f16, _lib_ref
     precision = precision or PRECISION[0]
     if precision == "bf16":
         if _lib is None:
@@ -121,6 +144,10 @@ def load(precision=None):
         if _lib_f16 is None:
             _lib_f16 = _open(LIB_PATH_F16, 1)
         return _lib_f16
+    if precision == "ref":
+        if _lib_ref is None:
+            _lib_ref = _open(LIB_PATH_REF, 2)
+        return _lib_ref
     raise ValueError(f"unknown precision {precision!r}")
 
 

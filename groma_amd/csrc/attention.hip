@@ -52,23 +52,34 @@ extern "C" int gr_diag_att_clk(unsigned long long* out) { return (int)hipMemcpyF
 
 // (soft-max row statistics are reduced across the four 16-lane rows with rows_max / rows_sum, gr_common.h)
 #ifndef ATT_G
+#if GR_SP
+#define ATT_G (HD == 128 ? 4 : 2)  // (each fragment is a hi / lo pair in the split build)
+#else
 #define ATT_G (HD == 128 ? 8 : 2)  // K / V^T fragments per prefetch group (A/B: hd 128 -5 % with 8, hd 64 neutral)
 #endif
+#endif
+// Split-operand build (gr_common.h): q, K, V^T and the context are (hi, lo) pairs in 32-element blocks, so a K row is 2*hd
+// physical elements whose 16-B chunk 8*kk + g holds the hi halves of d = 32*kk + 8*g.. and chunk 8*kk + 4 + g their lo halves, a
+// 64-key V^T tile row is 128 physical elements (chunk 8*tt + g = hi of keys 32*tt + 8*g.., + 4 = lo), and both contractions
+// issue hi.hi + hi.lo + lo.hi.  P is split in registers.  Tiles are twice as large: one workgroup per CU.
 
 template <int HD>
-__global__ __launch_bounds__(256, 2) void attention_kernel(AttnArgs p) {
+__global__ __launch_bounds__(256, GR_SP ? 1 : 2) void attention_kernel(AttnArgs p) {
   constexpr int KV = 64;
   constexpr int QT = 2;               // 16-row query tiles per wave -> 32 query rows / wave, 128 / block
-  constexpr int KROW = HD * 2;        // bytes per K row
-  constexpr int KCH = KROW / 16;      // 16-B chunks per K row (8 or 16)
+  constexpr int SPW = GR_SPW;         // physical elements per logical element (2 in the split build)
+  constexpr int KROW = HD * 2 * SPW;  // bytes per K row
+  constexpr int KCH = KROW / 16;      // 16-B chunks per K row (8 or 16; split build 16 or 32)
   constexpr int KTILE = KV * KROW;    // bytes
-  constexpr int VTILE = HD * KV * 2;  // Vt tile [HD][64] bf16, 128-B rows
+  constexpr int VROW = KV * 2 * SPW;  // bytes per V^T tile row (128; split build 256)
+  constexpr int VCH = VROW / 16;
+  constexpr int VTILE = HD * VROW;    // Vt tile [HD][64] bf16
   constexpr int STAGE = KTILE + VTILE;
   // Key order inside a 64-key tile: MFMA row i of score sub-tile j holds key (j>>1)*32 + (i>>2)*8 + (j&1)*4 + (i&3),
   // so that after S^T = K.Q^T a lane (k-group fg) owns keys 32*tt + fg*8 + {0..7} of query fr: exactly the 8
   // CONTIGUOUS keys of the standard MFMA k-slot, and the Vt fragment is ONE 16-B LDS read (ds_read_b128).
   // K-tile chunk swizzle (conflict-free for the 16 rows {0-3, 8-11, 16-19, 24-27}(+4) one ds_read_b128 touches):
-  auto kswz = [](int row) { return KCH == 16 ? ((row & 3) | (((row >> 3) & 3) << 2)) : (((row >> 1) & 1) | (((row >> 3) & 3) << 1)); };
+  auto kswz = [](int row) { return KCH >= 16 ? ((row & 3) | (((row >> 3) & 3) << 2)) : (((row >> 1) & 1) | (((row >> 3) & 3) << 1)); };
   extern __shared__ __attribute__((aligned(16))) char smem[];  // 2 stages (double buffer)
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -83,10 +94,10 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(AttnArgs p) {
   const int b = bh / p.H, h = bh - b * p.H;
   const int q0 = qb * (64 * QT);
 
-  const bf16_t* Qp = p.q_ld > 0 ? p.q + (long)b * p.Lq * p.q_ld + h * HD : p.q + (long)bh * p.Lq * HD;
+  const long q_base = p.q_ld > 0 ? (long)b * p.Lq * p.q_ld + h * HD : (long)bh * p.Lq * HD;  // logical element index
   const long q_rs = p.q_ld > 0 ? p.q_ld : HD;  // row stride
-  const bf16_t* Kp = p.k + (long)bh * p.kv_stride * HD;
-  const bf16_t* Vp = p.vt + (long)bh * HD * p.kv_stride;
+  const bf16_t* Kp = p.k + (long)bh * p.kv_stride * HD * SPW;
+  const bf16_t* Vp = p.vt + (long)bh * HD * p.kv_stride * SPW;
 
   const int q_pos0 = p.pos_dev ? p.pos_dev[b * p.pos_stride] : p.q_pos0;
   const int Skv = p.pos_dev ? q_pos0 + p.Lq : p.Skv;
@@ -97,18 +108,30 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(AttnArgs p) {
   int qi[QT], limit[QT];
   bool q_valid[QT];
   bf16x8 qf[QT][HD / 32];
+#if GR_SP
+  bf16x8 qfl[QT][HD / 32];  // lo halves
+#endif
 #pragma unroll
   for (int u = 0; u < QT; ++u) {
     qi[u] = q0 + wave * (16 * QT) + u * 16 + fr;
     q_valid[u] = qi[u] < p.Lq;
     if (!q_valid[u]) qi[u] = p.Lq - 1;
 #pragma unroll
-    for (int kk = 0; kk < HD / 32; ++kk) qf[u][kk] = *(const bf16x8*)(Qp + (long)qi[u] * q_rs + kk * 32 + fg * 8);
+    for (int kk = 0; kk < HD / 32; ++kk) {
+      const bf16_t* qsrc = p.q + sp_idx(q_base + (long)qi[u] * q_rs + kk * 32 + fg * 8);
+      qf[u][kk] = *(const bf16x8*)qsrc;
+#if GR_SP
+      qfl[u][kk] = *(const bf16x8*)(qsrc + 32);
+#endif
+    }
     if (p.rope_cos) {  // rotate in registers: out[d] = x[d]*cos - x[d+half]*sin (d < half), x[d]*cos + x[d-half]*sin (d >= half)
       constexpr int HALF = HD / 2, KH = HD / 64;  // fragments per half
       const float* cp = p.rope_cos + (long)(q_pos0 + qi[u]) * HALF + fg * 8;
       const float* sp = p.rope_sin + (long)(q_pos0 + qi[u]) * HALF + fg * 8;
       bf16x8 rot[HD / 32];
+#if GR_SP
+      bf16x8 rotl[HD / 32];
+#endif
 #pragma unroll
       for (int kk = 0; kk < HD / 32; ++kk) {
         const int kp = kk < KH ? kk + KH : kk - KH;
@@ -116,19 +139,32 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(AttnArgs p) {
         const int dc = (kk % KH) * 32;
         const f32x4 c0 = *(const f32x4*)(cp + dc), c1 = *(const f32x4*)(cp + dc + 4);
         const f32x4 s0 = *(const f32x4*)(sp + dc), s1 = *(const f32x4*)(sp + dc + 4);
-        union { bf16x8 v; uint32_t w[4]; } o;
+        union { bf16x8 v; uint32_t w[4]; } o, ol;
 #pragma unroll
         for (int e = 0; e < 8; e += 2) {
           const float ca = e < 4 ? c0[e] : c1[e - 4], cb = e < 4 ? c0[e + 1] : c1[e - 3];
           const float sa = e < 4 ? s0[e] : s1[e - 4], sb = e < 4 ? s0[e + 1] : s1[e - 3];
-          const float r0 = bf2f((bf16_t)qf[u][kk][e]) * ca + sgn * bf2f((bf16_t)qf[u][kp][e]) * sa;
-          const float r1 = bf2f((bf16_t)qf[u][kk][e + 1]) * cb + sgn * bf2f((bf16_t)qf[u][kp][e + 1]) * sb;
-          o.w[e >> 1] = pack2bf(r0, r1);
+#if GR_SP
+          const float x0 = bf2f((bf16_t)qf[u][kk][e]) + bf2f((bf16_t)qfl[u][kk][e]), x1 = bf2f((bf16_t)qf[u][kk][e + 1]) + bf2f((bf16_t)qfl[u][kk][e + 1]);
+          const float y0 = bf2f((bf16_t)qf[u][kp][e]) + bf2f((bf16_t)qfl[u][kp][e]), y1 = bf2f((bf16_t)qf[u][kp][e + 1]) + bf2f((bf16_t)qfl[u][kp][e + 1]);
+#else
+          const float x0 = bf2f((bf16_t)qf[u][kk][e]), x1 = bf2f((bf16_t)qf[u][kk][e + 1]);
+          const float y0 = bf2f((bf16_t)qf[u][kp][e]), y1 = bf2f((bf16_t)qf[u][kp][e + 1]);
+#endif
+          split2(x0 * ca + sgn * y0 * sa, x1 * cb + sgn * y1 * sb, o.w[e >> 1], ol.w[e >> 1]);
         }
         rot[kk] = o.v;
+#if GR_SP
+        rotl[kk] = ol.v;
+#endif
       }
 #pragma unroll
-      for (int kk = 0; kk < HD / 32; ++kk) qf[u][kk] = rot[kk];
+      for (int kk = 0; kk < HD / 32; ++kk) {
+        qf[u][kk] = rot[kk];
+#if GR_SP
+        qfl[u][kk] = rotl[kk];
+#endif
+      }
     }
     limit[u] = p.causal ? min(kvmax, q_pos0 + qi[u] + 1) : kvmax;  // keys [0, limit) visible
   }
@@ -165,15 +201,15 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(AttnArgs p) {
       const int c = pos ^ kswz(row);
       int kr = kv0 + row;
       if (kr > Skv - 1) kr = Skv - 1;
-      __builtin_amdgcn_global_load_lds((gptr_t)(Kp + (long)kr * HD + c * 8), (lptr_t)(ksm + i * 4096 + wave * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)(Kp + (long)kr * (HD * SPW) + c * 8), (lptr_t)(ksm + i * 4096 + wave * 1024), 16, 0, 0);
     }
-    constexpr int NVC = HD * 8;
+    constexpr int NVC = HD * VCH;
 #pragma unroll
     for (int i = 0; i < NVC / 256; ++i) {
       const int q = i * 256 + tid;
-      const int row = q >> 3, pos = q & 7;
+      const int row = q / VCH, pos = q % VCH;
       const int c = pos ^ (row & 7);
-      __builtin_amdgcn_global_load_lds((gptr_t)(Vp + (long)row * p.kv_stride + kv0 + c * 8),
+      __builtin_amdgcn_global_load_lds((gptr_t)(Vp + ((long)row * p.kv_stride + kv0) * SPW + c * 8),
                                        (lptr_t)(vsm + i * 4096 + wave * 1024), 16, 0, 0);
     }
   };
@@ -205,13 +241,16 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(AttnArgs p) {
     // LDS latency of the next group hides behind this group's MFMAs instead of stalling every MFMA pair
     constexpr int GK = ATT_G;                   // fragments per group
     constexpr int NKG = 4 * (HD / 32) / GK;     // groups over (j, kk)
-    bf16x8 kfr[2][GK];
+    bf16x8 kfr[2][GK * SPW];  // split build: [.., GK + e] = lo halves
     auto load_k = [&](int g, bf16x8* dst) {
 #pragma unroll
       for (int e = 0; e < GK; ++e) {
         const int step = g * GK + e, j = step / (HD / 32), kk = step % (HD / 32);
         const int row = (j >> 1) * 32 + (fr >> 2) * 8 + (j & 1) * 4 + (fr & 3);
-        dst[e] = *(const bf16x8*)(ksm + row * KROW + (((kk * 4 + fg) ^ kswz(row)) << 4));
+        dst[e] = *(const bf16x8*)(ksm + row * KROW + (((kk * 4 * SPW + fg) ^ kswz(row)) << 4));
+#if GR_SP
+        dst[GK + e] = *(const bf16x8*)(ksm + row * KROW + (((kk * 8 + 4 + fg) ^ kswz(row)) << 4));
+#endif
       }
     };
     load_k(0, kfr[0]);
@@ -224,6 +263,12 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(AttnArgs p) {
         const int step = g * GK + e, j = step / (HD / 32), kk = step % (HD / 32);
 #pragma unroll
         for (int u = 0; u < QT; ++u) s[u][j] = GR_MFMA_16x16x32(kfr[g & 1][e], qf[u][kk], s[u][j]);
+#if GR_SP
+#pragma unroll
+        for (int u = 0; u < QT; ++u) s[u][j] = GR_MFMA_16x16x32(kfr[g & 1][e], qfl[u][kk], s[u][j]);
+#pragma unroll
+        for (int u = 0; u < QT; ++u) s[u][j] = GR_MFMA_16x16x32(kfr[g & 1][GK + e], qf[u][kk], s[u][j]);
+#endif
       }
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -233,6 +278,9 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(AttnArgs p) {
     // (e = exp2(s*c - m*c)); masking (2 cmp + 2 select per element) is compiled only into boundary tiles.
     union PB { bf16x8 v; uint32_t w[4]; };
     PB pb[QT][2];
+#if GR_SP
+    PB pbl[QT][2];  // lo halves of P
+#endif
     const float cs = p.scale_log2;
     auto softmax_tile = [&](auto masked_tag) {
       constexpr bool MASKED = decltype(masked_tag)::value;
@@ -273,10 +321,17 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(AttnArgs p) {
         // P^T as the B operand; k-slot (fg,e) <-> key 32*tt + fg*8 + e (standard contiguous slot)
 #pragma unroll
         for (int tt = 0; tt < 2; ++tt) {
+#if GR_SP
+          split2(s[u][2 * tt][0], s[u][2 * tt][1], pb[u][tt].w[0], pbl[u][tt].w[0]);
+          split2(s[u][2 * tt][2], s[u][2 * tt][3], pb[u][tt].w[1], pbl[u][tt].w[1]);
+          split2(s[u][2 * tt + 1][0], s[u][2 * tt + 1][1], pb[u][tt].w[2], pbl[u][tt].w[2]);
+          split2(s[u][2 * tt + 1][2], s[u][2 * tt + 1][3], pb[u][tt].w[3], pbl[u][tt].w[3]);
+#else
           pb[u][tt].w[0] = pack2bf_unit(s[u][2 * tt][0], s[u][2 * tt][1]);
           pb[u][tt].w[1] = pack2bf_unit(s[u][2 * tt][2], s[u][2 * tt][3]);
           pb[u][tt].w[2] = pack2bf_unit(s[u][2 * tt + 1][0], s[u][2 * tt + 1][1]);
           pb[u][tt].w[3] = pack2bf_unit(s[u][2 * tt + 1][2], s[u][2 * tt + 1][3]);
+#endif
         }
       }
     };
@@ -287,14 +342,17 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(AttnArgs p) {
     // same for the V^T fragments: the next group's reads are issued before this group's MFMAs
     constexpr int GV = ATT_G;
     constexpr int NG = 2 * (HD / 16) / GV;  // groups of GV (tt, n) steps
-    bf16x8 vfr[2][GV];
+    bf16x8 vfr[2][GV * SPW];
     auto load_v = [&](int g, bf16x8* dst) {
 #pragma unroll
       for (int e = 0; e < GV; ++e) {
         const int step = g * GV + e, tt = step / (HD / 16), n = step % (HD / 16);
-        const int row = n * 16 + fr;  // d index
-        const int c = tt * 4 + fg;    // keys 32*tt + fg*8 .. +7 = one 16-B chunk of the Vt row
-        dst[e] = *(const bf16x8*)(vsm + row * 128 + ((c ^ (row & 7)) << 4));
+        const int row = n * 16 + fr;      // d index
+        const int c = tt * 4 * SPW + fg;  // keys 32*tt + fg*8 .. +7 = one 16-B chunk of the Vt row
+        dst[e] = *(const bf16x8*)(vsm + row * VROW + ((c ^ (row & 7)) << 4));
+#if GR_SP
+        dst[GV + e] = *(const bf16x8*)(vsm + row * VROW + (((c + 4) ^ (row & 7)) << 4));
+#endif
       }
     };
     load_v(0, vfr[0]);
@@ -307,6 +365,12 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(AttnArgs p) {
         const int step = g * GV + e, tt = step / (HD / 16), n = step % (HD / 16);
 #pragma unroll
         for (int u = 0; u < QT; ++u) o[u][n] = GR_MFMA_16x16x32(vfr[g & 1][e], pb[u][tt].v, o[u][n]);
+#if GR_SP
+#pragma unroll
+        for (int u = 0; u < QT; ++u) o[u][n] = GR_MFMA_16x16x32(vfr[g & 1][e], pbl[u][tt].v, o[u][n]);
+#pragma unroll
+        for (int u = 0; u < QT; ++u) o[u][n] = GR_MFMA_16x16x32(vfr[g & 1][GV + e], pb[u][tt].v, o[u][n]);
+#endif
       }
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -322,14 +386,9 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(AttnArgs p) {
   for (int u = 0; u < QT; ++u) {
     if (!q_valid[u]) continue;
     const float inv = l_run[u] > 0.f ? 1.0f / l_run[u] : 0.f;
-    bf16_t* orow = p.out + ((long)b * p.Lq + qi[u]) * (p.H * HD) + h * HD;
+    const long orow = ((long)b * p.Lq + qi[u]) * (p.H * HD) + h * HD;  // logical element index
 #pragma unroll
-    for (int n = 0; n < HD / 16; ++n) {
-      uint2 pk;
-      pk.x = pack2bf(o[u][n][0] * inv, o[u][n][1] * inv);
-      pk.y = pack2bf(o[u][n][2] * inv, o[u][n][3] * inv);
-      *(uint2*)(orow + n * 16 + fg * 4) = pk;
-    }
+    for (int n = 0; n < HD / 16; ++n) st4f(p.out, orow + n * 16 + fg * 4, o[u][n] * inv);
   }
 }
 
@@ -339,6 +398,7 @@ extern "C" int gr_attention_bf16(const void* q, const void* k, const void* vt, v
                                  const float* rope_sin, hipStream_t stream) {
   if (!q || !k || !vt || !out || B <= 0 || H <= 0 || Lq <= 0 || Skv <= 0) return GR_EINVAL;
   if (kv_stride % 64 != 0 || kv_stride < Skv) return GR_EINVAL;  // Vt tile reads run to the next multiple of 64
+  if (GR_SP && q_ld % 32 != 0) return GR_EINVAL;
   AttnArgs p;
   p.q = (const bf16_t*)q; p.k = (const bf16_t*)k; p.vt = (const bf16_t*)vt; p.out = (bf16_t*)out;
   p.kv_len = kv_len;
@@ -352,13 +412,13 @@ extern "C" int gr_attention_bf16(const void* q, const void* k, const void* vt, v
   dim3 grid(B * H, gr_cdiv(Lq, 128));
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)attention_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536) != hipSuccess ||
-        hipFuncSetAttribute((const void*)attention_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 32768) != hipSuccess)
+    if (hipFuncSetAttribute((const void*)attention_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536 * GR_SPW) != hipSuccess ||
+        hipFuncSetAttribute((const void*)attention_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 32768 * GR_SPW) != hipSuccess)
       return GR_EINVAL;
     attr_set = true;
   }
-  if (head_dim == 128) hipLaunchKernelGGL(attention_kernel<128>, grid, dim3(256), 65536, stream, p);
-  else if (head_dim == 64) hipLaunchKernelGGL(attention_kernel<64>, grid, dim3(256), 32768, stream, p);
+  if (head_dim == 128) hipLaunchKernelGGL(attention_kernel<128>, grid, dim3(256), 65536 * GR_SPW, stream, p);
+  else if (head_dim == 64) hipLaunchKernelGGL(attention_kernel<64>, grid, dim3(256), 32768 * GR_SPW, stream, p);
   else return GR_EINVAL;
   GR_CHECK_LAUNCH();
   return GR_OK;

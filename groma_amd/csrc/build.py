@@ -1,4 +1,4 @@
-"""Build libgroma_hip.so and libgroma_hip_f16.so (gfx950) in-tree with hipcc.  No cmake, no torch extension machinery:
+"""Build libgroma_hip.so, libgroma_hip_f16.so and libgroma_hip_ref.so (gfx950) in-tree with hipcc.  No cmake, no torch extension machinery:
 each library is a plain C-ABI shared object (include/groma_hip.h) loaded through ctypes.  The two are the same sources and the
 same ABI; they differ in the 16-bit operand type the kernels are compiled for (bfloat16 / IEEE half, -DGR_F16: gr_common.h)."""
 import os
@@ -26,7 +26,9 @@ SOURCES = {
 }
 LIB = os.path.join(HERE, "libgroma_hip.so")
 LIB_F16 = os.path.join(HERE, "libgroma_hip_f16.so")
-VARIANTS = [("", [], LIB), ("_f16", ["-DGR_F16=1"], LIB_F16)]
+LIB_REF = os.path.join(HERE, "libgroma_hip_ref.so")
+# _ref: the reference-precision build -- operands are (hi, lo) pairs of halves, every contraction is 3 MFMA passes (gr_common.h)
+VARIANTS = [("", [], LIB), ("_f16", ["-DGR_F16=1"], LIB_F16), ("_ref", ["-DGR_F16=1", "-DGR_SPLIT=1"], LIB_REF)]
 COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 
 
@@ -73,3 +75,4 @@ if __name__ == "__main__":
     build(force="--force" in sys.argv)
     print(LIB)
     print(LIB_F16)
+    print(LIB_REF)

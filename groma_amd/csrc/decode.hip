@@ -53,6 +53,7 @@ __global__ __launch_bounds__(1024) void decode_reduce_norm_kernel(const float* _
 
 extern "C" int gr_decode_reduce_norm(const float* part, int splits, float* h, const float* gamma, void* x, int M, int N,
                                      float eps, hipStream_t stream) {
+  if (GR_SP) return GR_EINVAL;  // the streaming decode / e4m3 kernels do not exist in the split-operand build (gr_common.h)
   if (!h || !gamma || !x || M <= 0 || N <= 0 || N % 4 != 0 || N > 8192 || (part && splits <= 0)) return GR_EINVAL;
   hipLaunchKernelGGL(decode_reduce_norm_kernel, dim3(M), dim3(1024), 0, stream, part, splits, h, gamma, (bf16_t*)x, M, N, eps);
   GR_CHECK_LAUNCH();
@@ -104,6 +105,7 @@ __global__ __launch_bounds__(HD) void decode_qkv_rope_kernel(const float* __rest
 extern "C" int gr_decode_qkv_rope(const float* part, int splits, void* q, void* k, void* vt, const float* cosT,
                                   const float* sinT, int B, int H, int head_dim, int pos0, int kv_stride,
                                   const int* pos_dev, int pos_stride, hipStream_t stream) {
+  if (GR_SP) return GR_EINVAL;  // the streaming decode / e4m3 kernels do not exist in the split-operand build (gr_common.h)
   if (!part || !q || !k || !vt || splits <= 0 || B <= 0 || H <= 0 || (!pos_dev && (pos0 < 0 || pos0 >= kv_stride))) return GR_EINVAL;
   if ((cosT == nullptr) != (sinT == nullptr)) return GR_EINVAL;
   dim3 grid(H, B);
@@ -249,6 +251,7 @@ __global__ __launch_bounds__(1024) void decode_attention_kernel(const bf16_t* __
 extern "C" int gr_decode_attention(const void* q, const void* k, const void* vt, void* out, const int* kv_len, int B, int H,
                                    int Smax, int kv_stride, int head_dim, int q_pos0, float scale, const int* pos_dev,
                                    int pos_stride, int nsplit, float* parts, hipStream_t stream) {
+  if (GR_SP) return GR_EINVAL;  // the streaming decode / e4m3 kernels do not exist in the split-operand build (gr_common.h)
   if (!q || !k || !vt || !out || B <= 0 || H <= 0 || Smax <= 0 || Smax > DEC_SMAX) return GR_EINVAL;
   if (nsplit < 1 || nsplit > 16 || (nsplit > 1 && !parts)) return GR_EINVAL;
   if (kv_stride % 64 != 0 || kv_stride < Smax || (!pos_dev && q_pos0 + 1 > Smax)) return GR_EINVAL;

@@ -57,6 +57,7 @@ __global__ __launch_bounds__(256) void quant_rows_fp8_kernel(const void* __restr
 
 extern "C" int gr_quant_rows_fp8(const void* x, int x_is_f32, void* q, float* scale, int rows, int K, long ldx,
                                  hipStream_t stream) {
+  if (GR_SP) return GR_EINVAL;  // the streaming decode / e4m3 kernels do not exist in the split-operand build (gr_common.h)
   if (!x || !q || !scale || rows <= 0 || K <= 0 || K % 8 != 0 || ldx % 8 != 0) return GR_EINVAL;
   if (x_is_f32)
     hipLaunchKernelGGL(quant_rows_fp8_kernel<true>, dim3(gr_cdiv(rows, 4)), dim3(256), 0, stream, x, (uint8_t*)q, scale, rows,
@@ -126,6 +127,7 @@ __global__ __launch_bounds__(256) void norm_fp8_rows_kernel(const float* __restr
 
 extern "C" int gr_norm_fp8(const float* x, const float* gamma, const float* beta, void* q, float* scale, int rows, int C,
                            float eps, int rms, hipStream_t stream) {
+  if (GR_SP) return GR_EINVAL;  // the streaming decode / e4m3 kernels do not exist in the split-operand build (gr_common.h)
   if (!x || !gamma || !q || !scale || rows <= 0 || C % 256 != 0 || C > 4096 || ((C >> 8) & ((C >> 8) - 1))) return GR_EINVAL;
 #define LAUNCH_NF(R, NVAL)                                                                                          \
   hipLaunchKernelGGL((norm_fp8_rows_kernel<R, NVAL>), dim3(gr_cdiv(rows, 4)), dim3(256), 0, stream, x, gamma, beta, \

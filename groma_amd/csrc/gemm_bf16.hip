@@ -89,6 +89,32 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16_kernel(GemmArgs p) {
     if (t + 1 < nt) stage(ks_begin + t + 1, (t + 1) & 1);
     const char* abuf = smem + (t & 1) * 32768;
     const char* wbuf = abuf + 16384;
+#if GR_SP
+    // split operands: k-step 0 of the K-tile = hi halves of 32 logical k-values, k-step 1 = their lo halves (gr_common.h);
+    // hi.hi + hi(W).lo(A) + lo(W).hi(A) into the same accumulators
+    bf16x8 af[2][4], wf[2][4];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      const int c = kk * 4 + fg;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int row = wm * 64 + i * 16 + fr;
+        af[kk][i] = *(const bf16x8*)(abuf + row * 128 + ((c ^ (row & 7)) << 4));
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int row = wn * 64 + j * 16 + fr;
+        wf[kk][j] = *(const bf16x8*)(wbuf + row * 128 + ((c ^ (row & 7)) << 4));
+      }
+    }
+#pragma unroll
+    for (int pp = 0; pp < 3; ++pp)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          acc[j][i] = GR_MFMA_16x16x32(wf[pp == 1][j], af[pp == 2][i], acc[j][i]);
+#else
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
       bf16x8 af[4], wf[4];
@@ -109,6 +135,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16_kernel(GemmArgs p) {
         for (int i = 0; i < 4; ++i)
           acc[j][i] = GR_MFMA_16x16x32(wf[j], af[i], acc[j][i]);
     }
+#endif
   }
 
   // ---- epilogue through LDS (coalesced; see gemm_common.h) ----
@@ -141,8 +168,13 @@ __global__ void gemm_splitk_reduce_kernel(GemmArgs p) {
   if (p.c_group > 0) orow = (long)(m / p.c_group) * p.c_group_stride + p.c_row_off + (m % p.c_group);
   if (p.bias) v += *(const f32x4*)(p.bias + n);
   if (p.act == 3) {
-    bf16_t* dst = (bf16_t*)p.C + orow * p.ldc + (n >> 1);
-    *(uint32_t*)dst = pack2bf(silu_f(v[0]) * v[1], silu_f(v[2]) * v[3]);
+    bf16_t* dst = (bf16_t*)p.C + orow * p.ldc + sp_idx(n >> 1);
+    uint32_t hi, lo;
+    split2(silu_f(v[0]) * v[1], silu_f(v[2]) * v[3], hi, lo);
+    *(uint32_t*)dst = hi;
+#if GR_SP
+    *(uint32_t*)(dst + 32) = lo;
+#endif
     return;
   }
   if (p.act) {
@@ -157,10 +189,7 @@ __global__ void gemm_splitk_reduce_kernel(GemmArgs p) {
   if (p.out_f32) {
     *(f32x4*)((float*)p.C + orow * p.ldc + n) = v;
   } else {
-    uint2 pk;
-    pk.x = pack2bf(v[0], v[1]);
-    pk.y = pack2bf(v[2], v[3]);
-    *(uint2*)((bf16_t*)p.C + orow * p.ldc + n) = pk;
+    st4f((bf16_t*)p.C + orow * p.ldc, n, v);
   }
 }
 
@@ -171,7 +200,9 @@ struct ProfRec { hipEvent_t a, b; double flops; int M, N, K, tag; };
 static std::vector<ProfRec> g_prof;
 
 extern "C" int gr_abi_version(void) { return GROMA_HIP_ABI_VERSION; }
-#ifdef GR_F16
+#if GR_SP
+extern "C" int gr_operand_type(void) { return GR_OPERAND_SPLIT; }
+#elif defined(GR_F16)
 extern "C" int gr_operand_type(void) { return GR_OPERAND_F16; }
 #else
 extern "C" int gr_operand_type(void) { return GR_OPERAND_BF16; }
@@ -246,6 +277,16 @@ extern "C" int gr_gemm_bf16(const gr_gemm_desc* d, hipStream_t stream) {
   p.act = d->act; p.out_f32 = d->out_f32; p.splits = splits;
   p.conv_H = d->conv_H; p.conv_W = d->conv_W; p.conv_C = d->conv_C;
   p.conv_seg_stride = d->conv_seg_stride;
+#if GR_SP
+  // Reference-precision build: every 16-bit operand is a (hi, lo) pair in 32-element blocks (gr_common.h), so a physical row holds
+  // 2K elements and one 64-wide physical K-tile = 32 logical k-values.  The descriptor stays LOGICAL; the kernels see physical
+  // extents.  The streaming decode kernels and the e4m3 path do not exist in this build.
+  if (d->fp8 || d->tile == 1 || d->tile == 2 || d->a_parts) return GR_EINVAL;
+  if (d->lda % 32 != 0 || d->ldw % 32 != 0 || (d->conv_C > 0 && d->conv_seg_stride % 32 != 0)) return GR_EINVAL;
+  if (!d->out_f32 && (d->ldc % 32 != 0 || (d->act == 3 ? d->N / 2 : d->N) % 32 != 0)) return GR_EINVAL;  // rows = whole hi / lo block pairs
+  p.K *= 2; p.lda *= 2; p.ldw *= 2; p.conv_C *= 2; p.conv_seg_stride *= 2;
+  if (!d->out_f32) p.ldc *= 2;
+#endif
   p.resid_mod = d->resid_mod;
   p.c_group = d->c_group; p.c_group_stride = d->c_group_stride; p.c_row_off = d->c_row_off;
   // ---- kernel choice: estimated time = rounds x per-slot tile time (slots: 512 for 128^2 at 2 blocks/CU, 256 for
@@ -278,8 +319,8 @@ extern "C" int gr_gemm_bf16(const gr_gemm_desc* d, hipStream_t stream) {
   if (g_prof_on) {
     (void)hipEventCreate(&rec.a);
     (void)hipEventCreate(&rec.b);
-    rec.flops = 2.0 * p.M * (double)p.N * p.K;  // (fp8 launches are tagged 16)
-    rec.M = p.M; rec.N = p.N; rec.K = p.K; rec.tag = (p.conv_C > 0 ? 1 : 0) | (splits > 1 ? 2 : 0) | (use256 ? 4 : 0) | (gemv ? 8 : 0) | (d->fp8 ? 16 : 0);
+    rec.flops = 2.0 * p.M * (double)p.N * d->K;  // algorithmic (logical K; the split build issues 3x this in MFMA work); fp8 launches are tagged 16
+    rec.M = p.M; rec.N = p.N; rec.K = d->K; rec.tag = (p.conv_C > 0 ? 1 : 0) | (splits > 1 ? 2 : 0) | (use256 ? 4 : 0) | (gemv ? 8 : 0) | (d->fp8 ? 16 : 0);
     (void)hipEventRecord(rec.a, stream);
   }
   if (gemv) {

@@ -282,16 +282,29 @@ __global__ __launch_bounds__(NT) void G256_KERNEL(GemmArgs p) {
 #define DRAIN_READS asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 // (Variants A/B-measured on one box and removed -- DESIGN.md 3a: handing the pipe over 6 MFMAs early, not draining the
 // reads, splitting the LDS-DMA issue 4 + 4 over the two segments, the original four 16-MFMA phases per K-tile.)
+// The MFMAs of one phase.  Unsplit operands: both 32-deep k-steps of the K-tile, 32 MFMAs.  Split operands (GR_SPLIT, the
+// reference-precision build): the K-tile's first k-step holds the hi halves of 32 logical k-values and the second their lo
+// halves (gr_common.h), and the phase issues hi.hi, hi(A).lo(W) and lo(A).hi(W): 48 MFMAs on the same fragments.
+#if GR_SP && !G256_FP8
+#define PHASE_MFMAS(I0)                                                                                   \
+  _Pragma("unroll") for (int pp = 0; pp < 3; ++pp)                                                        \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                         \
+      _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                       \
+        acc[I0 + i][j] = ABL_MFMA(bfr[j][pp == 1], af[i][pp == 2], acc[I0 + i][j]);
+#else
+#define PHASE_MFMAS(I0)                                                                                   \
+  _Pragma("unroll") for (int kk = 0; kk < 2; ++kk)                                                        \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                         \
+      _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                       \
+        acc[I0 + i][j] = ABL_MFMA(bfr[j][kk], af[i][kk], acc[I0 + i][j]);
+#endif
 #define PHASE32(P, I0)                                                                                    \
   __builtin_amdgcn_sched_barrier(0);                                                                      \
   __builtin_amdgcn_s_barrier();                                                                           \
   __builtin_amdgcn_sched_barrier(0);                                                                      \
   PH_MARK(2 * (P))                                                                                        \
   __builtin_amdgcn_s_setprio(1);                                                                          \
-  _Pragma("unroll") for (int kk = 0; kk < 2; ++kk)                                                        \
-    _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                         \
-      _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                       \
-        acc[I0 + i][j] = ABL_MFMA(bfr[j][kk], af[i][kk], acc[I0 + i][j]);                                 \
+  PHASE_MFMAS(I0)                                                                                         \
   __builtin_amdgcn_s_setprio(0);                                                                          \
   PH_MARK(2 * (P) + 1)                                                                                    \
   __builtin_amdgcn_sched_barrier(0);                                                                      \

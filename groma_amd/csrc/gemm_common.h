@@ -84,39 +84,6 @@ __device__ __forceinline__ long a_k_off(const GemmArgs& p, int ks) {
   return k0;
 }
 
-// Epilogue for one lane-owned vector: 4 consecutive columns n..n+3 of row m (the swapped-operand MFMA layout).
-__device__ __forceinline__ void epi_store(const GemmArgs& p, f32x4 v, int m, int n, int z) {
-  if (p.splits > 1) {
-    *(f32x4*)(p.ws + ((long)z * p.M + m) * p.N + n) = v;
-    return;
-  }
-  long orow = m;
-  if (p.c_group > 0) orow = (long)(m / p.c_group) * p.c_group_stride + p.c_row_off + (m % p.c_group);
-  if (p.bias) v += *(const f32x4*)(p.bias + n);
-  if (p.act == 3) {  // SwiGLU on interleaved (gate, up) pairs
-    bf16_t* dst = (bf16_t*)p.C + orow * p.ldc + (n >> 1);
-    *(uint32_t*)dst = pack2bf(silu_f(v[0]) * v[1], silu_f(v[2]) * v[3]);
-    return;
-  }
-  if (p.act) {
-#pragma unroll
-    for (int e = 0; e < 4; ++e) v[e] = act_apply(v[e], p.act);
-  }
-  if (p.scale) v *= *(const f32x4*)(p.scale + n);
-  if (p.resid) {
-    const long rrow = p.resid_mod > 0 ? (long)(m % p.resid_mod) : orow;
-    v += *(const f32x4*)(p.resid + rrow * p.ldr + n);
-  }
-  if (p.out_f32) {
-    *(f32x4*)((float*)p.C + orow * p.ldc + n) = v;
-  } else {
-    uint2 pk;
-    pk.x = pack2bf(v[0], v[1]);
-    pk.y = pack2bf(v[2], v[3]);
-    *(uint2*)((bf16_t*)p.C + orow * p.ldc + n) = pk;
-  }
-}
-
 // ---- coalesced epilogue -------------------------------------------------------------------------------------
 // The MFMA accumulator layout gives each lane 4 columns of ONE row, so a direct store touches 16 rows x 32 B per
 // wave-instruction (store-issue bound: the bf16 output of a K=1024..4096 GEMM is its largest HBM stream).  Instead
@@ -159,70 +126,6 @@ struct EpiCols {
     }
   }
 };
-// One thread's share of a staged row: W4 consecutive float4 starting at tile column c4*4 (tile-relative), row m.
-template <int COLS, int W4>
-__device__ __forceinline__ void epi_from_stage(const GemmArgs& p, const char* base, int srow, int c4, int m, int n0, int z,
-                                               const EpiCols<W4>& ec) {
-  if (m >= p.M) return;
-  f32x4 v[W4];
-#pragma unroll
-  for (int w = 0; w < W4; ++w) v[w] = stage_read4<COLS>(base, srow, c4 + w);
-  if (p.w_scale) {  // fp8: dequantise  acc * a_scale[m] * w_scale[n]
-    const float as = p.a_scale ? p.a_scale[m] : 1.f;
-#pragma unroll
-    for (int w = 0; w < W4; ++w) v[w] = v[w] * ec.wsc[w] * as;
-  }
-  const int n = n0 + c4 * 4;
-  if (p.splits > 1) {
-#pragma unroll
-    for (int w = 0; w < W4; ++w)
-      if (n + 4 * w < p.N) *(f32x4*)(p.ws + ((long)z * p.M + m) * p.N + n + 4 * w) = v[w];
-    return;
-  }
-  long orow = m;
-  if (p.c_group > 0) orow = (long)(m / p.c_group) * p.c_group_stride + p.c_row_off + (m % p.c_group);
-  if (p.act == 3) {  // SwiGLU over interleaved (gate, up) columns: 4*W4 fused columns -> 2*W4 outputs
-    uint32_t o[W4];
-#pragma unroll
-    for (int w = 0; w < W4; ++w) {
-      const f32x4 x = v[w] + ec.bias[w];
-      o[w] = pack2bf(silu_f(x[0]) * x[1], silu_f(x[2]) * x[3]);
-    }
-    bf16_t* dst = (bf16_t*)p.C + orow * p.ldc + (n >> 1);
-    if (W4 == 4 && n + 16 <= p.N && (p.ldc & 7) == 0) {
-      *(uint4*)dst = make_uint4(o[0], o[1], o[2], o[3]);
-    } else {
-#pragma unroll
-      for (int w = 0; w < W4; ++w)
-        if (n + 4 * w < p.N) *(uint32_t*)(dst + 2 * w) = o[w];
-    }
-    return;
-  }
-#pragma unroll
-  for (int w = 0; w < W4; ++w)
-    if (n + 4 * w < p.N) v[w] = epi_math4(p, v[w], m, orow, n + 4 * w, ec.bias[w], ec.scale[w]);
-  if (p.out_f32) {
-#pragma unroll
-    for (int w = 0; w < W4; ++w)
-      if (n + 4 * w < p.N) *(f32x4*)((float*)p.C + orow * p.ldc + n + 4 * w) = v[w];
-  } else {
-    bf16_t* dst = (bf16_t*)p.C + orow * p.ldc + n;
-    if (W4 == 2 && n + 8 <= p.N && (p.ldc & 7) == 0) {
-      *(uint4*)dst = make_uint4(pack2bf(v[0][0], v[0][1]), pack2bf(v[0][2], v[0][3]), pack2bf(v[1][0], v[1][1]),
-                                pack2bf(v[1][2], v[1][3]));
-    } else {
-#pragma unroll
-      for (int w = 0; w < W4; ++w)
-        if (n + 4 * w < p.N) {
-          uint2 pk;
-          pk.x = pack2bf(v[w][0], v[w][1]);
-          pk.y = pack2bf(v[w][2], v[w][3]);
-          *(uint2*)(dst + 4 * w) = pk;
-        }
-    }
-  }
-}
-
 // ---- batched epilogue: NIT staged rows per thread in ONE straight-line sequence ---------------------------------
 // vmcnt is an in-order counter shared by loads and stores: a row-at-a-time epilogue with a (possibly skipped) residual /
 // scale load inside each row made the compiler put `s_waitcnt vmcnt(0)` on the common path, so every 16-B store had to
@@ -299,21 +202,25 @@ __device__ __forceinline__ void epi_rows(const GemmArgs& p, const char* base, in
         for (int w = 0; w < W4; ++w)
           if (FULL || n + 4 * w < p.N) EPI_ST((f32x4*)((float*)p.C + orow * p.ldc + n + 4 * w), v[w]);
       } else {
-        bf16_t* dst = (bf16_t*)p.C + orow * p.ldc + n;
+        // (split build: p.ldc is the physical row stride; a thread's 8 columns lie inside one 32-column hi / lo block pair)
+        bf16_t* dst = (bf16_t*)p.C + orow * p.ldc + sp_idx(n);
         if (W4 == 2 && (FULL || n + 8 <= p.N) && (p.ldc & 7) == 0) {
           typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
-          const u32x4 pk4 = {pack2bf(v[0][0], v[0][1]), pack2bf(v[0][2], v[0][3]), pack2bf(v[W4 - 1][0], v[W4 - 1][1]),
-                             pack2bf(v[W4 - 1][2], v[W4 - 1][3])};
-          EPI_ST((u32x4*)dst, pk4);
+          uint32_t h[4], l[4];
+          split2(v[0][0], v[0][1], h[0], l[0]);
+          split2(v[0][2], v[0][3], h[1], l[1]);
+          split2(v[W4 - 1][0], v[W4 - 1][1], h[2], l[2]);
+          split2(v[W4 - 1][2], v[W4 - 1][3], h[3], l[3]);
+          const u32x4 hi4 = {h[0], h[1], h[2], h[3]};
+          EPI_ST((u32x4*)dst, hi4);
+#if GR_SP
+          const u32x4 lo4 = {l[0], l[1], l[2], l[3]};
+          EPI_ST((u32x4*)(dst + 32), lo4);
+#endif
         } else {
 #pragma unroll
           for (int w = 0; w < W4; ++w)
-            if (n + 4 * w < p.N) {
-              uint2 pk;
-              pk.x = pack2bf(v[w][0], v[w][1]);
-              pk.y = pack2bf(v[w][2], v[w][3]);
-              *(uint2*)(dst + 4 * w) = pk;
-            }
+            if (n + 4 * w < p.N) st4f((bf16_t*)p.C + orow * p.ldc, n + 4 * w, v[w]);
         }
       }
     }
@@ -337,21 +244,29 @@ __device__ __forceinline__ void epi_rows_swiglu(const GemmArgs& p, const char* b
     if (!FULL && m >= p.M) continue;
     long orow = m;
     if (!FULL && p.c_group > 0) orow = (long)(m / p.c_group) * p.c_group_stride + p.c_row_off + (m % p.c_group);
-    uint32_t o[4];
+    uint32_t o[4], ol[4];
 #pragma unroll
     for (int w = 0; w < 4; ++w) {
       f32x4 x = stage_read4<COLS>(base, rm(it), c4 + w);
       if (DEQ) x = x * ec.wsc[w] * as[DEQ ? it : 0];
       x += ec.bias[w];
-      o[w] = pack2bf(silu_f(x[0]) * x[1], silu_f(x[2]) * x[3]);
+      split2(silu_f(x[0]) * x[1], silu_f(x[2]) * x[3], o[w], ol[w]);
     }
-    bf16_t* dst = (bf16_t*)p.C + orow * p.ldc + (n >> 1);
+    bf16_t* dst = (bf16_t*)p.C + orow * p.ldc + sp_idx(n >> 1);
     if ((FULL || n + 16 <= p.N) && (p.ldc & 7) == 0) {
       *(uint4*)dst = make_uint4(o[0], o[1], o[2], o[3]);
+#if GR_SP
+      *(uint4*)(dst + 32) = make_uint4(ol[0], ol[1], ol[2], ol[3]);
+#endif
     } else {
 #pragma unroll
       for (int w = 0; w < 4; ++w)
-        if (n + 4 * w < p.N) *(uint32_t*)(dst + 2 * w) = o[w];
+        if (n + 4 * w < p.N) {
+          *(uint32_t*)(dst + 2 * w) = o[w];
+#if GR_SP
+          *(uint32_t*)(dst + 32 + 2 * w) = ol[w];
+#endif
+        }
     }
   }
 }

@@ -53,6 +53,84 @@ __device__ __forceinline__ uint32_t pack2bf_unit(float a, float b) { return pack
 #define GR_MFMA_16x16x32(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0)
 #endif
 
+// ---- split-operand storage: the reference-precision build (libgroma_hip_ref.so, -DGR_F16 -DGR_SPLIT) ------------------------
+// A third build of the same sources whose "16-bit operand" is a PAIR of halves: x ~= hi + lo with hi = f16(x), lo = f16(x - hi),
+// 22 mantissa bits instead of 11 (bf16: 8).  Every contraction multiplies hi.hi + hi.lo + lo.hi into the same fp32 MFMA
+// accumulators (the dropped lo.lo term is 2^-22 relative), so a GEMM costs 3x the MFMA work and 2x the operand bytes and is
+// within ~1e-6 of an fp32 GEMM -- what north_star's "logits within 1e-3 of reference" needs at 32 layers of depth, where one
+// 16-bit rounding per operand already costs 3e-3 (fp16) / 2.6e-2 (bf16): DESIGN.md 4.
+// Layout: a logical tensor of n 16-bit elements is stored as 2n, interleaved in blocks of 32 -- logical element i sits at
+// physical element (i / 32) * 64 + i % 32 (hi) and 32 further (lo).  One 64-element physical block is exactly one 128-B K-tile
+// row of the GEMM kernels: its first MFMA k-step (32 deep) reads hi, the second lo, so the three products are three MFMAs on
+// fragments the unsplit kernel already holds.  Every innermost extent on the path is a multiple of 32 (K % 64 == 0 is an ABI
+// requirement, head dims are 64 / 128, KV capacities multiples of 64), so the map is a function of the FLAT logical index.
+// All dimension / stride arguments of the C ABI stay LOGICAL in this build; buffers are twice as large.
+#ifdef GR_SPLIT
+#define GR_SP 1
+#else
+#define GR_SP 0
+#endif
+#define GR_SPW (1 + GR_SP)  // physical 16-bit elements per logical element
+__device__ __host__ __forceinline__ long sp_idx(long i) { return GR_SP ? (((i >> 5) << 6) + (i & 31)) : i; }
+// (a, b) -> packed hi pair (+ packed lo pair in the split build)
+__device__ __forceinline__ void split2(float a, float b, uint32_t& hi, uint32_t& lo) {
+  hi = pack2bf(a, b);
+#if GR_SP
+  lo = pack2bf(a - bf2f((bf16_t)(hi & 0xffffu)), b - bf2f((bf16_t)(hi >> 16)));
+#else
+  lo = 0;
+#endif
+}
+__device__ __forceinline__ float ld1f(const bf16_t* base, long i) {
+  const long p = sp_idx(i);
+  float v = bf2f(base[p]);
+#if GR_SP
+  v += bf2f(base[p + 32]);
+#endif
+  return v;
+}
+__device__ __forceinline__ void st1f(bf16_t* base, long i, float v) {
+  const long p = sp_idx(i);
+  const bf16_t h = f2bf(v);
+  base[p] = h;
+#if GR_SP
+  base[p + 32] = f2bf(v - bf2f(h));
+#endif
+}
+// 4 consecutive logical elements (i % 4 == 0): one 8-B store (two in the split build)
+__device__ __forceinline__ void st4f(bf16_t* base, long i, f32x4 v) {
+  const long p = sp_idx(i);
+  uint2 h, l;
+  split2(v[0], v[1], h.x, l.x);
+  split2(v[2], v[3], h.y, l.y);
+  *(uint2*)(base + p) = h;
+#if GR_SP
+  *(uint2*)(base + p + 32) = l;
+#endif
+}
+// 8 consecutive logical elements (i % 8 == 0): one 16-B access (two in the split build)
+__device__ __forceinline__ void st8f(bf16_t* base, long i, const float* v) {
+  const long p = sp_idx(i);
+  union { bf16x8 x; uint32_t u[4]; } h, l;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) split2(v[2 * k], v[2 * k + 1], h.u[k], l.u[k]);
+  *(bf16x8*)(base + p) = h.x;
+#if GR_SP
+  *(bf16x8*)(base + p + 32) = l.x;
+#endif
+}
+__device__ __forceinline__ void ld8f(const bf16_t* base, long i, float* o) {
+  const long p = sp_idx(i);
+  const bf16x8 h = *(const bf16x8*)(base + p);
+#pragma unroll
+  for (int k = 0; k < 8; ++k) o[k] = bf2f((bf16_t)h[k]);
+#if GR_SP
+  const bf16x8 l = *(const bf16x8*)(base + p + 32);
+#pragma unroll
+  for (int k = 0; k < 8; ++k) o[k] += bf2f((bf16_t)l[k]);
+#endif
+}
+
 // erf via Abramowitz-Stegun 7.1.26 (|abs err| <= 1.5e-7, i.e. fp32-roundoff class): ~14 VALU ops instead of the
 // ~60 of ocml erff -- the exact-erf GELU (HF "gelu") epilogue of the ViT fc1 / bridge GEMMs is VALU-visible otherwise.
 __device__ __forceinline__ float erf_as(float x) {

@@ -76,10 +76,7 @@ __global__ __launch_bounds__(256) void norm_rows_kernel(const float* __restrict_
         if (beta) o += *(const f32x4*)(beta + c);
       }
       if (out_bf16) {
-        uint2 pk;
-        pk.x = pack2bf(o[0], o[1]);
-        pk.y = pack2bf(o[2], o[3]);
-        *(uint2*)((bf16_t*)out + (long)row * ldo + c) = pk;
+        st4f((bf16_t*)out + (long)row * ldo * GR_SPW, c, o);
       } else {
         *(f32x4*)((float*)out + (long)row * ldo + c) = o;
       }
@@ -141,10 +138,7 @@ __global__ __launch_bounds__(256) void norm_rows_generic_kernel(const float* __r
       if (beta) o += *(const f32x4*)(beta + c);
     }
     if (out_bf16) {
-      uint2 pk;
-      pk.x = pack2bf(o[0], o[1]);
-      pk.y = pack2bf(o[2], o[3]);
-      *(uint2*)((bf16_t*)out + (long)row * ldo + c) = pk;
+      st4f((bf16_t*)out + (long)row * ldo * GR_SPW, c, o);
     } else {
       *(f32x4*)((float*)out + (long)row * ldo + c) = o;
     }
@@ -156,6 +150,7 @@ extern "C" int gr_layernorm(const float* x, const float* add, const float* gamma
                             int rows, int C, long ldx, long ldo, float eps, int out_bf16, int relu_in,
                             hipStream_t stream) {
   if (!x || !gamma || !out || rows <= 0 || C <= 0 || C % 4 != 0 || (ldx & 3) || (ldo & 3)) return GR_EINVAL;
+  if (GR_SP && out_bf16 && (ldo % 32 != 0 || C % 32 != 0)) return GR_EINVAL;  // split rows are whole hi / lo block pairs
   if (!norm_fast_shape(C)) {
     if (out == (const void*)x) return GR_EINVAL;  // the generic kernel re-reads the row: no in-place normalisation
     hipLaunchKernelGGL(norm_rows_generic_kernel<false>, dim3(gr_cdiv(rows, 4)), dim3(256), 0, stream, x, add, gamma, beta, out,
@@ -181,6 +176,7 @@ extern "C" int gr_layernorm(const float* x, const float* add, const float* gamma
 extern "C" int gr_rmsnorm(const float* x, const float* gamma, void* out, int rows, int C, long ldx, long ldo, float eps,
                           int out_bf16, hipStream_t stream) {
   if (!x || !gamma || !out || rows <= 0 || C <= 0 || C % 4 != 0 || (ldx & 3) || (ldo & 3)) return GR_EINVAL;
+  if (GR_SP && out_bf16 && (ldo % 32 != 0 || C % 32 != 0)) return GR_EINVAL;  // split rows are whole hi / lo block pairs
   if (!norm_fast_shape(C)) {
     if (out == (const void*)x) return GR_EINVAL;
     hipLaunchKernelGGL(norm_rows_generic_kernel<true>, dim3(gr_cdiv(rows, 4)), dim3(256), 0, stream, x, (const float*)nullptr,

@@ -13,6 +13,78 @@
 //   x'[d] = x[d]*cos[d-hd/2] + x[d-hd/2]*sin[d-hd/2] (d >= hd/2)
 // One block = 64 tokens x one head; V goes through an LDS transpose so Vt rows are written
 // as 128-B segments.
+#if GR_SP
+// Split-operand build (gr_common.h): same work items, values carried as fp32 (hi + lo) between the helper loads and stores;
+// RoPE is evaluated on the reconstructed 22-bit values.  (Separate body so the tuned 16-bit kernel below stays as it is.)
+template <int HD>
+__global__ __launch_bounds__(256) void qkv_split_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ q,
+                                                        bf16_t* __restrict__ k, bf16_t* __restrict__ vt,
+                                                        const float* __restrict__ cosT, const float* __restrict__ sinT,
+                                                        int B, int H, int L, int pos0_arg, int kv_stride,
+                                                        const int* __restrict__ pos_dev, int pos_stride) {
+  __shared__ float vs[64][HD + 1];
+  const int t0 = blockIdx.x * 64;
+  const int h = blockIdx.y, b = blockIdx.z;
+  const int pos0 = pos_dev ? pos_dev[b * pos_stride] : pos0_arg;
+  const int tid = threadIdx.x;
+  const long row_stride = 3L * H * HD;
+  constexpr int HALF = HD / 2;
+  constexpr int CH = HD / 8;
+  for (int it = tid; it < 64 * CH; it += 256) {
+    const int tt = it / CH, d = (it - tt * CH) * 8;
+    const int t = t0 + tt;
+    if (t >= L) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) vs[tt][d + i] = 0.f;
+      continue;
+    }
+    const long src = ((long)b * L + t) * row_stride + h * HD;  // logical flat index of (token, head) in the q block
+    const int pos = pos0 + t;
+    float v8[8];
+    ld8f(qkv, src + 2L * H * HD + d, v8);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) vs[tt][d + i] = v8[i];
+#pragma unroll
+    for (int which = 0; which < 2; ++which) {
+      if (which == 0 && !q) continue;
+      const long sp = src + (long)which * H * HD;
+      bf16_t* dst = which == 0 ? q : k;
+      const long di = which == 0 ? (((long)b * H + h) * L + t) * HD : (((long)b * H + h) * kv_stride + pos) * HD;
+      float x[8];
+      ld8f(qkv, sp + d, x);
+      if (cosT) {
+        const int dp = d < HALF ? d + HALF : d - HALF;
+        float y[8];
+        ld8f(qkv, sp + dp, y);
+        const int dc = d < HALF ? d : d - HALF;
+        const float sgn = d < HALF ? -1.f : 1.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+          x[i] = x[i] * cosT[(long)pos * HALF + dc + i] + sgn * y[i] * sinT[(long)pos * HALF + dc + i];
+      }
+      st8f(dst, di + d, x);
+    }
+  }
+  __syncthreads();
+  const bool aligned = ((pos0 + t0) & 7) == 0;
+  for (int it = tid; it < HD * 8; it += 256) {
+    const int d = it >> 3, seg = it & 7;
+    const int tb = t0 + seg * 8;
+    if (tb >= L) continue;
+    const long di = (((long)b * H + h) * HD + d) * kv_stride + pos0 + tb;
+    if (aligned && tb + 8 <= L) {
+      float o[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) o[i] = vs[seg * 8 + i][d];
+      st8f(vt, di, o);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+        if (tb + i < L) st1f(vt, di + i, vs[seg * 8 + i][d]);
+    }
+  }
+}
+#else
 template <int HD>
 __global__ __launch_bounds__(256) void qkv_split_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ q,
                                                         bf16_t* __restrict__ k, bf16_t* __restrict__ vt,
@@ -88,11 +160,14 @@ __global__ __launch_bounds__(256) void qkv_split_kernel(const bf16_t* __restrict
   }
 }
 
+#endif  // GR_SP
+
 extern "C" int gr_qkv_split(const void* qkv, void* q, void* k, void* vt, const float* cosT, const float* sinT, int B,
                             int H, int L, int head_dim, int pos0, int kv_stride, const int* pos_dev, int pos_stride,
                             hipStream_t stream) {
   if (!qkv || !k || !vt || B <= 0 || H <= 0 || L <= 0) return GR_EINVAL;  // q may be NULL (left in qkv)
   if ((cosT == nullptr) != (sinT == nullptr)) return GR_EINVAL;
+  if (GR_SP && kv_stride % 32 != 0) return GR_EINVAL;
   dim3 grid(gr_cdiv(L, 64), H, B);
   if (head_dim == 128)
     hipLaunchKernelGGL(qkv_split_kernel<128>, grid, dim3(256), 0, stream, (const bf16_t*)qkv, (bf16_t*)q, (bf16_t*)k,
@@ -124,11 +199,11 @@ __global__ void patchify_kernel(const float* __restrict__ img, bf16_t* __restric
     const int gx = (int)(m % G), gy = (int)((m / G) % G), b = (int)(m / ((long)G * G));
     v = img[(((long)b * 3 + c) * S + gy * P + ky) * S + gx * P + kx];
   }
-  out[idx] = f2bf(v);
+  st1f(out, idx, v);
 }
 
 extern "C" int gr_patchify(const float* images, void* out, int B, int S, int P, int Kpad, hipStream_t stream) {
-  if (!images || !out || B <= 0 || S % P != 0 || Kpad < 3 * P * P) return GR_EINVAL;
+  if (!images || !out || B <= 0 || S % P != 0 || Kpad < 3 * P * P || (GR_SP && Kpad % 32 != 0)) return GR_EINVAL;
   const int G = S / P;
   const long total = (long)B * G * G * Kpad;
   hipLaunchKernelGGL(patchify_kernel, dim3(gr_cdiv(total, 256)), dim3(256), 0, stream, images, (bf16_t*)out, B, S, P, G,
@@ -197,13 +272,10 @@ __global__ void s2d_kernel(const float* __restrict__ h, bf16_t* __restrict__ out
   const int dy = blk & 1, dx = blk >> 1;  // blocks: (0,0),(1,0),(0,1),(1,1) as (row offset, col offset)
   const int y = 2 * i + dy, x = 2 * j + dx;
   const f32x4 v = *(const f32x4*)(h + ((long)b * (1 + G * G) + 1 + y * G + x) * C + c);
-  uint2 pk;
-  pk.x = pack2bf(v[0], v[1]);
-  pk.y = pack2bf(v[2], v[3]);
-  *(uint2*)(out + m * 4 * C + cc) = pk;
+  st4f(out, m * 4 * C + cc, v);
 }
 extern "C" int gr_s2d_pack(const float* h, void* out, int B, int G, int C, hipStream_t stream) {
-  if (!h || !out || G % 2 != 0 || C % 4 != 0) return GR_EINVAL;
+  if (!h || !out || G % 2 != 0 || C % 4 != 0 || (GR_SP && C % 32 != 0)) return GR_EINVAL;
   const long total = (long)B * (G / 2) * (G / 2) * C;
   hipLaunchKernelGGL(s2d_kernel, dim3(gr_cdiv(total, 256)), dim3(256), 0, stream, h, (bf16_t*)out, B, G, C);
   GR_CHECK_LAUNCH();
@@ -245,14 +317,11 @@ __global__ void upsample_coord_kernel(const float* __restrict__ h, bf16_t* __res
     v[0] = x < Ho / 2 ? -1.f + step * x : 1.f - step * (Ho - 1 - x);
     v[1] = y < Ho / 2 ? -1.f + step * y : 1.f - step * (Ho - 1 - y);
   }
-  uint2 pk;
-  pk.x = pack2bf(v[0], v[1]);
-  pk.y = pack2bf(v[2], v[3]);
-  *(uint2*)(out + m * Cpad + c) = pk;
+  st4f(out, m * Cpad + c, v);
 }
 extern "C" int gr_upsample_coord_pack(const float* h, void* out, int B, int G, int Ho, int C, int Cpad,
                                       hipStream_t stream) {
-  if (!h || !out || C % 4 != 0 || Cpad % 4 != 0 || Cpad < C + 2) return GR_EINVAL;
+  if (!h || !out || C % 4 != 0 || Cpad % 4 != 0 || Cpad < C + 2 || (GR_SP && Cpad % 32 != 0)) return GR_EINVAL;
   const long total = (long)B * Ho * Ho * (Cpad >> 2);
   hipLaunchKernelGGL(upsample_coord_kernel, dim3(gr_cdiv(total, 256)), dim3(256), 0, stream, h, (bf16_t*)out, B, G, Ho,
                      C, Cpad);
@@ -277,12 +346,12 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const bf16_t* __restrict_
   for (int i = 0; i < 8; ++i) s[i] = q[i] = 0.f;
   const int rend = min(HW, r0 + rows_per_block);
   for (int r = r0 + (tid >> 3); r < rend; r += 32) {
-    const bf16x8 v = *(const bf16x8*)(x + ((long)img * HW + r) * C + cblk * 64 + ch);
+    float v[8];
+    ld8f(x, ((long)img * HW + r) * C + cblk * 64 + ch, v);
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-      const float f = bf2f((bf16_t)v[i]);
-      s[i] += f;
-      q[i] += f * f;
+      s[i] += v[i];
+      q[i] += v[i] * v[i];
     }
   }
   // reduce over the 32 row-lanes sharing (tid&7): shuffle within wave over bits 3..5, then LDS across 4 waves
@@ -386,12 +455,10 @@ __device__ __forceinline__ void load_coef(const ShufSrc& s, int img, int c, int 
 }
 __device__ __forceinline__ void load8(const ShufSrc& s, bool norm, const float* a, const float* bb, int img, int y, int x,
                                       int c, int C, float* o) {
-  const bf16x8 v = *(const bf16x8*)(s.x + (((long)img * s.S + y) * s.S + x) * C + c);
+  ld8f(s.x, (((long)img * s.S + y) * s.S + x) * C + c, o);
+  if (norm) {
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    float f = bf2f((bf16_t)v[i]);
-    if (norm) f = fmaxf(f * a[i] + bb[i], 0.f);
-    o[i] = f;
+    for (int i = 0; i < 8; ++i) o[i] = fmaxf(o[i] * a[i] + bb[i], 0.f);
   }
 }
 __global__ __launch_bounds__(256) void fuse_shuffle_kernel(ShufSrc tar, ShufSrc top, ShufSrc down, bf16_t* __restrict__ out,
@@ -434,11 +501,8 @@ __global__ __launch_bounds__(256) void fuse_shuffle_kernel(ShufSrc tar, ShufSrc 
       for (int i = 0; i < 8; ++i) o[i] = hy * (hx * v00[i] + lx * v01[i]) + ly * (hx * v10[i] + lx * v11[i]);
     }
   }
-  union { bf16x8 v; uint32_t u[4]; } pk;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) pk.u[i] = pack2bf(o[2 * i], o[2 * i + 1]);
   const int Sp = S + 2 * pad;
-  *(bf16x8*)(out + (((long)img * Sp + y + pad) * Sp + x + pad) * C + c) = pk.v;
+  st8f(out, (((long)img * Sp + y + pad) * Sp + x + pad) * C + c, o);
 }
 extern "C" int gr_fuse_shuffle(const void* tar, const float* tar_coef, int tarS, const void* top, const float* top_coef,
                                int topS, const void* down, const float* down_coef, int downS, void* out, int imgs, int C,
@@ -462,13 +526,10 @@ __global__ void cast_add_kernel(const float* __restrict__ a, const float* __rest
   if (idx >= n4) return;
   f32x4 v = *(const f32x4*)(a + idx * 4);
   if (b) v += *(const f32x4*)(b + idx * 4);
-  uint2 pk;
-  pk.x = pack2bf(v[0], v[1]);
-  pk.y = pack2bf(v[2], v[3]);
-  *(uint2*)(out + idx * 4) = pk;
+  st4f(out, idx * 4, v);
 }
 extern "C" int gr_cast_f32_bf16(const float* a, const float* b, void* out, long n, hipStream_t stream) {
-  if (!a || !out || n <= 0 || n % 4 != 0) return GR_EINVAL;
+  if (!a || !out || n <= 0 || n % 4 != 0 || (GR_SP && n % 32 != 0)) return GR_EINVAL;
   hipLaunchKernelGGL(cast_add_kernel, dim3(gr_cdiv(n / 4, 256)), dim3(256), 0, stream, a, b, (bf16_t*)out, n / 4);
   GR_CHECK_LAUNCH();
   return GR_OK;
@@ -506,29 +567,23 @@ __global__ void embed_gather_kernel(const long* __restrict__ ids, const bf16_t* 
   const int c = (int)(idx % c8) << 3;
   const long r = idx / c8;
   long id = ids[r];
-  const bf16_t* src;
+  const bf16_t* tab = t0;
   if (id >= V0) {
     id -= V0;
     if (id >= V1) id = V1 - 1;
-    src = t1 + id * C + c;
-  } else {
-    if (id < 0) id = 0;
-    src = t0 + id * C + c;
+    tab = t1;
+  } else if (id < 0) {
+    id = 0;
   }
-  const bf16x8 v = *(const bf16x8*)src;
+  float v[8];
+  ld8f(tab, id * C + c, v);
   float* o = out + r * C + c;
-  f32x4 lo, hi;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    lo[i] = bf2f((bf16_t)v[i]);
-    hi[i] = bf2f((bf16_t)v[4 + i]);
-  }
-  *(f32x4*)o = lo;
-  *(f32x4*)(o + 4) = hi;
+  *(f32x4*)o = (f32x4){v[0], v[1], v[2], v[3]};
+  *(f32x4*)(o + 4) = (f32x4){v[4], v[5], v[6], v[7]};
 }
 extern "C" int gr_embed_gather(const long* ids, const void* table0, const void* table1, float* out, long n, int C,
                                int V0, int V1, hipStream_t stream) {
-  if (!ids || !table0 || !table1 || !out || n <= 0 || C % 8 != 0) return GR_EINVAL;
+  if (!ids || !table0 || !table1 || !out || n <= 0 || C % 8 != 0 || (GR_SP && C % 32 != 0)) return GR_EINVAL;
   hipLaunchKernelGGL(embed_gather_kernel, dim3(gr_cdiv(n * (C >> 3), 256)), dim3(256), 0, stream, ids,
                      (const bf16_t*)table0, (const bf16_t*)table1, out, n, C, V0, V1);
   GR_CHECK_LAUNCH();

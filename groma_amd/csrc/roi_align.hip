@@ -16,7 +16,8 @@
 #include "gr_common.h"
 #include "../../include/groma_hip.h"
 
-__device__ __forceinline__ void bilinear8(const bf16_t* __restrict__ fmap, int H, int W, int C, float y, float x,
+// fmap = base of the image's map, c0 = first of this lane's 8 channels: element indices stay logical (gr_common.h)
+__device__ __forceinline__ void bilinear8(const bf16_t* __restrict__ fmap, long c0, int H, int W, int C, float y, float x,
                                           float* val) {
   if (y < -1.0f || y > (float)H || x < -1.0f || x > (float)W) {
 #pragma unroll
@@ -31,13 +32,13 @@ __device__ __forceinline__ void bilinear8(const bf16_t* __restrict__ fmap, int H
   const float ly = y - y_low, lx = x - x_low;
   const float hy = 1.f - ly, hx = 1.f - lx;
   const float w1 = hy * hx, w2 = hy * lx, w3 = ly * hx, w4 = ly * lx;
-  const bf16x8 v1 = *(const bf16x8*)(fmap + ((long)y_low * W + x_low) * C);
-  const bf16x8 v2 = *(const bf16x8*)(fmap + ((long)y_low * W + x_high) * C);
-  const bf16x8 v3 = *(const bf16x8*)(fmap + ((long)y_high * W + x_low) * C);
-  const bf16x8 v4 = *(const bf16x8*)(fmap + ((long)y_high * W + x_high) * C);
+  float v1[8], v2[8], v3[8], v4[8];
+  ld8f(fmap, ((long)y_low * W + x_low) * C + c0, v1);
+  ld8f(fmap, ((long)y_low * W + x_high) * C + c0, v2);
+  ld8f(fmap, ((long)y_high * W + x_low) * C + c0, v3);
+  ld8f(fmap, ((long)y_high * W + x_high) * C + c0, v4);
 #pragma unroll
-  for (int i = 0; i < 8; ++i)
-    val[i] = w1 * bf2f((bf16_t)v1[i]) + w2 * bf2f((bf16_t)v2[i]) + w3 * bf2f((bf16_t)v3[i]) + w4 * bf2f((bf16_t)v4[i]);
+  for (int i = 0; i < 8; ++i) val[i] = w1 * v1[i] + w2 * v2[i] + w3 * v3[i] + w4 * v4[i];
 }
 
 __global__ __launch_bounds__(256) void roi_align_pack_kernel(const bf16_t* __restrict__ feat, const float* __restrict__ rois,
@@ -64,7 +65,7 @@ __global__ __launch_bounds__(256) void roi_align_pack_kernel(const bf16_t* __res
   const int grid_h = sampling_ratio > 0 ? sampling_ratio : (int)ceilf(roi_height / (float)PH);
   const int grid_w = sampling_ratio > 0 ? sampling_ratio : (int)ceilf(roi_width / (float)PW);
   const float count = (float)max(grid_h * grid_w, 1);
-  const bf16_t* fmap = feat + (long)batch * H * W * C;
+  const bf16_t* fmap = feat + (long)batch * H * W * C * GR_SPW;
   const int c8n = C >> 3;
   const int OPH = PH + 2 * pad, OPW = PW + 2 * pad;
   for (int item = threadIdx.x; item < PW * c8n; item += 256) {
@@ -78,7 +79,7 @@ __global__ __launch_bounds__(256) void roi_align_pack_kernel(const bf16_t* __res
       for (int ix = 0; ix < grid_w; ++ix) {
         const float x = roi_start_w + pw * bin_size_w + ((float)ix + .5f) * bin_size_w / (float)grid_w;
         float val[8];
-        bilinear8(fmap + c, H, W, C, y, x, val);
+        bilinear8(fmap, c, H, W, C, y, x, val);
 #pragma unroll
         for (int i = 0; i < 8; ++i) acc[i] += val[i];
       }
@@ -89,10 +90,10 @@ __global__ __launch_bounds__(256) void roi_align_pack_kernel(const bf16_t* __res
 #pragma unroll
       for (int i = 0; i < 8; ++i) dst[i] = acc[i] / count;
     } else {
-      union { bf16x8 v; uint32_t u[4]; } pk;
+      float r8[8];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) pk.u[i] = pack2bf(acc[2 * i] / count, acc[2 * i + 1] / count);
-      *(bf16x8*)((bf16_t*)out + o) = pk.v;
+      for (int i = 0; i < 8; ++i) r8[i] = acc[i] / count;
+      st8f((bf16_t*)out, o, r8);
     }
   }
 }
@@ -101,6 +102,7 @@ extern "C" int gr_roi_align_pack(const void* feat_nhwc, const float* rois, void*
                                  int pooled_h, int pooled_w, float spatial_scale, int sampling_ratio, int aligned,
                                  int pad, int out_f32, hipStream_t stream) {
   if (R < 0 || C <= 0 || C % 8 != 0 || H <= 0 || W <= 0 || pooled_h <= 0 || pooled_w <= 0) return GR_EINVAL;
+  if (GR_SP && C % 32 != 0) return GR_EINVAL;
   if (pad < 0 || pad > 1) return GR_EINVAL;
   if (R == 0) return GR_OK;  // empty ROI set: nothing to do (reference: roi_align.py:300)
   if (!feat_nhwc || !rois || !out) return GR_EINVAL;

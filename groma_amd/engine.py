@@ -25,6 +25,12 @@ def _ru(x, m):
     return (x + m - 1) // m * m
 
 
+def h16(*shape):
+    """physical shape of a 16-bit buffer with this LOGICAL shape under the active operand type: the innermost extent doubles
+    when the operands are (hi, lo) pairs (precision "ref": ops.SP() == 2, csrc/gr_common.h); kernels take logical sizes"""
+    return tuple(shape[:-1]) + (shape[-1] * ops.SP(),)
+
+
 def normal_mode(fn):
     """Run an entry point of the boundary with autograd off and torch.inference_mode DISABLED, whatever the caller set.
     The reference's callers wrap generate() in `with torch.inference_mode():` (groma/eval/eval_rec.py:92, run_groma.py:82,
@@ -43,7 +49,7 @@ def normal_mode(fn):
 
 def model_entry(precision_of):
     """normal_mode + the model's 16-bit operand type active (ops.precision) for the duration of the call.
-    precision_of(self, *args, **kwargs) -> "bf16" | "fp16"."""
+    precision_of(self, *args, **kwargs) -> "bf16" | "fp16" | "ref"."""
     import functools
 
     def deco(fn):
@@ -208,17 +214,17 @@ class VitEngine:
             img.copy_(images)
         else:
             img = images
-        a = ws.get("vit_patch", (bs * G * G, w["Kpad"]), H16())
+        a = ws.get("vit_patch", h16(bs * G * G, w["Kpad"]), H16())
         kept = [ws.get(f"vit_h{i}", (bs, T, D), F32) for i in range(self.keep)]
         scratch = [ws.get(f"vit_s{i}", (bs, T, D), F32) for i in range(2)]
         mid = ws.get("vit_mid", (bs, T, D), F32)
-        q = None if Q_IN_PLACE else ws.get("vit_q", (bs, H, T, hd), H16())
-        k = ws.get("vit_k", (bs, H, Tp, hd), H16(), zero=True)
-        vt = ws.get("vit_vt", (bs, H, hd, Tp), H16(), zero=True)
-        x_b = ws.get("vit_x", (M, D), H16())
-        qkv_b = ws.get("vit_qkv", (M, 3 * D), H16())
-        ctx_b = ws.get("vit_ctx", (M, D), H16())
-        y_b = ws.get("vit_y", (M, I), H16())
+        q = None if Q_IN_PLACE else ws.get("vit_q", h16(bs, H, T, hd), H16())
+        k = ws.get("vit_k", h16(bs, H, Tp, hd), H16(), zero=True)
+        vt = ws.get("vit_vt", h16(bs, H, hd, Tp), H16(), zero=True)
+        x_b = ws.get("vit_x", h16(M, D), H16())
+        qkv_b = ws.get("vit_qkv", h16(M, 3 * D), H16())
+        ctx_b = ws.get("vit_ctx", h16(M, D), H16())
+        y_b = ws.get("vit_y", h16(M, I), H16())
 
         def out_buf(layer_out_index):  # hidden_states index (0 = embeddings ... nl = last layer)
             j = layer_out_index - (nl + 1 - self.keep)
@@ -383,15 +389,15 @@ class RegionEngine:
         for l in range(3):
             a = _trace(f"reg.up{l}", ops.upsample_coord_pack(hidden3[l], G, S[l], w["Cpad"]))
             maps.append(_trace(f"reg.in{l}", ops.gemm(a, w["in_w"][l], bias=w["in_b"][l],
-                                                      out=ws.get(f"reg_in{l}", (bs * S[l] * S[l], D), H16()))))
+                                                      out=ws.get(f"reg_in{l}", h16(bs * S[l] * S[l], D), H16()))))
         for r in range(rc.num_fuse):
             new_maps, new_coef = [], []
             for l in range(3):
                 top, dow = min(l + 1, 2), max(l - 1, 0)
-                pad = ws.get(f"reg_pad{l}", (bs, S[l] + 2, S[l] + 2, D), H16(), zero=True)
+                pad = ws.get(f"reg_pad{l}", h16(bs, S[l] + 2, S[l] + 2, D), H16(), zero=True)
                 ops.fuse_shuffle((maps[l], sums[l], S[l]), (maps[top], sums[top], S[top]), (maps[dow], sums[dow], S[dow]),
                                  pad, imgs=bs, C=D, shuffle=True, pad=1)
-                out = ws.get(f"reg_conv{l}_{r & 1}", (bs * S[l] * S[l], D), H16())
+                out = ws.get(f"reg_conv{l}_{r & 1}", h16(bs * S[l] * S[l], D), H16())
                 ops.gemm(pad, w["fuse"][r]["w"], conv=(bs, S[l], S[l], D, 0), out=out)
                 if r == 0:
                     _trace(f"reg.pad{l}", pad), _trace(f"reg.conv{l}", out)
@@ -401,7 +407,7 @@ class RegionEngine:
             maps, sums = new_maps, new_coef
         feats = []
         for l in range(3):
-            f = ws.get(f"reg_feat{l}", (bs, S[l], S[l], D), H16())
+            f = ws.get(f"reg_feat{l}", h16(bs, S[l], S[l], D), H16())
             ops.fuse_shuffle((maps[l], sums[l], S[l]), None, None, f, imgs=bs, C=D, shuffle=False, pad=0)
             if rc.num_fuse == 1:  # then maps[l] is the traced round-0 conv output: feat = ReLU(GN(conv))
                 _trace(f"reg.feat{l}", f)
@@ -414,12 +420,12 @@ class RegionEngine:
         R = boxes.shape[0]
         P = rc.roi_size
         rois = torch.cat([img_idx[:, None], boxes * float(self.img)], dim=1).contiguous()  # (idx, "x1,y1,x2,y2") -- T1
-        tiles = ws.get("reg_tiles", (3, R, P + 2, P + 2, D), H16(), zero=True)
+        tiles = ws.get("reg_tiles", h16(3, R, P + 2, P + 2, D), H16(), zero=True)
         for l in range(3):
             ops.roi_align_pack(feats[l], rois, tiles[l], C=D, H=S[l], W=S[l], ph=P, pw=P,
                                spatial_scale=1.0 / self.STRIDES[l], sampling_ratio=2, aligned=True, pad=1)
         pc = ops.gemm(tiles, w["pconv_w"], bias=w["pconv_b"], act=2, conv=(R, P, P, D, R * (P + 2) * (P + 2) * D),
-                      out=ws.get("reg_pc", (R * P * P, D), H16()))
+                      out=ws.get("reg_pc", h16(R * P * P, D), H16()))
         _trace("reg.rois", rois), _trace("reg.tiles", tiles), _trace("reg.pc", pc)
         # pos_embedd(rois) on the UNSCALED cxcywh boxes (roi_align.py:278)
         b16 = torch.zeros((R, 16), dtype=F32, device=boxes.device)
@@ -430,7 +436,7 @@ class RegionEngine:
         pe = ops.layernorm(pe, w["pe_ln2"][0], w["pe_ln2"][1], 1e-5)
         K = P * P * D
         splits = max(1, min(32, K // 4096))
-        fl = ops.gemm(pc.view(R, K), w["flat_w"], bias=w["flat_b"], resid=pe, splits=splits)
+        fl = ops.gemm(pc.view(R, K * ops.SP()), w["flat_w"], bias=w["flat_b"], resid=pe, splits=splits)
         _trace("reg.pe", pe), _trace("reg.fl", fl)
         return _trace("reg.out", ops.gemm(fl, w["up_w"], bias=w["up_b"], out_f32=True))
 
@@ -441,9 +447,10 @@ class KVCache:
     tuple view: cache[l][0].shape == [bs, H, S, hd] (groma/model/groma.py:377-378, groma/serve/model_worker.py:298)."""
 
     def __init__(self, n_layers, bs, H, hd, smax, device):
-        self.k = [torch.zeros((bs, H, smax, hd), dtype=H16(), device=device) for _ in range(n_layers)]
-        self.vt = [torch.zeros((bs, H, hd, smax), dtype=H16(), device=device) for _ in range(n_layers)]
+        self.k = [torch.zeros(h16(bs, H, smax, hd), dtype=H16(), device=device) for _ in range(n_layers)]
+        self.vt = [torch.zeros(h16(bs, H, hd, smax), dtype=H16(), device=device) for _ in range(n_layers)]
         self.seq_len, self.smax, self.bs = 0, smax, bs
+        self.sp = ops.SP()  # 2: (hi, lo) operand pairs, innermost extents doubled (precision "ref")
         self._addr = None
 
     def __len__(self):
@@ -451,6 +458,8 @@ class KVCache:
 
     def __getitem__(self, l):
         S = self.seq_len
+        if self.sp == 2:  # reference-precision cache: hand out the values the pairs stand for (f32)
+            return (ops.unsplit(self.k[l])[:, :, :S], ops.unsplit(self.vt[l])[:, :, :, :S].transpose(2, 3))
         return (self.k[l][:, :, :S], self.vt[l][:, :, :, :S].transpose(2, 3))
 
     def __bool__(self):
@@ -463,8 +472,9 @@ class KVCache:
             k = torch.zeros((self.bs,) + tuple(self.k[l].shape[1:2]) + (smax, self.k[l].shape[3]), dtype=self.k[l].dtype,
                             device=self.k[l].device)
             k[:, :, : self.smax] = self.k[l]
-            v = torch.zeros(tuple(self.vt[l].shape[:3]) + (smax,), dtype=self.vt[l].dtype, device=self.k[l].device)
-            v[..., : self.smax] = self.vt[l]
+            # (capacities are multiples of 64, so the old columns are a whole-block prefix of the new row in either layout)
+            v = torch.zeros(tuple(self.vt[l].shape[:3]) + (smax * self.sp,), dtype=self.vt[l].dtype, device=self.k[l].device)
+            v[..., : self.smax * self.sp] = self.vt[l]
             self.k[l], self.vt[l] = k, v
         self.smax, self._addr = smax, None
 
@@ -506,7 +516,7 @@ class LlamaEngine:
         past = 0 if dyn else cache.seq_len
         if not dyn and past + L > cache.smax:
             cache.grow(_ru(past + L + 64, 64))
-        if L == 1 and M <= 8 and not w["fp8"] and T <= 8192 and cache.smax <= 8192:
+        if L == 1 and M <= 8 and not w["fp8"] and T <= 8192 and cache.smax <= 8192 and ops.SP() == 1:
             return self._decode_forward(h, bs, cache, kv_len, pos_dev, pos_stride, past)
         # A decode step that does not fit the weight-streaming path (more than 8 rows, e4m3 operands, > 8192 keys) runs the
         # general kernels below.  Its scratch may be baked into GreedyDecoder's captured hipGraph, so -- like _decode_forward --
@@ -517,10 +527,10 @@ class LlamaEngine:
         def buf(name, shape, dtype):
             return ws.get(name + "_dec", shape, dtype, exact=True) if dec else ws.get(name, shape, dtype)
 
-        q = None if Q_IN_PLACE else buf("llm_q", (bs, H, L, hd), H16())
+        q = None if Q_IN_PLACE else buf("llm_q", h16(bs, H, L, hd), H16())
         fp8 = w["fp8"]
-        x_b, qkv_b = buf("llm_x", (M, T), H16()), buf("llm_qkv", (M, 3 * T), H16())
-        ctx_b, y_b = buf("llm_ctx", (M, T), H16()), buf("llm_y", (M, self.I), H16())
+        x_b, qkv_b = buf("llm_x", h16(M, T), H16()), buf("llm_qkv", h16(M, 3 * T), H16())
+        ctx_b, y_b = buf("llm_ctx", h16(M, T), H16()), buf("llm_y", h16(M, self.I), H16())
         # a prefill whose shape and memory repeat is replayed from a captured hipGraph (GraphPool): everything the launches
         # bake in goes into the key; the ragged-row lengths are staged into a buffer of our own
         graph = not dec and not fp8 and TRACE is None and GraphPool.enabled
@@ -607,10 +617,10 @@ class LlamaEngine:
         (csrc/decode.hip): 9 launches per layer instead of 13, and a one-block-per-(row, head) attention."""
         w, ws, T, H, hd = self.w, self.ws, self.T, self.H, self.hd
         dyn = pos_dev is not None
-        x = ws.get("dec_x", (bs, T), H16(), exact=True)
-        q = ws.get("dec_q", (bs, H, 1, hd), H16(), exact=True)
-        ctx = ws.get("dec_ctx", (bs, T), H16(), exact=True)
-        y = ws.get("dec_y", (bs, self.I), H16(), exact=True)
+        x = ws.get("dec_x", h16(bs, T), H16(), exact=True)
+        q = ws.get("dec_q", h16(bs, H, 1, hd), H16(), exact=True)
+        ctx = ws.get("dec_ctx", h16(bs, T), H16(), exact=True)
+        y = ws.get("dec_y", h16(bs, self.I), H16(), exact=True)
         part, splits = None, 0
         for i, Lw in enumerate(w["layers"]):
             t0 = TRACE is not None and i == 0

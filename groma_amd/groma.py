@@ -72,8 +72,15 @@ class GromaModel:
         # "bf16" (libgroma_hip.so: BASELINE's benchmark dtype) or "fp16" (libgroma_hip_f16.so: what the reference's inference
         # scripts autocast to, R: groma/eval/run_groma.py:82; same MFMA rate, 3 more mantissa bits).  Accumulation, residual
         # streams, norms and the proposer are fp32 either way.
-        if precision not in ("bf16", "fp16"):
-            raise ValueError(f"precision must be 'bf16' or 'fp16', got {precision!r}")
+        # "ref" (libgroma_hip_ref.so) is the reference-precision path: every operand is a (hi, lo) pair of halves (22 mantissa
+        # bits) and every contraction -- GEMMs, implicit-GEMM convs, both attention products -- issues hi.hi + hi.lo + lo.hi
+        # into the fp32 MFMA accumulators: 3x the MFMA work, within ~1e-6 of fp32 per contraction, which is what keeps the
+        # 24 + 32-layer chain inside north_star's 1e-3 of the reference's fp32 forward (R: groma/eval/eval_rec.py:69 loads fp32
+        # weights).  Same kernels, same launch sequence; 16-bit buffers are twice as wide.
+        if precision not in ("bf16", "fp16", "ref"):
+            raise ValueError(f"precision must be 'bf16', 'fp16' or 'ref', got {precision!r}")
+        if precision == "ref" and fp8:
+            raise ValueError("fp8=True and precision='ref' are exclusive")
         self.precision = precision
         self.decode_graph = True  # generate(): replay one captured hipGraph per token (False = eager per-kernel launches)
         # proposer chain (input_proj -> DDETR encoder x6 -> two-stage top-300 -> decoder x6 -> heads -> score fusion -> NMS,
@@ -143,13 +150,14 @@ class GromaModel:
     def from_pretrained(cls, path, torch_dtype=None, device="cuda", **kw):
         """Reads a reference checkpoint directory: config.json + *.safetensors / pytorch_model*.bin shards with the
         reference's parameter names (groma/eval/eval_rec.py:69).  Weights are repacked to 16-bit device layouts:
-        torch_dtype=torch.float16 (what groma/eval/run_groma.py and the model worker pass) selects the fp16 operand build,
-        anything else bf16; `precision="bf16" | "fp16"` overrides."""
+        torch_dtype=torch.float16 (what groma/eval/run_groma.py and the model worker pass) selects the fp16 operand build, an
+        EXPLICIT torch_dtype=torch.float32 the reference-precision build ("ref": split operands, ~fp32 results at 3x the MFMA
+        work), anything else (None / "auto" / bfloat16) bf16; `precision="bf16" | "fp16" | "ref"` overrides."""
         if torch_dtype not in (None, "auto", torch.float32, torch.float16, torch.bfloat16):
             raise NotImplementedError(f"torch_dtype={torch_dtype}: the MI355X path computes with bf16 or fp16 operands (fp32 accumulate)")
         # torch_dtype states how the CALLER would have held the weights (fp32 in eval_rec.py:69, fp16 in run_groma.py): norms,
         # biases and the proposer stay fp32, the GEMM operands take the 16-bit type
-        precision = kw.get("precision") or ("fp16" if torch_dtype == torch.float16 else "bf16")
+        precision = kw.get("precision") or ("fp16" if torch_dtype == torch.float16 else "ref" if torch_dtype == torch.float32 else "bf16")
         for unsupported in ("load_in_8bit", "load_in_4bit", "quantization_config"):
             if kw.get(unsupported):
                 raise NotImplementedError(f"{unsupported} is not supported by the MI355X path (bf16 / fp32 only)")

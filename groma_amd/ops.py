@@ -15,8 +15,51 @@ FP8 = torch.float8_e4m3fn  # OCP e4m3 (gfx950 native)
 
 
 def H16():
-    """torch dtype of the active 16-bit operand type: bfloat16 (libgroma_hip.so) or float16 (libgroma_hip_f16.so)"""
-    return torch.float16 if _lib.PRECISION[0] == "fp16" else torch.bfloat16
+    """torch dtype of the active 16-bit operand type: bfloat16 (libgroma_hip.so) or float16 (libgroma_hip_f16.so, and the
+    halves of libgroma_hip_ref.so's operand pairs)"""
+    return torch.bfloat16 if _lib.PRECISION[0] == "bf16" else torch.float16
+
+
+def SP():
+    """physical 16-bit elements per logical operand element: 2 under precision "ref" (libgroma_hip_ref.so: every operand is a
+    (hi, lo) pair of halves, 32-element blocks interleaved along the innermost axis -- csrc/gr_common.h), else 1.  16-bit
+    buffers are allocated SP() times as wide; every size handed to the C ABI stays logical."""
+    return 2 if _lib.PRECISION[0] == "ref" else 1
+
+
+def split_pack(t):
+    """f32 [..., K] (K % 32 == 0) -> the split-operand storage of libgroma_hip_ref.so: half [..., 2K] with
+    hi = f16(x), lo = f16(x - hi) interleaved in blocks of 32 (load-time / test plumbing; the kernels write this layout
+    themselves on the forward path)"""
+    t = t.float().clamp(-65504.0, 65504.0)
+    K = t.shape[-1]
+    if K % 32:
+        raise ValueError(f"split operand rows must be multiples of 32 elements, got {K}")
+    hi = t.to(torch.float16)
+    lo = (t - hi.float()).to(torch.float16)
+    return torch.stack((hi.reshape(*t.shape[:-1], K // 32, 32), lo.reshape(*t.shape[:-1], K // 32, 32)), dim=-2) \
+        .reshape(*t.shape[:-1], 2 * K).contiguous()
+
+
+def unsplit(t):
+    """inverse view of split_pack: half [..., 2K] -> f32 [..., K] = hi + lo (exact in fp32)"""
+    K2 = t.shape[-1]
+    v = t.reshape(*t.shape[:-1], K2 // 64, 2, 32).float()
+    return (v[..., 0, :] + v[..., 1, :]).reshape(*t.shape[:-1], K2 // 2)
+
+
+def to_h16(t):
+    """f32 values -> the active operand storage (bf16 / fp16 cast, or the split pair layout)"""
+    if SP() == 2:
+        return split_pack(t)
+    if H16() == torch.float16:
+        t = t.float().clamp(-65504.0, 65504.0)  # the device-side conversions saturate too (gr_common.h sat_h16): never inf
+    return t.to(H16()).contiguous()
+
+
+def from_h16(t):
+    """operand storage -> f32 values (tests / the legacy KV view)"""
+    return unsplit(t) if SP() == 2 else t.float()
 
 
 class precision:
@@ -25,7 +68,7 @@ class precision:
     precision and wraps its entry points in this; "bf16" is the process default."""
 
     def __init__(self, p):
-        if p not in ("bf16", "fp16"):
+        if p not in ("bf16", "fp16", "ref"):
             raise ValueError(f"unknown precision {p!r}")
         self.p = p
 
@@ -76,7 +119,7 @@ def _gemv_ws(splits, M, N, device):
 #              One image per call: 39 -> 47 img/s (o-proj / down-proj / ViT fc2 / bridge leave most CUs idle otherwise); at
 #              large M it costs the partial-sum traffic, which is why it is a plan the CALLER picks (GromaModel.gemm_plan),
 #              not something inferred from the batch.
-_PLAN = ["throughput"]
+_PLAN = _lib.ThreadSlot("throughput")  # per thread, like the operand type (groma_amd/_lib.py)
 _PLAN_REF_ROWS = 640
 
 
@@ -135,7 +178,8 @@ def gemm(a, w, *, out=None, bias=None, scale=None, resid=None, act=0, out_f32=Fa
             raise ValueError("fp8 gemm needs w_scale")
     else:
         _chk(a, H16(), "a"); _chk(w, H16(), "w")
-    N, K = w.shape
+    sp = 1 if fp8 else SP()
+    N, K = w.shape[0], w.shape[1] // sp  # logical K
     d = GemmDesc()
     d.fp8 = int(fp8)
     d.a_scale = _chk(a_scale, F32, "a_scale").data_ptr() if a_scale is not None else None
@@ -148,18 +192,19 @@ def gemm(a, w, *, out=None, bias=None, scale=None, resid=None, act=0, out_f32=Fa
     else:
         if M is None:
             M = a.numel() // a.shape[-1]
-        d.lda = lda if lda is not None else a.shape[-1]
-        if a.shape[-1] != K and lda is None:
-            raise ValueError(f"gemm: K mismatch {a.shape[-1]} vs {K}")
-    if tile == 0 and conv is None and not fp8 and M <= 8 and splits == 1 and N * K >= (1 << 20):
+        d.lda = lda if lda is not None else a.shape[-1] // sp
+        if a.shape[-1] != K * sp and lda is None:
+            raise ValueError(f"gemm: K mismatch {a.shape[-1] // sp} vs {K}")
+    if tile == 0 and conv is None and not fp8 and M <= 8 and splits == 1 and N * K >= (1 << 20) and sp == 1:
         tile, splits = 1, (K + 511) // 512  # decode step: weight-streaming kernel + deterministic split-K reduce
         ws = _gemv_ws(splits, M, N, a.device)
     # (the implicit-conv GEMMs are never split by the plan: measured gain at one image per GPU was within box-to-box spread)
     elif tile == 0 and conv is None and not fp8 and splits == 1 and ws is None and M > 8:
         splits = plan_splits(N, K)
     n_out = N // 2 if act == 3 else N
+    osp = 1 if out_f32 else sp  # 16-bit outputs are operand pairs too
     if out is None:
-        out = torch.empty((M, n_out), dtype=F32 if out_f32 else H16(), device=a.device)
+        out = torch.empty((M, n_out * osp), dtype=F32 if out_f32 else H16(), device=a.device)
     _chk(out, F32 if out_f32 else H16(), "out")
     if splits > 1 and ws is None:
         ws = _split_ws(splits, M, N, a.device)
@@ -169,8 +214,8 @@ def gemm(a, w, *, out=None, bias=None, scale=None, resid=None, act=0, out_f32=Fa
     d.resid = _chk(resid, F32, "resid").data_ptr() if resid is not None else None
     d.ws = ws.data_ptr() if ws is not None else None
     d.M, d.N, d.K = M, N, K
-    d.ldw = w.stride(0)
-    d.ldc = ldc if ldc is not None else out.shape[-1]
+    d.ldw = w.stride(0) // sp
+    d.ldc = ldc if ldc is not None else out.shape[-1] // osp
     d.ldr = ldr if ldr is not None else (resid.shape[-1] if resid is not None else 0)
     d.act, d.out_f32, d.splits = act, int(out_f32), splits
     d.resid_mod = resid_mod
@@ -259,6 +304,10 @@ def decode_attention(q, k, vt, out, *, Smax, q_pos0=0, kv_len=None, scale=None, 
     return out
 
 
+def _h16_shape(shape):
+    return tuple(shape[:-1]) + (shape[-1] * SP(),)
+
+
 def gemm_f32(a, w, *, bias=None, resid=None, act=0, out=None, M=None, lda=None, ldc=None):
     lib = _lib.load()
     _chk(a, F32, "a"); _chk(w, F32, "w")
@@ -280,7 +329,7 @@ def layernorm(x, gamma, beta, eps, *, add=None, out_bf16=False, relu_in=False, o
     C = x.shape[-1]
     rows = x.numel() // C
     if out is None:
-        out = torch.empty(x.shape, dtype=H16() if out_bf16 else F32, device=x.device)
+        out = torch.empty(_h16_shape(x.shape) if out_bf16 else x.shape, dtype=H16() if out_bf16 else F32, device=x.device)
     _lib.check(lib.gr_layernorm(_p(x), _p(add), _p(gamma), _p(beta), _p(out), rows, C, C, C, eps, int(out_bf16),
                                 int(relu_in), _stream()), "gr_layernorm")
     return out
@@ -292,7 +341,7 @@ def rmsnorm(x, gamma, eps, *, out_bf16=True, out=None):
     C = x.shape[-1]
     rows = x.numel() // C
     if out is None:
-        out = torch.empty(x.shape, dtype=H16() if out_bf16 else F32, device=x.device)
+        out = torch.empty(_h16_shape(x.shape) if out_bf16 else x.shape, dtype=H16() if out_bf16 else F32, device=x.device)
     _lib.check(lib.gr_rmsnorm(_p(x), _p(gamma), _p(out), rows, C, C, C, eps, int(out_bf16), _stream()), "gr_rmsnorm")
     return out
 
@@ -306,14 +355,15 @@ def attention(q, k, vt, *, Skv, causal, q_pos0=0, kv_len=None, scale=None, out=N
     q_ld, cos, sin = 0, None, None
     if fused is not None:  # q = the fused projection buffer [B*Lq, ld]; fused = dict(B, H, Lq, hd, cos=None, sin=None)
         B, H, Lq, hd = fused["B"], fused["H"], fused["Lq"], fused["hd"]
-        q_ld, cos, sin = q.shape[-1], fused.get("cos"), fused.get("sin")
+        q_ld, cos, sin = q.shape[-1] // SP(), fused.get("cos"), fused.get("sin")
     else:
         B, H, Lq, hd = q.shape
+        hd //= SP()
     kv_stride = k.shape[2]
     if scale is None:
         scale = hd ** -0.5
     if out is None:
-        out = torch.empty((B * Lq, H * hd), dtype=H16(), device=q.device)
+        out = torch.empty((B * Lq, H * hd * SP()), dtype=H16(), device=q.device)
     if kv_len is not None:
         _chk(kv_len, I32, "kv_len")
     if pos_dev is not None:
@@ -340,7 +390,7 @@ def patchify(images, P, Kpad, out=None):
     B, _, S, _ = images.shape
     G = S // P
     if out is None:
-        out = torch.empty((B * G * G, Kpad), dtype=H16(), device=images.device)
+        out = torch.empty((B * G * G, Kpad * SP()), dtype=H16(), device=images.device)
     _chk(out, H16(), "out")
     _lib.check(lib.gr_patchify(_p(images), _p(out), B, S, P, Kpad, _stream()), "gr_patchify")
     return out
@@ -362,7 +412,7 @@ def mean4_tokens(h0, h1, h2, h3):
 def s2d_pack(h, G):
     lib = _lib.load()
     B, T, C = h.shape
-    out = torch.empty((B * (G // 2) ** 2, 4 * C), dtype=H16(), device=h.device)
+    out = torch.empty((B * (G // 2) ** 2, 4 * C * SP()), dtype=H16(), device=h.device)
     _lib.check(lib.gr_s2d_pack(_p(h), _p(out), B, G, C, _stream()), "gr_s2d_pack")
     return out
 
@@ -370,7 +420,7 @@ def s2d_pack(h, G):
 def upsample_coord_pack(h, G, Ho, Cpad):
     lib = _lib.load()
     B, T, C = h.shape
-    out = torch.empty((B * Ho * Ho, Cpad), dtype=H16(), device=h.device)
+    out = torch.empty((B * Ho * Ho, Cpad * SP()), dtype=H16(), device=h.device)
     _lib.check(lib.gr_upsample_coord_pack(_p(h), _p(out), B, G, Ho, C, Cpad, _stream()), "gr_upsample_coord_pack")
     return out
 
@@ -399,7 +449,7 @@ def fuse_shuffle(tar, top, down, out, *, imgs, C, shuffle, pad):
 def cast_bf16(a, b=None):
     lib = _lib.load()
     _chk(a, F32, "a")
-    out = torch.empty(a.shape, dtype=H16(), device=a.device)
+    out = torch.empty(_h16_shape(a.shape), dtype=H16(), device=a.device)
     _lib.check(lib.gr_cast_f32_bf16(_p(a), _p(b), _p(out), a.numel(), _stream()), "gr_cast_f32_bf16")
     return out
 
@@ -417,7 +467,7 @@ def add_rows(a, b, b_mod=0, out=None):
 def embed_gather(ids, table0, table1, out=None):
     lib = _lib.load()
     _chk(ids, I64, "ids")
-    C = table0.shape[1]
+    C = table0.shape[1] // SP()
     if out is None:
         out = torch.empty((ids.numel(), C), dtype=F32, device=ids.device)
     _lib.check(lib.gr_embed_gather(_p(ids), _p(table0), _p(table1), _p(out), ids.numel(), C, table0.shape[0],

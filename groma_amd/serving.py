@@ -84,13 +84,15 @@ class _RowView:
     def __init__(self, arena, n):
         self.k = [t[:n] for t in arena.k]
         self.vt = [t[:n] for t in arena.vt]
-        self.bs, self.smax, self.seq_len = n, arena.smax, 0
+        self.bs, self.smax, self.seq_len, self.sp = n, arena.smax, 0, getattr(arena, "sp", 1)
 
     def __len__(self):
         return len(self.k)
 
     def __getitem__(self, l):
         S = self.seq_len
+        if self.sp == 2:  # reference-precision cache (engine.KVCache): the values the operand pairs stand for
+            return (ops.unsplit(self.k[l])[:, :, :S], ops.unsplit(self.vt[l])[:, :, :, :S].transpose(2, 3))
         return (self.k[l][:, :, :S], self.vt[l][:, :, :, :S].transpose(2, 3))
 
     def __bool__(self):

@@ -9,6 +9,7 @@ import math
 import torch
 import torch.nn.functional as F
 
+from . import ops
 from .ops import H16  # dtype of the active 16-bit operand type (the model being built sets ops.precision around packing)
 
 F32 = torch.float32
@@ -53,7 +54,9 @@ class Source:
 
 
 def bf(t):
-    return t.to(H16()).contiguous()
+    """f32 [.., K] -> the active operand storage: bf16 / fp16 (saturating, like the device-side conversions), or the
+    (hi, lo) pair layout of precision "ref" (twice as wide; ops.split_pack)"""
+    return ops.to_h16(t)
 
 
 FP8 = torch.float8_e4m3fn
@@ -67,7 +70,9 @@ def q8(t):
 
 
 def wq(t, fp8):
-    """GEMM weight in the compute format of the engine: bf16, or (e4m3, per-row scale)"""
+    """GEMM weight in the compute format of the engine: bf16 / fp16 / operand pairs, or (e4m3, per-row scale)"""
+    if fp8 and ops.SP() == 2:
+        raise NotImplementedError("e4m3 operands and the reference-precision build are exclusive")
     return q8(t) if fp8 else (bf(t), None)
 
 
@@ -256,9 +261,9 @@ def pack_llm(W, cfg, fp8=False):
     out["norm"] = W("llm.model.norm.weight")
     V = lc.vocab_size + cfg.num_new_token
     Vp = _ru(V, 128)
-    head = torch.zeros((Vp, T), dtype=H16(), device=W.device)
-    head[: lc.vocab_size] = W("llm.lm_head.weight").to(H16())
-    head[lc.vocab_size: V] = W("extra_lm_head.weight").to(H16())
+    head = torch.zeros((Vp, T * ops.SP()), dtype=H16(), device=W.device)
+    head[: lc.vocab_size] = bf(W("llm.lm_head.weight"))
+    head[lc.vocab_size: V] = bf(W("extra_lm_head.weight"))
     out["head"], out["V"], out["Vpad"] = head, V, Vp
     hd = T // lc.num_attention_heads
     inv = 1.0 / (lc.rope_theta ** (torch.arange(0, hd, 2, dtype=F32) / hd))

@@ -18,6 +18,16 @@
  * points autocast to (groma/eval/run_groma.py:82, groma/serve/model_worker.py:256).  In the second build every parameter this
  * header calls "bf16" holds half bit patterns (conversions saturate at +-65504); names and signatures are identical, and
  * gr_operand_type() tells a host which build it has loaded.
+ *
+ * A third build, libgroma_hip_ref.so (-DGR_F16 -DGR_SPLIT), is the reference-precision path: its "16-bit operand" is a PAIR of
+ * halves, x ~= hi + lo with hi = f16(x), lo = f16(x - hi) (22 mantissa bits), and every contraction issues hi.hi + hi.lo + lo.hi
+ * into the same fp32 MFMA accumulators -- 3x the MFMA work, within ~1e-6 of an fp32 GEMM, which is what a 32-layer-deep chain
+ * needs to stay inside north_star's 1e-3 of the reference's fp32 path (groma/eval/eval_rec.py:69 loads fp32 weights).
+ * Storage: a logical 16-bit tensor of n elements occupies 2n; logical element i (flat) sits at physical element
+ * (i / 32) * 64 + i % 32 (hi) and 32 elements further (lo).  Every size / stride / index argument of this header stays
+ * LOGICAL; only the buffers double.  Innermost extents and row strides of 16-bit tensors must be multiples of 32 there
+ * (GR_EINVAL otherwise).  Entry points without a split form (the weight-streaming decode kernels, tile 1 / 2 of gr_gemm_bf16,
+ * the e4m3 path) return GR_EINVAL in that build; a decode step runs through the general kernels.
  */
 #ifndef GROMA_HIP_H
 #define GROMA_HIP_H
@@ -36,6 +46,7 @@ typedef struct ihipStream_t* hipStream_t;
 int gr_abi_version(void);
 #define GR_OPERAND_BF16 0
 #define GR_OPERAND_F16 1
+#define GR_OPERAND_SPLIT 2 /* libgroma_hip_ref.so: (hi, lo) pairs of halves, see below */
 /* the 16-bit operand type this build of the library was compiled for */
 int gr_operand_type(void);
 /* kernel timing hook used by bench.py: when enabled, every gr_gemm_bf16 launch is bracketed by HIP

@@ -9,8 +9,14 @@ copy never exists (a layer's tensors are dropped as soon as the oracle has used 
 Three distances are reported for every stage (relative L2): device <-> fp32 oracle, device <-> bf16-rounded oracle, and
 bf16-rounded oracle <-> fp32 oracle -- the last one is what the bf16 FORMAT costs any implementation at this depth, so the
 first must not be materially worse than it.  The oracles consume the device's ViT states for the stages behind the ViT (stage
-chaining, SURVEY 'Hard parts') and run their own 24-layer ViT for the ViT comparison.  ~1.5 minutes, most of it the two oracle
-passes on the host cores."""
+chaining, SURVEY 'Hard parts') and run their own 24-layer ViT for the ViT comparison; what survives WITHOUT chaining (the fp32
+oracle's proposer fed its own ViT states) is reported beside it: fraction of the top-300 / NMS ids that agree, next to the
+oracle's smallest adjacent logit gap and the device's logit error.  ~1.5 minutes, most of it the two oracle passes on the host
+cores.
+
+precision="ref" (operand pairs, csrc/gr_common.h) is compared UNCHAINED only: one fp32 oracle pass that runs its own ViT end to
+end, which is the reference's computation (R: groma/model/groma.py:222-280,389-402 in one fp32 pass); there is no rounded
+oracle for it -- pure fp32 is its oracle."""
 import os, sys, time, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
@@ -43,8 +49,8 @@ class LazyDeviceStateDict:
 
 
 def run(seed=0, precision="bf16"):
-    """-> dict of the measured numbers (also printed).  precision: the 16-bit operand type of the device model AND of the
-    rounded oracle it is compared with ("bf16" | "fp16")"""
+    """-> dict of the measured numbers (also printed).  precision: the operand type of the device model AND of the rounded
+    oracle it is compared with ("bf16" | "fp16"), or "ref": device vs the fp32 oracle, unchained"""
     torch.set_num_threads(min(64, os.cpu_count() or 8))
     full = gconfig.groma_7b(box_score_thres=0.0)
     dev = torch.device("cuda")
@@ -56,9 +62,10 @@ def run(seed=0, precision="bf16"):
     sd = LazyDeviceStateDict(full, seed, dev)
     # spot check: the lazy dict serves exactly what the device model packed (distinct per layer)
     a, b = sd["llm.model.layers.0.mlp.down_proj.weight"], sd["llm.model.layers.31.mlp.down_proj.weight"]
-    h16 = torch.float16 if precision == "fp16" else torch.bfloat16
-    assert not torch.equal(a, b) and torch.equal(a.to(h16), model.llm.w["layers"][0]["wd"][0].cpu())
-    assert torch.equal(b.to(h16), model.llm.w["layers"][31]["wd"][0].cpu())
+    from groma_amd import ops
+    with ops.precision(precision):
+        assert not torch.equal(a, b) and torch.equal(ops.to_h16(a), model.llm.w["layers"][0]["wd"][0].cpu())
+        assert torch.equal(ops.to_h16(b), model.llm.w["layers"][31]["wd"][0].cpu())
     print(f"device model (distinct per-layer weights) packed in {time.time() - t:.1f} s")
     rel = util.relerr
     cd = full.to_dict()
@@ -67,15 +74,37 @@ def run(seed=0, precision="bf16"):
         out = model.forward(input_ids=ids.clone(), images=images, return_dict=True, output_hidden_states=True, use_cache=True)
         aux = model._last_aux
         dev_h = [h.float().cpu() for h in aux["hidden4"]]
+        dbg = {}
+        model.proposer.forward(aux["hidden4"], debug=dbg)   # the device's own class logits (arena views of this forward)
+        dev_cls = dbg["enc_class"].float().cpu()
+        unchained = precision == "ref"
         ref, ref_v = {}, {}
-        for mode in (None, precision):
+        for mode in ((None,) if unchained else (None, precision)):
             t = time.time()
             with O.rounding(mode):
-                ref_v[mode] = O.vit_forward(sd, cd, images)[-4:]
+                own = O.vit_forward(sd, cd, images)
+                ref_v[mode] = own[-4:]
                 torch.manual_seed(77)
-                ref[mode] = O.groma_forward(sd, cd, util.tok_dict(tk), ids.clone(), images, hidden_states=tuple(dev_h))
-            print(f"oracle ({'fp32' if mode is None else precision + '-rounded'}): 24-layer ViT + proposer + region encoder + 32-layer LLaMA in {time.time() - t:.1f} s")
-    r32, r16 = ref[None], ref[precision]
+                ref[mode] = O.groma_forward(sd, cd, util.tok_dict(tk), ids.clone(), images,
+                                            hidden_states=tuple(own) if unchained else tuple(dev_h))
+            print(f"oracle ({'fp32' if mode is None else precision + '-rounded'}{', UNCHAINED (its own ViT states)' if unchained else ''}): "
+                  f"24-layer ViT + proposer + region encoder + 32-layer LLaMA in {time.time() - t:.1f} s")
+        # what the index-valued results do WITHOUT stage chaining: the fp32 oracle's proposer on the oracle's own ViT states
+        torch.manual_seed(77)
+        per = ref[None] if unchained else O.perceive(sd, cd, images, hidden_states=tuple(ref_v[None]))
+    o_cls = per["det"]["enc_class"]
+    srt = torch.sort(o_cls, dim=1, descending=True, stable=True)[0]
+    Q = aux["topk_idx"].shape[1]
+    d_ids, o_ids = aux["topk_idx"].cpu().long(), per["det"]["topk_idx"]
+    un = dict(topk_pos_equal=(d_ids == o_ids).float().mean().item(),
+              topk_set_overlap=len(set(d_ids[0].tolist()) & set(o_ids[0].tolist())) / Q,
+              nms_equal=torch.equal(aux["nms_keep"][0], per["nms_inds"][0]),
+              nms_set_overlap=len(set(aux["nms_keep"][0].tolist()) & set(per["nms_inds"][0].tolist())) / max(1, len(per["nms_inds"][0])),
+              min_gap=(srt[:, :Q] - srt[:, 1:Q + 1]).min().item(), cls_err=(dev_cls - o_cls).abs().max().item())
+    print(f"UNCHAINED (oracle runs its own fp32 ViT): top-300 ids equal at {un['topk_pos_equal']:.3f} of slots, set overlap {un['topk_set_overlap']:.3f}; "
+          f"NMS ids equal: {un['nms_equal']} (set overlap {un['nms_set_overlap']:.3f}); oracle min adjacent gap of the top-301 logits "
+          f"{un['min_gap']:.2e}, device class-logit max abs error {un['cls_err']:.2e}")
+    r32, r16 = ref[None], ref[None if unchained else precision]
     eq = dict(topk_equal=torch.equal(aux["topk_idx"].cpu().long(), r32["det"]["topk_idx"]),
               nms_equal=torch.equal(aux["nms_keep"][0], r32["nms_inds"][0]),
               ids_equal=torch.equal(aux["input_ids"], r32["input_ids"]) and torch.equal(r16["input_ids"], r32["input_ids"]))
@@ -85,12 +114,18 @@ def run(seed=0, precision="bf16"):
 
     def three(name, d, f):
         a, b, c = rel(d, f(r32)), rel(d, f(r16)), rel(f(r16), f(r32))
-        print(f"{name:42s} device<->fp32 {a:.3e} | device<->{precision}-rounded {b:.3e} | {precision}-rounded<->fp32 {c:.3e} | ratio {a / c:.2f}")
+        if unchained:
+            print(f"{name:42s} device<->fp32 oracle (unchained) {a:.3e}")
+        else:
+            print(f"{name:42s} device<->fp32 {a:.3e} | device<->{precision}-rounded {b:.3e} | {precision}-rounded<->fp32 {c:.3e} | ratio {a / c:.2f}")
         return a, b, c
-    res = {}
-    res["vit"] = [(rel(a, b), rel(a, c), rel(c, b)) for a, b, c in zip(dev_h, ref_v[None], ref_v[precision])]
+    res = {"unchained": un}
+    res["vit"] = [(rel(a, b), rel(a, c), rel(c, b)) for a, b, c in zip(dev_h, ref_v[None], ref_v[None if unchained else precision])]
     for i, (a, b, c) in enumerate(res["vit"]):
-        print(f"{'ViT state ' + str(21 + i) + ' layers deep':42s} device<->fp32 {a:.3e} | device<->{precision}-rounded {b:.3e} | {precision}-rounded<->fp32 {c:.3e} | ratio {a / c:.2f}")
+        if unchained:
+            print(f"{'ViT state ' + str(21 + i) + ' layers deep':42s} device<->fp32 oracle {a:.3e}")
+        else:
+            print(f"{'ViT state ' + str(21 + i) + ' layers deep':42s} device<->fp32 {a:.3e} | device<->{precision}-rounded {b:.3e} | {precision}-rounded<->fp32 {c:.3e} | ratio {a / c:.2f}")
     res["image_tokens"] = three("image tokens (s2d + bridge)", vis["image_features"], lambda r: r["image_features"])
     res["region_tokens"] = three("region tokens (5 fusion rounds + RoI)", vis["region_features"], lambda r: r["region_features"])
     res["k0"] = three("K cache layer 0", out.past_key_values[0][0], lambda r: r["past"][0][0])

@@ -18,13 +18,29 @@ def test_header_symbols_are_exported_and_typed():
     from groma_amd import _lib
     names = _declared()
     assert len(names) >= 25
-    for path in (_lib.LIB_PATH, _lib.LIB_PATH_F16):   # the two builds of the one ABI (bf16 / fp16 operands)
+    for path in (_lib.LIB_PATH, _lib.LIB_PATH_F16, _lib.LIB_PATH_REF):   # the three builds of the one ABI (bf16 / fp16 / split operands)
         lib = ctypes.CDLL(path)
         for n in names:
             assert hasattr(lib, n), f"{n} declared in include/groma_hip.h but not exported by {path}"
     assert set(names) == set(_lib.SIGNATURES), "ctypes signature table out of sync with the header"
     assert _lib.load().gr_abi_version() == 6 and _lib.load().gr_operand_type() == 0
     assert _lib.load("fp16").gr_abi_version() == 6 and _lib.load("fp16").gr_operand_type() == 1
+    assert _lib.load("ref").gr_abi_version() == 6 and _lib.load("ref").gr_operand_type() == 2
+
+
+def test_split_build_rejects_what_it_has_no_form_of():
+    """libgroma_hip_ref.so: the streaming decode kernels / e4m3 path return EINVAL before any launch (include/groma_hip.h)"""
+    from groma_amd import _lib
+    lib = _lib.load("ref")
+    d = _lib.GemmDesc()
+    d.A = d.W = d.C = d.ws = 1  # non-null; validation only
+    d.M, d.N, d.K, d.lda, d.ldw, d.ldc = 4, 4096, 4096, 4096, 4096, 4096
+    d.tile, d.splits = 1, 8
+    assert lib.gr_gemm_bf16(ctypes.byref(d), None) == 22
+    d.tile, d.splits, d.lda = 0, 1, 4100  # a 16-bit row stride that is not whole (hi, lo) blocks
+    assert lib.gr_gemm_bf16(ctypes.byref(d), None) == 22
+    assert lib.gr_decode_attention(ctypes.c_void_p(1), ctypes.c_void_p(1), ctypes.c_void_p(1), ctypes.c_void_p(1), None, 1, 1, 1, 64, 64,
+                                   0, 1.0, None, 0, 1, None, None) == 22
 
 
 def test_bad_arguments_are_rejected_without_a_gpu():

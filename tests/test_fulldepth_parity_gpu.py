@@ -6,7 +6,8 @@ most of it the two oracle passes on the host cores.  R: groma/model/groma.py:202
 Asserted: index-valued results identical (top-300 ids, NMS ids, spliced ids); the device is no further from the fp32 oracle
 than 1.5x what the bf16 format itself costs at this depth (bf16-rounded oracle <-> fp32 oracle), stage by stage; the
 bf16-rounded oracle is the closer reference; arg-max identical on every clear-margin position.
-Measured numbers: profiles/r03_fulldepth_distinct.txt."""
+Round 4: the same run with fp16 operands is asserted too, and precision="ref" (operand pairs) is held to north_star's 1e-3 against
+an UNCHAINED fp32 oracle.  Measured numbers: profiles/r04_fulldepth_*.txt."""
 import importlib.util
 import os
 
@@ -15,19 +16,55 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-def test_full_depth_distinct_weights_vs_both_oracles(dev):
+def _diag():
     here = os.path.dirname(os.path.abspath(__file__))
     spec = importlib.util.spec_from_file_location("fulldepth_parity", os.path.join(here, "diag", "fulldepth_parity.py"))
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
-    r = mod.run()
-    assert r["topk_equal"] and r["nms_equal"] and r["ids_equal"] and r["L"] == 582
+    return mod
+
+
+def _format_gates(r, slack):
+    """the device is no further from the fp32 oracle than `slack` x what the operand FORMAT itself costs at that depth, and the
+    rounded oracle is the closer reference (or as close)"""
     for name in ("image_tokens", "region_tokens", "k0", "k31", "logits", "region_logits"):
         d32, d16, fmt = r[name]
-        assert d32 <= 1.5 * fmt, (name, r[name])      # no worse than the format's own distance (x1.5)
-        assert d16 <= d32 * 1.05, (name, r[name])     # and the bf16-rounded oracle is the closer one (or as close)
+        assert d32 <= slack * fmt, (name, r[name])
+        assert d16 <= d32 * 1.05, (name, r[name])
+
+
+def test_full_depth_distinct_weights_vs_both_oracles(dev):
+    r = _diag().run()
+    assert r["topk_equal"] and r["nms_equal"] and r["ids_equal"] and r["L"] == 582
+    _format_gates(r, 1.5)
     for d32, d16, fmt in r["vit"][1:]:
         assert d32 <= 1.5 * fmt and d32 < 1e-2
-    assert r["logits"][0] < 4e-2                       # 32 layers deep (aliased-layer run of round 2: 1.6e-2)
+    d32, d16, fmt = r["logits"]
+    assert d32 <= 1.1 * fmt                            # 32 layers deep: the bf16 format's own distance (2.6e-2), within 10 %
     assert r["argmax_agree_clear"] == 1.0
     assert r["argmax_agree"] >= r["argmax_agree_bf16_oracle"] - 0.05
+
+
+def test_full_depth_fp16_operands(dev):
+    """the fp16 operand build at the real depth (profiles/r03_fulldepth_fp16.txt was a diag print until round 4)"""
+    r = _diag().run(precision="fp16")
+    assert r["topk_equal"] and r["nms_equal"] and r["ids_equal"] and r["L"] == 582
+    _format_gates(r, 1.5)
+    d32, d16, fmt = r["logits"]
+    assert d32 <= 4e-3 and d32 <= 1.1 * fmt            # measured 3.3e-3 = the half format's own distance at this depth
+    assert r["argmax_agree"] >= 0.98 and r["argmax_agree_clear"] == 1.0
+
+
+def test_full_depth_reference_precision_unchained(dev):
+    """precision="ref" (operand pairs, 3-pass contractions) against ONE fp32 oracle pass that runs its own ViT: north_star's
+    "logits within 1e-3 of reference" and configs[1]'s "box-index bit-exact vs ref" at the real depth, no stage chaining
+    (R: groma/model/groma.py:222-280,389-402; eval loads fp32 weights, groma/eval/eval_rec.py:69)"""
+    r = _diag().run(precision="ref")
+    un = r["unchained"]
+    assert r["topk_equal"] and r["nms_equal"] and r["ids_equal"] and r["L"] == 582
+    assert un["topk_pos_equal"] == 1.0 and un["nms_equal"]   # (oracle min gap / device logit error are printed beside it)
+    for d32, _, _ in r["vit"]:
+        assert d32 < 1e-4
+    for name in ("image_tokens", "region_tokens", "k0", "k31", "logits", "region_logits"):
+        assert r[name][0] <= 1e-3, (name, r[name])    # the north-star tolerance, every stage, 24 + 32 layers deep
+    assert r["argmax_agree"] >= 0.999
