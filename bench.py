@@ -293,6 +293,51 @@ def measure(model, cfg, args, dev, rank, job, P, gen, batch, plan="throughput", 
     return elapsed, step
 
 
+def launch_roofline(m, step, n, kind):
+    """Roofline block of a secondary line: `n` more steps of `step` with HIP events (on the launch stream) around every GEMM
+    launch of model m's library, launched eagerly (the hook sits in the launch functions, not in replayed graphs).
+    kind "mfma": the 256x256 MFMA GEMM against the dense peak of the operand type (bf16 / fp16 2.5 PF, e4m3 5 PF); for the
+    reference-precision build the MFMA work is 3x the algorithmic flops (hi.hi + hi.lo + lo.hi) and both are reported.
+    kind "hbm": the decode-step weight-streaming kernel against 8 TB/s (bytes = the N x K 16-bit weight, read once per launch)."""
+    from groma_amd import engine, ops
+    old_graph, old_pool = m.decode_graph, engine.GraphPool.enabled
+    m.decode_graph, engine.GraphPool.enabled = False, False
+    try:
+        with ops.precision(m.precision):
+            ops.prof_enable(True)
+        for i in range(n):
+            step(1000 + i)
+        torch.cuda.synchronize()
+        with ops.precision(m.precision):
+            ops.prof_enable(False)
+            recs = ops.prof_read_launches()
+    finally:
+        m.decode_graph, engine.GraphPool.enabled = old_graph, old_pool
+    if kind == "hbm":
+        gv = [r for r in recs if r[3] & 8]
+        ms = sum(r[4] for r in gv)
+        nbytes = sum(2.0 * r[1] * r[2] for r in gv)
+        ach = nbytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+        return {"bound": "hbm", "kernel": "gemv_bf16_kernel<M>(GemmArgs) -- decode-step weight streaming", "achieved": ach, "peak": 8000.0,
+                "unit": "GB/s", "frac": ach / 8000.0, "traffic": None, "launches_per_step": len(gv) / n,
+                "avg_launch_us": ms * 1e3 / max(len(gv), 1), "bytes_per_launch": nbytes / max(len(gv), 1)}
+    fp8 = bool(m.fp8)
+    dom = [r for r in recs if (r[3] & 16 if fp8 else (r[3] & 4 and not r[3] & 16))]
+    ms = sum(r[4] for r in dom)
+    fl = sum(2.0 * r[0] * r[1] * r[2] for r in dom)
+    mult = 3.0 if m.precision == "ref" else 1.0
+    peak = 5000.0 if fp8 else 2500.0
+    ach = mult * fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+    out = {"bound": "mfma", "kernel": ("gemm_fp8_256_kernel" if fp8 else "gemm_bf16_256_kernel") + "(GemmArgs)", "achieved": ach, "peak": peak,
+           "unit": "TFLOP/s", "frac": ach / peak, "traffic": None, "launches_per_step": len(dom) / n,
+           "avg_launch_us": ms * 1e3 / max(len(dom), 1), "flops_per_launch": mult * fl / max(len(dom), 1)}
+    if mult != 1.0:
+        out["note"] = ("operand pairs: every contraction issues hi.hi + hi.lo + lo.hi, so `achieved` counts 3x the algorithmic 2MNK "
+                       "(the MFMA work actually issued); algorithmic rate = achieved / 3")
+        out["algorithmic_tflops"] = ach / 3.0
+    return out
+
+
 def extras_block(model, cfg, args, dev, P):
     """Secondary lines measured in the SAME run, after (outside) the headline's timed region, N = 1 only: the small-batch
     forward (SURVEY 8d configs[2] at 1 and 4 images per call), configs[3]'s per-GPU share (greedy generate, 4 images, 32 new
@@ -301,39 +346,69 @@ def extras_block(model, cfg, args, dev, P):
     from groma_amd.groma import GromaModel
     ex = {}
 
-    def line(m, batch, gen, plan="throughput", steps=10, warmup=3):
+    def line(m, batch, gen, plan="throughput", steps=10, warmup=3, roof=None):
         head = (P + args.new_tokens) if gen else 100
         job = gdist.ShardedJob(dev, (head + ROW_BOXES + 1,), torch.float32, rows_per_rank=batch)
-        el, _ = measure(m, cfg, args, dev, 0, job, P, gen, batch, plan=plan, steps=steps, warmup=warmup)
-        return {"value": batch * steps / el, "unit": "images/s", "ms_per_step": el / steps * 1e3, "images_per_call": batch,
-                "gemm_plan": plan, "steps": steps, "warmup": warmup}
+        el, step = measure(m, cfg, args, dev, 0, job, P, gen, batch, plan=plan, steps=steps, warmup=warmup)
+        out = {"value": batch * steps / el, "unit": "images/s", "ms_per_step": el / steps * 1e3, "images_per_call": batch,
+               "gemm_plan": plan, "steps": steps, "warmup": warmup}
+        if roof:
+            old = m.gemm_plan
+            m.gemm_plan = plan
+            try:
+                out["roofline"] = launch_roofline(m, step, 2, roof)
+            finally:
+                m.gemm_plan = old
+            n_reg = [b.shape[0] for b in m._last_aux["sel_idx"]]
+            tf = flops_per_image(cfg, sum(n_reg) / len(n_reg), P)["total"] * batch * steps / el / 1e12
+            if not gen:
+                out["e2e_algorithmic_tflops_per_gpu"] = tf
+        return out
 
     ex["forward_1_image_per_call"] = line(model, 1, False)
     ex["forward_1_image_per_call_latency_plan"] = line(model, 1, False, plan="latency")
-    ex["forward_4_images_per_call"] = line(model, 4, False)
+    ex["forward_4_images_per_call"] = line(model, 4, False, roof="mfma")
     ex["forward_4_images_per_call_latency_plan"] = line(model, 4, False, plan="latency")
     eos = model.generation_config.eos_token_id
     model.generation_config.eos_token_id = None
     try:
-        g = line(model, 4, True, steps=3, warmup=3)
+        g = line(model, 4, True, steps=3, warmup=3, roof="hbm")
     finally:
         model.generation_config.eos_token_id = eos
     g["new_tokens"] = args.new_tokens
+    try:  # per decode step: (generate - prefill) / new tokens against the 13.2 GB of weights every token streams once
+        pre = ex["forward_4_images_per_call"]["ms_per_step"]
+        tok_ms = (g["ms_per_step"] - pre) / max(args.new_tokens - 1, 1)
+        wbytes = sum(t.numel() * t.element_size() for L in model.llm.w["layers"] for t in (L["wqkv"][0], L["wo"][0], L["wgu"][0], L["wd"][0]))
+        wbytes += model.llm.w["head"].numel() * model.llm.w["head"].element_size()
+        g["decode_step"] = {"ms_per_token": tok_ms, "weight_bytes_per_token": wbytes, "hbm_GBps_end_to_end": wbytes / (tok_ms * 1e-3) / 1e9,
+                            "frac_of_8TBps": wbytes / (tok_ms * 1e-3) / 8e12,
+                            "note": "(generate ms - 4-image prefill ms) / (new_tokens - 1): everything a token costs, not only the GEMV launches"}
+    except Exception as e:
+        g["decode_step"] = {"error": str(e)}
     g["workload"] = "configs[3] per-GPU share: prefill + greedy decode (hipGraph replay), no EOS"
     ex["generate_4_images_per_call"] = g
     m8 = GromaModel.from_synthetic(cfg, seed=0, device=dev, fp8=True)
     m8.init_special_token_id(constants.SyntheticTokenizer())
-    f8 = line(m8, args.batch, False, steps=5, warmup=3)
+    f8 = line(m8, args.batch, False, steps=5, warmup=3, roof="mfma")
     f8["dtype"] = "fp8 (OCP e4m3 operands for the DINOv2 / LLaMA linears, f32 accumulate; lm_head and region convs bf16)"
     ex["forward_fp8"] = f8
     del m8
     torch.cuda.empty_cache()
     m16 = GromaModel.from_synthetic(cfg, seed=0, device=dev, precision="fp16")
     m16.init_special_token_id(constants.SyntheticTokenizer())
-    f16 = line(m16, args.batch, False, steps=5, warmup=3)
+    f16 = line(m16, args.batch, False, steps=5, warmup=3, roof="mfma")
     f16["dtype"] = "fp16 (IEEE half operands through libgroma_hip_f16.so, f32 accumulate: the reference's inference autocast dtype)"
     ex["forward_fp16"] = f16
     del m16
+    torch.cuda.empty_cache()
+    mr = GromaModel.from_synthetic(cfg, seed=0, device=dev, precision="ref")
+    mr.init_special_token_id(constants.SyntheticTokenizer())
+    fr = line(mr, args.batch, False, steps=3, warmup=3, roof="mfma")
+    fr["dtype"] = ("ref: (hi, lo) pairs of halves through libgroma_hip_ref.so, three MFMA passes per contraction, f32 accumulate -- the mode "
+                   "that holds north_star's 1e-3 on the full-depth logits against the fp32 oracle (tests/test_fulldepth_parity_gpu.py)")
+    ex["forward_ref"] = fr
+    del mr
     torch.cuda.empty_cache()
     return ex
 
