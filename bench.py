@@ -224,14 +224,22 @@ def run_dry_exchange(args, rank, world):
     if world > 1:
         gdist.init("gloo", None)
     strong = args.global_batch > 0
-    head = 100
+    gen = args.mode == "generate"
+    # the row head is what the real step packs: 100 region logits, or -- configs[3], --mode generate -- the P + new_tokens ids of
+    # `sequences` carried as f32 (token ids < 2^24 are exact in f32; the dry run checks the round trip)
+    head = (128 + args.new_tokens) if gen else 100
     job = gdist.ShardedJob(dev, (head + ROW_BOXES + 1,), torch.float32,
                            **(dict(global_batch=args.global_batch) if strong else dict(rows_per_rank=args.batch)))
     ranks = gdist.count_ranks(dev)
 
     def rows_of(lo, hi, i):   # deterministic function of the GLOBAL image index, so rank 0 can check what it gathered
         idx = torch.arange(lo, hi, dtype=torch.float32)
-        heads = idx[:, None] * 1000.0 + torch.arange(head, dtype=torch.float32)[None] + float(i)
+        if gen:   # synthetic token ids over the whole 32 114-entry vocabulary, as int64 -> f32 like pack_rows(g.sequences.float(), ...)
+            ids = (idx.long()[:, None] * 7919 + torch.arange(head)[None] * 104729 + i) % 32114
+            heads = ids.float()
+            assert torch.equal(heads.long(), ids)
+        else:
+            heads = idx[:, None] * 1000.0 + torch.arange(head, dtype=torch.float32)[None] + float(i)
         boxes = [torch.full((100 - (int(g) % 3), 4), float(g)) for g in idx]
         return pack_rows(heads, boxes)
 
@@ -246,6 +254,9 @@ def run_dry_exchange(args, rank, world):
         print(json.dumps({"metric": "dry exchange (no model)", "value": job.global_batch * args.steps / elapsed, "unit": "rows/s",
                           "n_gpus": world, "rccl_ranks": ranks, "backend": "gloo", "steps": args.steps, "warmup": args.warmup,
                           "scaling": "strong" if strong else "weak", "global_batch": job.global_batch, "shards": job.counts,
+                          "mode": args.mode, "row_width": head + ROW_BOXES + 1,
+                          "ms_per_step_rank_max": job.last_elapsed_max / max(args.steps, 1) * 1e3,
+                          "ms_per_step_rank_min": job.last_elapsed_min / max(args.steps, 1) * 1e3,
                           "exchange_ok": bool(ok), "exchanged_regions": int(last["out"][:, -1].sum().item())}), flush=True)
     if world > 1:
         import torch.distributed as dist
@@ -286,10 +297,15 @@ def measure(model, cfg, args, dev, rank, job, P, gen, batch, plan="throughput", 
 
     old = model.gemm_plan
     model.gemm_plan = plan
+    caps = lambda: model.vit.graphs.captures + model.llm.graphs.captures
+    mark = {}
     try:
-        elapsed = job.timed(step, warmup, steps)
+        elapsed = job.timed(step, warmup, steps, after_warmup=lambda: mark.update(c=caps()))
     finally:
         model.gemm_plan = old
+    # a hipGraph capture (GraphPool: third sighting of a shape) inside the timed region would put a capture pass and a
+    # stream sync into the measurement: counted, reported, and 0 whenever warmup >= GraphPool.CAPTURE_AT
+    job.captures_in_timed_region = caps() - mark.get("c", caps())
     return elapsed, step
 
 
@@ -413,6 +429,23 @@ def extras_block(model, cfg, args, dev, P):
     return ex
 
 
+def pin_host_threads(local_rank, world):
+    """One rank per GPU shares the host with world - 1 others: give each rank its own contiguous slice of the cores it may run
+    on (affinity) and size torch's intra-op pool to it, so the ranks' host glue around the NMS sync (randperm, splice, pinned
+    copies) does not contend for the same cores.  Returns the thread count in effect.  N = 1: untouched."""
+    if world <= 1:
+        return torch.get_num_threads()
+    try:
+        cores = sorted(os.sched_getaffinity(0))
+        per = max(1, len(cores) // world)
+        mine = cores[local_rank * per:(local_rank + 1) * per] or cores
+        os.sched_setaffinity(0, mine)
+        torch.set_num_threads(max(1, min(len(mine), 16)))
+    except (AttributeError, OSError):
+        torch.set_num_threads(max(1, (os.cpu_count() or world) // world))
+    return torch.get_num_threads()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -469,6 +502,7 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     use_dist = world > 1 or args.force_dist
+    host_threads = pin_host_threads(local_rank, world)
 
     from groma_amd import config as gconfig, constants, dist as gdist, engine, ops, synth
     from groma_amd.groma import GromaModel
@@ -565,6 +599,9 @@ def main():
         "vs_baseline": None,
         "dtype": args.dtype, "data": "synthetic",
         "rccl_ranks": rccl_ranks,  # all-reduce of ones over the process group: the ranks that actually took part
+        # the slowest / fastest rank's own time per step (max is what `value` is computed from): load imbalance across ranks
+        "ms_per_step_rank_max": job.last_elapsed_max / args.steps * 1e3, "ms_per_step_rank_min": job.last_elapsed_min / args.steps * 1e3,
+        "graph_captures_in_timed_region": job.captures_in_timed_region, "host_threads_per_rank": host_threads,
         "exchange": {"collective": "one all_gather_into_tensor per step" if use_dist else "none (single process)",
                      "row_f32": {"head": head_w, "pred_boxes": ROW_BOXES, "n_regions": 1},
                      "rows_gathered": int(gathered.shape[0]), "regions_gathered": exchanged_regions},

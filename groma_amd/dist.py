@@ -121,19 +121,25 @@ class ShardedJob:
             if self.device.type == "cuda":
                 torch.cuda.synchronize(self.device)
 
-    def timed(self, step_fn, warmup, steps):
-        """W untimed + exactly K timed calls of step_fn(i); returns seconds, MAX over ranks."""
+    def timed(self, step_fn, warmup, steps, after_warmup=None):
+        """W untimed + exactly K timed calls of step_fn(i); returns seconds, MAX over ranks.  The slowest and the fastest rank's
+        own time are kept in `last_elapsed_max` / `last_elapsed_min` (load imbalance across ranks); `after_warmup()` runs
+        between the warm-up and the first barrier (e.g. to snapshot counters that must not move inside the timed region)."""
         import time
         for i in range(warmup):
             step_fn(i)
+        if after_warmup is not None:
+            after_warmup()
         self.barrier()
         t0 = time.perf_counter()
         for i in range(steps):
             step_fn(warmup + i)
         self.barrier()
         elapsed = time.perf_counter() - t0
+        self.last_elapsed_min = self.last_elapsed_max = elapsed
         if self.dist is not None:
-            t = torch.tensor([elapsed], dtype=torch.float64, device=self.device)
+            t = torch.tensor([elapsed, -elapsed], dtype=torch.float64, device=self.device)
             self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
-            elapsed = float(t.item())
+            elapsed = float(t[0].item())
+            self.last_elapsed_max, self.last_elapsed_min = elapsed, -float(t[1].item())
         return elapsed

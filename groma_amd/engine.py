@@ -147,8 +147,11 @@ class GraphPool:
 
     CAPTURE_AT = 3
 
-    def __init__(self, cap=16):
-        self.cap, self._graphs, self._seen = cap, collections.OrderedDict(), collections.OrderedDict()
+    def __init__(self, cap=16, byte_budget=2 << 30):
+        # cap: graphs kept (LRU); byte_budget: device memory the graphs' private pools may pin in total (what a capture reserved is
+        # measured around it) -- the least recently used graphs go first when either bound is exceeded
+        self.cap, self.byte_budget = cap, byte_budget
+        self._graphs, self._seen, self._bytes = collections.OrderedDict(), collections.OrderedDict(), {}
         self.replays = self.captures = 0
 
     def run(self, key, launch):
@@ -168,18 +171,41 @@ class GraphPool:
                 self._seen.popitem(last=False)
             launch()
             return
-        torch.cuda.synchronize()  # nothing of this forward (side stream) may overlap the capture
+        self._capture(key, launch).replay()
+
+    def warm(self, key, launch):
+        """capture `key` now (admission-time warm-up of a serving loop: keeps the capture pass out of the first live requests)"""
+        if GraphPool.enabled and TRACE is None and key not in self._graphs and not torch.cuda.is_current_stream_capturing():
+            self._capture(key, launch)
+
+    def _capture(self, key, launch):
+        """Capture on a stream of our own in thread-local error mode.  Only the CALLER's stream is waited for -- not the device:
+        torch.cuda.graph() would synchronise the whole device, collect garbage and empty the allocator cache, stalling every
+        other stream (another model's forward, a serving loop's decode ticks) for a capture that concerns none of them."""
+        cur = torch.cuda.current_stream()
+        cur.synchronize()
+        dev = cur.device
+        before = torch.cuda.memory_reserved(dev)
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
-            launch()
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            g.capture_begin(capture_error_mode="thread_local")
+            try:
+                launch()
+            finally:
+                g.capture_end()
+        cur.wait_stream(side)
         self._graphs[key] = g
+        self._bytes[key] = max(0, torch.cuda.memory_reserved(dev) - before)
         self.captures += 1
-        if len(self._graphs) > self.cap:
-            self._graphs.popitem(last=False)
-        g.replay()
+        while len(self._graphs) > 1 and (len(self._graphs) > self.cap or sum(self._bytes.values()) > self.byte_budget):
+            old, _ = self._graphs.popitem(last=False)
+            self._bytes.pop(old, None)
+        return g
 
     def clear(self):
-        self._graphs.clear(), self._seen.clear()
+        self._graphs.clear(), self._seen.clear(), self._bytes.clear()
 
 
 # ------------------------------------------------------------------------------------------------ DINOv2
@@ -225,6 +251,10 @@ class VitEngine:
         qkv_b = ws.get("vit_qkv", h16(M, 3 * D), H16())
         ctx_b = ws.get("vit_ctx", h16(M, D), H16())
         y_b = ws.get("vit_y", h16(M, I), H16())
+        # split-K partial sums of the plan-split GEMMs (latency plan): an arena of our own whose address keys the graph, never
+        # the shared eager arena of ops (which must not be born or regrown inside a capture)
+        n_sk = ops.plan_ws_elems(M, [(3 * D, D), (D, D), (I, D), (D, I)])
+        skw = ws.get("vit_splitk", (n_sk,), F32) if n_sk else None
 
         def out_buf(layer_out_index):  # hidden_states index (0 = embeddings ... nl = last layer)
             j = layer_out_index - (nl + 1 - self.keep)
@@ -239,14 +269,14 @@ class VitEngine:
             x = ops.layernorm(x_f32, ln_g, ln_b, self.eps, out_bf16=True, out=x_b)
             if tag:
                 _trace(tag, x)
-            return ops.gemm(x, wt[0], **kw)
+            return ops.gemm(x, wt[0], split_ws=skw, **kw)
 
         def lin_bf16(x_bf16, wt, tag=None, **kw):
             if fp8:
                 x8, sx = ops.quant_rows_fp8(x_bf16)
                 _trace_q8(tag, x8, sx)
                 return ops.gemm(x8, wt[0], a_scale=sx, w_scale=wt[1], **kw)
-            return ops.gemm(x_bf16, wt[0], **kw)
+            return ops.gemm(x_bf16, wt[0], split_ws=skw, **kw)
 
         def launch():
             ops.patchify(img, self.P, w["Kpad"], out=a)
@@ -276,7 +306,7 @@ class VitEngine:
                 h = hn
 
         if graph:
-            bufs = [img, a, mid, k, vt, x_b, qkv_b, ctx_b, y_b] + kept + scratch + ([] if q is None else [q])
+            bufs = [img, a, mid, k, vt, x_b, qkv_b, ctx_b, y_b] + kept + scratch + ([] if q is None else [q]) + ([] if skw is None else [skw])
             self.graphs.run(("vit", bs, ops._PLAN[0]) + tuple(t.data_ptr() for t in bufs), launch)
         else:
             launch()
@@ -531,6 +561,8 @@ class LlamaEngine:
         fp8 = w["fp8"]
         x_b, qkv_b = buf("llm_x", h16(M, T), H16()), buf("llm_qkv", h16(M, 3 * T), H16())
         ctx_b, y_b = buf("llm_ctx", h16(M, T), H16()), buf("llm_y", h16(M, self.I), H16())
+        n_sk = ops.plan_ws_elems(M, [(3 * T, T), (T, T), (2 * self.I, T), (T, self.I)]) if M > 8 else 0
+        skw = buf("llm_splitk", (n_sk,), F32) if n_sk else None  # caller-owned split-K workspace: see VitEngine.forward
         # a prefill whose shape and memory repeat is replayed from a captured hipGraph (GraphPool): everything the launches
         # bake in goes into the key; the ragged-row lengths are staged into a buffer of our own
         graph = not dec and not fp8 and TRACE is None and GraphPool.enabled
@@ -548,14 +580,14 @@ class LlamaEngine:
             x = ops.rmsnorm(x_f32, gain, self.eps, out=x_b)
             if tag:
                 _trace(tag, x)
-            return ops.gemm(x, wt[0], **kw)
+            return ops.gemm(x, wt[0], split_ws=skw, **kw)
 
         def lin_bf16(x_bf16, wt, tag=None, **kw):
             if fp8:
                 x8, sx = ops.quant_rows_fp8(x_bf16)
                 _trace_q8(tag, x8, sx)
                 return ops.gemm(x8, wt[0], a_scale=sx, w_scale=wt[1], **kw)
-            return ops.gemm(x_bf16, wt[0], **kw)
+            return ops.gemm(x_bf16, wt[0], split_ws=skw, **kw)
 
         def launch():
             for i, Lw in enumerate(w["layers"]):
@@ -585,7 +617,7 @@ class LlamaEngine:
                     _trace("llm0.h_out", h)
 
         if graph:
-            bufs = [h, x_b, qkv_b, ctx_b, y_b] + ([] if q is None else [q]) + ([] if kv_len is None else [kv_len])
+            bufs = [h, x_b, qkv_b, ctx_b, y_b] + ([] if q is None else [q]) + ([] if kv_len is None else [kv_len]) + ([] if skw is None else [skw])
             self.graphs.run(("llm", bs, L, past, kv_len is None, ops._PLAN[0]) + tuple(t.data_ptr() for t in bufs)
                             + cache_addresses(cache), launch)
         else:
@@ -599,7 +631,7 @@ class LlamaEngine:
             logits = ops.gemm(hn, w["head"], out_f32=True, out=self.decode_logits(bs))
             return logits.view(bs, 1, self.Vpad)[:, :, : self.V], hn
         if not all_logits and L > 1:
-            hn = hn.view(bs, L, T)[:, -1].contiguous()
+            hn = hn.view(bs, L, -1)[:, -1].contiguous()   # (2T physical columns per row in the operand-pair build)
             logits = ops.gemm(hn, w["head"], out_f32=True)
             return logits.view(bs, 1, self.Vpad)[:, :, : self.V], hn
         # prefill logits are handed to the caller (GromaModel.forward returns them): a fresh tensor per call, never a

@@ -500,7 +500,8 @@ class GromaModel:
         # generate() loop, which consumes the views immediately.
         if past_key_values is not None and not _last_logits_only:
             logits = logits.clone()
-        hidden_states = (hn.view(bs, -1, hn.shape[-1]).clone(),) if output_hidden_states else None
+        # (precision "ref" holds the normed state as operand pairs: hand out the f32 values they stand for)
+        hidden_states = ((ops.unsplit(hn) if ops.SP() == 2 else hn.clone()).view(bs, -1, self.llm.T),) if output_hidden_states else None
         if not use_cache and past_key_values is None:
             cache = None  # HF returns past_key_values=None without use_cache; the scratch KV buffer is recycled
         if not return_dict:

@@ -153,23 +153,40 @@ _SPLIT_WS = {}
 
 
 def _split_ws(splits, M, N, device):
-    """fp32 partial-sum workspace [splits, M, N], one growing arena per (device, stream): concurrent launches on the two streams
-    of a forward never share it, launches on one stream are ordered"""
+    """fp32 partial-sum workspace [splits, M, N] for EAGER launches, one growing arena per (device, stream): concurrent launches
+    on the two streams of a forward never share it, launches on one stream are ordered.  Never (re)allocated inside a hipGraph
+    capture: an arena born in a graph's private pool would be baked into every later graph by address and freed with its
+    owner -- launch sequences that are captured own their workspace (`split_ws=`: engine.Workspace, part of the graph key)."""
     key = (str(device), torch.cuda.current_stream().cuda_stream)
     n = splits * M * N
     t = _SPLIT_WS.get(key)
     if t is None or t.numel() < n:
-        if t is not None and not torch.cuda.is_current_stream_capturing():
-            torch.cuda.synchronize(device)  # (inside a capture the graph's own pool orders the reuse)
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("split-K workspace requested inside a hipGraph capture: the captured sequence must pass its own "
+                               "`split_ws` (sized with ops.plan_ws_elems)")
+        if t is not None:
+            torch.cuda.synchronize(device)
         t = _SPLIT_WS[key] = torch.empty((max(n, 0 if t is None else t.numel() * 3 // 2),), dtype=F32, device=device)
     return t[:n].view(splits, M, N)
 
 
+def plan_ws_elems(M, shapes, plan=None):
+    """f32 elements of split-K workspace the plain GEMMs `shapes` = [(N, K), ...] need at M rows under `plan` (0: none split)"""
+    need = 0
+    for N, K in shapes:
+        sp = plan_splits(N, K, plan)
+        if sp > 1:
+            need = max(need, sp * M * N)
+    return need
+
+
 def gemm(a, w, *, out=None, bias=None, scale=None, resid=None, act=0, out_f32=False, splits=1, ws=None,
          M=None, lda=None, conv=None, resid_mod=0, row_map=None, ldc=None, ldr=None, tile=0,
-         a_scale=None, w_scale=None):
+         a_scale=None, w_scale=None, split_ws=None):
     """out[M,N] = epilogue(a[M,K] @ w[N,K]^T).  `conv=(imgs,H,W,C,seg_stride)` switches A to the implicit
-    3x3 gather over zero-bordered NHWC maps (then M = imgs*H*W, K = w.shape[1])."""
+    3x3 gather over zero-bordered NHWC maps (then M = imgs*H*W, K = w.shape[1]).
+    split_ws: caller-owned flat f32 buffer (>= ops.plan_ws_elems) used when the active GEMM plan splits this launch along K --
+    required for launch sequences captured in a hipGraph (the shared arena of eager launches is never touched in a capture)."""
     lib = _lib.load()
     fp8 = w.dtype == FP8
     if fp8:
@@ -207,7 +224,12 @@ def gemm(a, w, *, out=None, bias=None, scale=None, resid=None, act=0, out_f32=Fa
         out = torch.empty((M, n_out * osp), dtype=F32 if out_f32 else H16(), device=a.device)
     _chk(out, F32 if out_f32 else H16(), "out")
     if splits > 1 and ws is None:
-        ws = _split_ws(splits, M, N, a.device)
+        if split_ws is not None:
+            if split_ws.numel() < splits * M * N:
+                raise ValueError("split_ws is smaller than ops.plan_ws_elems asks for")
+            ws = _chk(split_ws, F32, "split_ws").view(-1)[: splits * M * N].view(splits, M, N)
+        else:
+            ws = _split_ws(splits, M, N, a.device)
     d.A, d.W, d.C = a.data_ptr(), w.data_ptr(), out.data_ptr()
     d.bias = _chk(bias, F32, "bias").data_ptr() if bias is not None else None
     d.scale = _chk(scale, F32, "scale").data_ptr() if scale is not None else None

@@ -40,6 +40,19 @@ def test_bench_strong_shards_with_an_empty_rank():
     assert d["exchanged_regions"] == 100 + 99   # N_i of global images 0 and 1 as the synthetic rows define them
 
 
+def test_bench_configs3_verbatim_generate_rows_over_8_ranks():
+    """BASELINE configs[3] as the driver would launch it: 8 ranks, greedy generate, global batch 32 = 4 images per GPU.  The row
+    carries the P + new_tokens generated ids as f32 (exact below 2^24) + pred_boxes + N_i; per-rank min / max step time is in
+    the JSON so load imbalance shows when a node is available."""
+    r = _run(["--gpus", "8", "--dry-exchange", "--mode", "generate", "--global-batch", "32", "--batch", "4", "--steps", "2",
+              "--warmup", "1"], timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = _json_line(r.stdout)
+    assert d["rccl_ranks"] == 8 and d["scaling"] == "strong" and d["shards"] == [4] * 8 and d["global_batch"] == 32
+    assert d["mode"] == "generate" and d["row_width"] == 128 + 32 + 400 + 1 and d["exchange_ok"]
+    assert 0 < d["ms_per_step_rank_min"] <= d["ms_per_step_rank_max"]
+
+
 def test_bench_refuses_inconsistent_launches():
     # a launcher exported another world size than --gpus says
     r = _run(["--gpus", "1", "--dry-exchange", "--steps", "1", "--warmup", "0"], {"WORLD_SIZE": "2", "RANK": "0"})
