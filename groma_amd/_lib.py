@@ -39,6 +39,18 @@ class GemmDesc(ctypes.Structure):
     ]
 
 
+class GemvDesc(ctypes.Structure):
+    """mirror of `gr_gemv_desc` (include/groma_hip.h): the fused decode-step weight-streaming kernel"""
+    _fields_ = [
+        ("W", c_void_p), ("ldw", c_long), ("M", c_int), ("N", c_int), ("K", c_int),
+        ("x_mode", c_int), ("A", c_void_p), ("lda", c_long), ("h", c_void_p), ("ldh", c_long), ("gamma", c_void_p), ("eps", c_float),
+        ("a_parts", c_void_p), ("a_nsplit", c_int), ("a_hd", c_int),
+        ("epi", c_int), ("C", c_void_p), ("ldc", c_long), ("resid", c_void_p), ("ldr", c_long),
+        ("q", c_void_p), ("kc", c_void_p), ("vt", c_void_p), ("cosT", c_void_p), ("sinT", c_void_p),
+        ("H", c_int), ("HD", c_int), ("pos0", c_int), ("kv_stride", c_int), ("pos_dev", c_void_p), ("pos_stride", c_int),
+    ]
+
+
 # name -> argtypes ; every function returns int
 _P, _I, _L, _F = c_void_p, c_int, c_long, c_float
 SIGNATURES = {
@@ -48,6 +60,7 @@ SIGNATURES = {
     "gr_prof_read": [_P, _P, _P],
     "gr_prof_read_launches": [_L, _P, _P, _P],
     "gr_gemm_bf16": [ctypes.POINTER(GemmDesc), _P],
+    "gr_gemv_fused": [ctypes.POINTER(GemvDesc), _P],
     "gr_gemm_f32": [_P, _P, _P, _P, _P, _I, _I, _I, _L, _L, _L, _I, _P],
     "gr_quant_rows_fp8": [_P, _I, _P, _P, _I, _I, _L, _P],
     "gr_norm_fp8": [_P, _P, _P, _P, _P, _I, _I, _F, _I, _P],
@@ -125,7 +138,7 @@ def _open(path, operand):
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
         fn.argtypes = argtypes
         fn.restype = c_long if name == "gr_nms_workspace_bytes" else c_int
-    if lib.gr_abi_version() != 6:
+    if lib.gr_abi_version() != 7:
         raise RuntimeError(f"{os.path.basename(path)} ABI version mismatch")
     if lib.gr_operand_type() != operand:
         raise RuntimeError(f"{os.path.basename(path)} was built for another 16-bit operand type")

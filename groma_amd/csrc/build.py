@@ -11,6 +11,7 @@ SOURCES = {
     "gemm_bf16.hip": [],
     "gemm_bf16_256.hip": [],
     "gemv_bf16.hip": [],
+    "gemv_fused.hip": [],
     "gemm_fp8_256.hip": [],
     "fp8.hip": [],
     "gemm_f32.hip": [],

@@ -1,0 +1,317 @@
+// Decode-step weight streaming, round 4: one kernel per weight matrix, nothing between them (R: the decode
+// branch of groma/model/groma.py:376-379 + HF LlamaDecoderLayer at L = 1).
+//
+// A decode step streams every 16-bit weight once (13.2 GB), shared by the <= 8 rows of the per-GPU batch: HBM-bound.  Round 1-3
+// ran each GEMV as K/512 independent slices whose fp32 partials a SECOND kernel summed (fused with the RMSNorm / RoPE /
+// SwiGLU that followed): 9 launches per layer, 294 per token, and the small kernels between the GEMVs cost 1.3 ms of a 4.1 ms
+// token (65 x 7.2 us of reduce + norm on ONE workgroup per row, 32 x 5 us of RoPE, 32 x 4.7 us of SwiGLU) next to 2.8 ms of
+// streaming (profiles/r03: 0.40 of the HBM roofline end to end).  Here a workgroup owns ROWS whole rows of W:
+//   * its 4 waves take the 512-wide K slices round-robin and keep TWO slices of loads in flight (all ROWS x 16 B of a slice are
+//     issued before the previous slice is consumed: 2 x 8 KB per wave, 64 KB per workgroup, and the register budget -- < 256
+//     VGPRs -- keeps TWO workgroups on a CU, so one streams while the other runs its prologue / reduction / epilogue) -- no
+//     partial sums leave the kernel, a cross-lane butterfly + one LDS exchange finish the dot products in a fixed order
+//     (bit-reproducible);
+//   * the operand x is built by a PROLOGUE that runs while the first weight loads fly: x = f16(RMSNorm(h) * gamma) from the fp32
+//     residual stream (every workgroup recomputes the row statistics: 64 KB of L2 reads against 128+ KB of weights), or the
+//     merge of decode_attention's key slices, staged once in LDS; or plain 16-bit rows read from L2 one slice ahead;
+//   * the EPILOGUE is the consumer the old reduce kernels were: fp32 residual update in place (o-proj, down-proj), SwiGLU over
+//     the interleaved (gate, up) rows, HF rotate_half RoPE + q / K-cache row / V^T-cache column (the workgroup's rows are the
+//     pairs d, d + hd/2 of one head, so the partner sits in the same wave), or fp32 logits.
+// 5 launches per layer (QKV, attention, o-proj, gate/up, down) instead of 9.
+#include "gr_common.h"
+#include "../../include/groma_hip.h"
+
+#define GF_KS 512  // K slice: 64 lanes x 8 elements
+
+struct GemvFArgs {
+  const bf16_t* W;
+  long ldw;
+  int M, N, K;
+  int x_mode;  // 0: A bf16 [M,K] ; 1: RMSNorm(h) * gamma ; 2: merged attention slices (a_parts)
+  const bf16_t* A;
+  long lda;
+  const float* h;
+  long ldh;
+  const float* gamma;
+  float eps;
+  const float* a_parts;
+  int a_nsplit, a_hd;
+  int epi;  // 0: f32 out ; 1: resid += ; 2: SwiGLU -> bf16 [M, N/2] ; 3: QKV RoPE + cache write
+  void* C;
+  long ldc;
+  float* resid;
+  long ldr;
+  bf16_t* q;
+  bf16_t* kc;
+  bf16_t* vt;
+  const float* cosT;
+  const float* sinT;
+  int H, HD, pos0, kv_stride;
+  const int* pos_dev;
+  int pos_stride;
+};
+
+// XG: the operand comes from global memory (x_mode 0) -- else it is staged in LDS by the prologue (compile-time, so neither
+// instantiation carries the other's registers: both stay under 256 VGPRs = two workgroups per CU)
+template <int MB, bool XG>
+__global__ __launch_bounds__(256, 2) void gemv_fused_kernel(GemvFArgs p) {
+  constexpr int NV = 32;         // dot products per workgroup = ROWS x MB: lanes 0..31 own one each after the butterfly
+  constexpr int ROWS = NV / MB;  // rows of W per workgroup (8 at <= 4 batch rows, 4 at 8)
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  bf16_t* xs = (bf16_t*)smem;                         // x_mode 1 / 2: [MB][K]
+  __shared__ float red[4][NV];
+  __shared__ float stat[4][MB];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int blk = blockIdx.x;
+
+  // ---- this workgroup's rows.  epi 3 (fused QKV): inside the q and k sections a workgroup takes ROWS/2 dims d and their
+  // rotate_half partners d + HD/2 of one head; the v section and every other mode take ROWS consecutive rows.
+  // (row numbers and row byte offsets are wave-uniform and computed ONCE: the loads below must issue back to back)
+  const bool rope_rows = p.epi == 3 && (long)blk * ROWS < 2L * p.H * p.HD;
+  int r_lo = blk * ROWS, r_hi = blk * ROWS + ROWS / 2;  // first row of the lower / upper half of the workgroup's rows
+  if (rope_rows) {
+    const int bph = p.HD / ROWS;  // workgroups per head
+    const int hh = blk / bph, j = blk - hh * bph;
+    r_lo = hh * p.HD + j * (ROWS / 2);
+    r_hi = r_lo + p.HD / 2;
+  }
+  auto row_of = [&](int r) -> int { return r < ROWS / 2 ? r_lo + r : r_hi + (r - ROWS / 2); };
+  const char* wrow[ROWS];  // wave-uniform row bases (SGPR pairs); the per-lane part of an address is one 32-bit byte offset
+#pragma unroll
+  for (int r = 0; r < ROWS; ++r) wrow[r] = (const char*)(p.W + (long)min(row_of(r), p.N - 1) * p.ldw);
+  const int ns = (p.K + GF_KS - 1) / GF_KS;          // K slices; wave w takes w, w + 4, ...
+  const int cnt = wave < ns ? (ns - wave + 3) / 4 : 0;
+
+  bf16x8 wA[ROWS], wB[ROWS];
+  bf16x8 xn[XG ? MB : 1];  // XG: raw x of the NEXT slice to be consumed (one buffer: requested at the start of the previous consume)
+  const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+  auto load_x = [&](int i) {
+    if constexpr (XG) {
+      const int k0 = (wave + 4 * i) * GF_KS + lane * 8;
+      const unsigned voff = (unsigned)min(k0, p.K - 8) * 2u;
+#pragma unroll
+      for (int m = 0; m < MB; ++m) {
+        xn[m] = *(const bf16x8*)((const char*)(p.A + (long)min(m, p.M - 1) * p.lda) + voff);
+        if (k0 >= p.K || m >= p.M) xn[m] = zero8;
+      }
+    }
+  };
+  auto load = [&](int i, bf16x8* w) {  // slice i of this wave: every load issued before anything is consumed
+    const int k0 = (wave + 4 * i) * GF_KS + lane * 8;
+    // K % 64 == 0: a lane's 8 values are all in or all out.  Lanes beyond K (last slice of K = 11008) re-read the row's last
+    // 16 B instead of branching around the load -- their x is zero, so the product is 0 whatever the (finite) weight is.
+    const unsigned voff = (unsigned)min(k0, p.K - 8) * 2u;
+    // read exactly once per step by exactly one wave: non-temporal (do not displace the KV cache / x in L2 / MALL)
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) w[r] = __builtin_nontemporal_load((const bf16x8*)(wrow[r] + voff));
+  };
+  if (cnt > 0) { load(0, wA); load_x(0); }
+  if (cnt > 1) load(1, wB);
+
+  // ---- prologue (x_mode 1 / 2), in the shadow of the first weight loads
+  if (!XG && p.x_mode == 1) {  // x = f16(gamma * (h * rsqrt(mean(h^2) + eps)))  (HF LlamaRMSNorm)
+    float ss[MB];
+#pragma unroll
+    for (int m = 0; m < MB; ++m) {
+      ss[m] = 0.f;
+      if (m < p.M)
+        for (int c = tid * 4; c < p.K; c += 1024) {
+          const f32x4 v = *(const f32x4*)(p.h + (long)m * p.ldh + c);
+          ss[m] += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+        }
+      ss[m] = wave_sum(ss[m]);
+    }
+    if (lane == 0) {
+#pragma unroll
+      for (int m = 0; m < MB; ++m) stat[wave][m] = ss[m];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int m = 0; m < MB; ++m) {
+      const float rstd = rsqrtf((stat[0][m] + stat[1][m] + stat[2][m] + stat[3][m]) / (float)p.K + p.eps);
+      for (int c = tid * 4; c < p.K; c += 1024) {
+        uint2 pk = {0u, 0u};
+        if (m < p.M) {
+          const f32x4 v = *(const f32x4*)(p.h + (long)m * p.ldh + c);
+          const f32x4 g = *(const f32x4*)(p.gamma + c);
+          const f32x4 o = g * (v * rstd);
+          pk.x = pack2bf(o[0], o[1]);
+          pk.y = pack2bf(o[2], o[3]);
+        }
+        *(uint2*)(xs + (long)m * p.K + c) = pk;
+      }
+    }
+    __syncthreads();
+  } else if (!XG && p.x_mode == 2) {  // merge the key slices of decode_attention (slice order; rounded like its nsplit = 1 output)
+    const int hd = p.a_hd, c8 = p.K >> 3;
+    for (int idx = tid; idx < MB * c8; idx += 256) {
+      const int m = idx / c8, k0 = (idx - m * c8) << 3;
+      union { bf16x8 v; uint32_t u[4]; } pk;
+      pk.v = zero8;
+      if (m < p.M) {
+        const int hh = k0 / hd, dd = k0 - hh * hd;
+        const float* base = p.a_parts + ((long)(m * (p.K / hd) + hh) * p.a_nsplit) * (hd + 2);
+        float mx = -1e30f;
+        for (int i = 0; i < p.a_nsplit; ++i) mx = fmaxf(mx, base[i * (hd + 2) + hd]);
+        float o[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, l = 0.f;
+        for (int i = 0; i < p.a_nsplit; ++i) {
+          const float* bi = base + i * (hd + 2);
+          const float f = __expf(bi[hd] - mx);
+          l += f * bi[hd + 1];
+          const f32x4 o0 = *(const f32x4*)(bi + dd), o1 = *(const f32x4*)(bi + dd + 4);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { o[e] += f * o0[e]; o[4 + e] += f * o1[e]; }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) pk.u[e] = pack2bf(o[2 * e] / l, o[2 * e + 1] / l);
+      }
+      *(bf16x8*)(xs + (long)m * p.K + k0) = pk.v;
+    }
+    __syncthreads();
+  }
+
+  // ---- main loop: two slices in flight per wave
+  float acc[ROWS][MB];
+#pragma unroll
+  for (int r = 0; r < ROWS; ++r)
+#pragma unroll
+    for (int m = 0; m < MB; ++m) acc[r][m] = 0.f;
+  auto consume = [&](int i, const bf16x8* w) {
+    // raw 16-bit pairs straight into v_dot2c_f32_(bf16|f16): 4 instructions per (row, batch row) and slice, no conversions
+    union X8 { bf16x8 v; uint32_t u[4]; };
+    X8 xv[MB];
+    const int k0 = (wave + 4 * i) * GF_KS + lane * 8;
+#pragma unroll
+    for (int m = 0; m < MB; ++m) {
+      if constexpr (XG) xv[m].v = xn[m];
+      else xv[m].v = k0 < p.K ? *(const bf16x8*)(xs + (long)m * p.K + k0) : zero8;
+    }
+    if (i + 1 < cnt) load_x(i + 1);  // (L2-resident rows: one consume of lead time)
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) {
+      X8 wv;
+      wv.v = w[r];
+#pragma unroll
+      for (int m = 0; m < MB; ++m) {
+        float a = acc[r][m];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) a = GR_DOT2(wv.u[e], xv[m].u[e], a);
+        acc[r][m] = a;
+      }
+    }
+  };
+  for (int i = 0; i < cnt; i += 2) {
+    consume(i, wA);
+    if (i + 2 < cnt) load(i + 2, wA);
+    if (i + 1 < cnt) {
+      consume(i + 1, wB);
+      if (i + 3 < cnt) load(i + 3, wB);
+    }
+  }
+
+  // ---- 32 per-lane partials x 64 lanes -> lane l (and l + 32) owns dot product (row (l & 31) / MB, batch row l % MB):
+  // one all-lanes add across the wave halves, then a reduce-scatter butterfly; fixed order
+  float v[NV];
+#pragma unroll
+  for (int r = 0; r < ROWS; ++r)
+#pragma unroll
+    for (int m = 0; m < MB; ++m) v[r * MB + m] = acc[r][m];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) v[i] += __shfl_xor(v[i], 32, 64);
+#pragma unroll
+  for (int off = NV / 2; off >= 1; off >>= 1) {
+    const bool hi = (lane & off) != 0;
+#pragma unroll
+    for (int i = 0; i < off; ++i) {
+      const float keep = hi ? v[i + off] : v[i];
+      const float send = hi ? v[i] : v[i + off];
+      v[i] = keep + __shfl_xor(send, off, 64);
+    }
+  }
+  if (lane < NV) red[wave][lane] = v[0];
+  __syncthreads();
+  if (wave != 0) return;
+  const int l32 = lane & (NV - 1);
+  const float val = ((red[0][l32] + red[1][l32]) + red[2][l32]) + red[3][l32];  // waves in a fixed order
+
+  // ---- epilogue (wave 0; all 64 lanes stay active for the shuffles, lanes 32..63 mirror 0..31 and do not write)
+  const int rr = l32 / MB, m = l32 % MB;
+  const int n = row_of(rr);
+  const bool ok = lane < NV && m < p.M && n < p.N;
+  if (p.epi == 0) {
+    if (ok) ((float*)p.C)[(long)m * p.ldc + n] = val;
+  } else if (p.epi == 1) {
+    if (ok) p.resid[(long)m * p.ldr + n] += val;
+  } else if (p.epi == 2) {  // interleaved rows: even = gate_j, odd = up_j ; partner row = lane ^ MB
+    const float other = __shfl_xor(val, MB, 64);
+    if (ok && (rr & 1) == 0) ((bf16_t*)p.C)[(long)m * p.ldc + (n >> 1)] = f2bf(silu_f(val) * other);
+  } else {  // epi 3: the summed projection is rounded to 16 bits first (what the prefill GEMM stores), then rotate_half in f32
+    const int HHD = p.H * p.HD;
+    const int sect = n / HHD, nn = n - sect * HHD;
+    const int hh = nn / p.HD, d = nn - hh * p.HD;
+    const int HALF = p.HD / 2;
+    const float a = bf2f(f2bf(val));
+    const float partner = __shfl_xor(a, (ROWS / 2) * MB, 64);  // row r <-> r + ROWS/2 = d <-> d + HD/2 (rope_rows blocks)
+    if (ok) {
+      const int pos = p.pos_dev ? p.pos_dev[m * p.pos_stride] : p.pos0;
+      const long bh = (long)m * p.H + hh;
+      if (sect == 2) {
+        p.vt[(bh * p.HD + d) * p.kv_stride + pos] = f2bf(val);
+      } else {
+        float o = a;
+        if (p.cosT) {
+          const int dc = d < HALF ? d : d - HALF;
+          const float sgn = d < HALF ? -1.f : 1.f;
+          o = a * p.cosT[(long)pos * HALF + dc] + sgn * partner * p.sinT[(long)pos * HALF + dc];
+        }
+        if (sect == 0) p.q[bh * p.HD + d] = f2bf(o);
+        else p.kc[(bh * p.kv_stride + pos) * p.HD + d] = f2bf(o);
+      }
+    }
+  }
+}
+
+extern "C" int gr_gemv_fused(const gr_gemv_desc* d, hipStream_t stream) {
+  if (GR_SP) return GR_EINVAL;  // no split-operand form: a decode step of the reference-precision build runs the general kernels
+  if (!d || !d->W || d->M <= 0 || d->M > 8 || d->N <= 0 || d->K <= 0 || d->K % 64 != 0 || d->ldw < d->K) return GR_EINVAL;
+  if (d->x_mode < 0 || d->x_mode > 2 || d->epi < 0 || d->epi > 3) return GR_EINVAL;
+  if (d->x_mode == 0 && (!d->A || d->lda < d->K)) return GR_EINVAL;
+  if (d->x_mode == 1 && (!d->h || !d->gamma || d->K % 4 != 0 || d->ldh < d->K)) return GR_EINVAL;
+  if (d->x_mode == 2 && (!d->a_parts || d->a_nsplit < 1 || d->a_hd < 8 || d->a_hd % 8 != 0 || d->K % d->a_hd != 0)) return GR_EINVAL;
+  if (d->epi == 0 && (!d->C || d->ldc < d->N)) return GR_EINVAL;
+  if (d->epi == 1 && (!d->resid || d->ldr < d->N)) return GR_EINVAL;
+  if (d->epi == 2 && (!d->C || d->N % 2 != 0 || d->ldc < d->N / 2)) return GR_EINVAL;
+  const int MB = d->M <= 4 ? 4 : 8, ROWS = 32 / MB;
+  if (d->epi == 3) {
+    if (!d->q || !d->kc || !d->vt || d->H <= 0 || d->HD <= 0 || d->HD % (2 * ROWS) != 0 || d->N != 3 * d->H * d->HD) return GR_EINVAL;
+    if ((d->cosT == nullptr) != (d->sinT == nullptr) || d->kv_stride <= 0 || (!d->pos_dev && (d->pos0 < 0 || d->pos0 >= d->kv_stride)))
+      return GR_EINVAL;
+  }
+  const size_t lds = d->x_mode == 0 ? 0 : (size_t)MB * d->K * sizeof(bf16_t);
+  if (lds > 128 * 1024) return GR_EINVAL;
+  GemvFArgs p;
+  p.W = (const bf16_t*)d->W; p.ldw = d->ldw; p.M = d->M; p.N = d->N; p.K = d->K;
+  p.x_mode = d->x_mode; p.A = (const bf16_t*)d->A; p.lda = d->lda; p.h = d->h; p.ldh = d->ldh; p.gamma = d->gamma; p.eps = d->eps;
+  p.a_parts = d->a_parts; p.a_nsplit = d->a_nsplit; p.a_hd = d->a_hd;
+  p.epi = d->epi; p.C = d->C; p.ldc = d->ldc; p.resid = d->resid; p.ldr = d->ldr;
+  p.q = (bf16_t*)d->q; p.kc = (bf16_t*)d->kc; p.vt = (bf16_t*)d->vt; p.cosT = d->cosT; p.sinT = d->sinT;
+  p.H = d->H; p.HD = d->HD; p.pos0 = d->pos0; p.kv_stride = d->kv_stride; p.pos_dev = d->pos_dev; p.pos_stride = d->pos_stride;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)gemv_fused_kernel<4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) != hipSuccess ||
+        hipFuncSetAttribute((const void*)gemv_fused_kernel<8, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) != hipSuccess)
+      return GR_EINVAL;
+    attr_set = true;
+  }
+  const dim3 grid(gr_cdiv(d->N, ROWS));
+  if (d->x_mode == 0) {
+    if (MB == 4) hipLaunchKernelGGL((gemv_fused_kernel<4, true>), grid, dim3(256), 0, stream, p);
+    else hipLaunchKernelGGL((gemv_fused_kernel<8, true>), grid, dim3(256), 0, stream, p);
+  } else {
+    if (MB == 4) hipLaunchKernelGGL((gemv_fused_kernel<4, false>), grid, dim3(256), lds, stream, p);
+    else hipLaunchKernelGGL((gemv_fused_kernel<8, false>), grid, dim3(256), lds, stream, p);
+  }
+  GR_CHECK_LAUNCH();
+  return GR_OK;
+}

@@ -36,6 +36,8 @@ __device__ __forceinline__ uint32_t pack2bf_unit(float a, float b) {
 }
 #define GR_MFMA_16x16x32(a, b, c) \
   __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h16x8_hw, a), __builtin_bit_cast(h16x8_hw, b), c, 0, 0, 0)
+// c + a.lo * b.lo + a.hi * b.hi on two packed 16-bit pairs (v_dot2c_f32_f16): the VALU dot product of the streaming GEMV
+#define GR_DOT2(a_u32, b_u32, c) __builtin_amdgcn_fdot2(__builtin_bit_cast(h16x2_hw, a_u32), __builtin_bit_cast(h16x2_hw, b_u32), c, false)
 #else
 // f32 -> bf16, round-to-nearest-even (same rule as torch .to(bfloat16)): the __bf16 casts lower to ONE
 // v_cvt_pk_bf16_f32 per pair on gfx950 (the bit-twiddling form costs ~7 VALU ops per element).
@@ -51,6 +53,7 @@ __device__ __forceinline__ uint32_t pack2bf(float a, float b) {
 }
 __device__ __forceinline__ uint32_t pack2bf_unit(float a, float b) { return pack2bf(a, b); }
 #define GR_MFMA_16x16x32(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0)
+#define GR_DOT2(a_u32, b_u32, c) __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_hw, a_u32), __builtin_bit_cast(bf16x2_hw, b_u32), c, false)
 #endif
 
 // ---- split-operand storage: the reference-precision build (libgroma_hip_ref.so, -DGR_F16 -DGR_SPLIT) ------------------------

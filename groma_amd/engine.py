@@ -645,25 +645,21 @@ class LlamaEngine:
         return self.ws.get("dec_logits", (bs, self.Vpad), F32, exact=True)
 
     def _decode_forward(self, h, bs, cache, kv_len, pos_dev, pos_stride, past):
-        """One new position per row.  Weight GEMVs leave their split-K partials for the next kernel
-        (csrc/decode.hip): 9 launches per layer instead of 13, and a one-block-per-(row, head) attention."""
+        """One new position per row: 5 launches per layer.  Every weight matrix is ONE streaming kernel whose
+        prologue builds its operand (RMSNorm of the fp32 residual rows / the merge of the attention's key slices) and whose
+        epilogue is its consumer (RoPE + cache write, in-place residual update, SwiGLU): csrc/gemv_fused.hip."""
         w, ws, T, H, hd = self.w, self.ws, self.T, self.H, self.hd
         dyn = pos_dev is not None
-        x = ws.get("dec_x", h16(bs, T), H16(), exact=True)
         q = ws.get("dec_q", h16(bs, H, 1, hd), H16(), exact=True)
         ctx = ws.get("dec_ctx", h16(bs, T), H16(), exact=True)
         y = ws.get("dec_y", h16(bs, self.I), H16(), exact=True)
-        part, splits = None, 0
         for i, Lw in enumerate(w["layers"]):
             t0 = TRACE is not None and i == 0
             if t0:
                 _trace("dec0.h_in", h)
-            ops.decode_reduce_norm(part, splits, h, Lw["n1"], x, self.eps)  # (+ previous layer's down-proj partials)
-            if t0:
-                _trace("dec0.n1", x)
-            pq, sq = ops.gemv_partials(x, Lw["wqkv"][0])
-            ops.decode_qkv_rope(pq, sq, q, cache.k[i], cache.vt[i], w["cos"], w["sin"], B=bs, H=H, hd=hd, pos0=past,
-                                pos_dev=pos_dev, pos_stride=pos_stride)
+            ops.gemv_fused(Lw["wqkv"][0], M=bs, norm=(h, Lw["n1"], self.eps),
+                           qkv=dict(q=q, k=cache.k[i], vt=cache.vt[i], cos=w["cos"], sin=w["sin"], H=H, hd=hd, pos0=past,
+                                    pos_dev=pos_dev, pos_stride=pos_stride))
             att = ops.decode_attention(q, cache.k[i], cache.vt[i], ctx, Smax=cache.smax if dyn else past + 1, q_pos0=past,
                                        kv_len=kv_len, pos_dev=pos_dev, pos_stride=pos_stride)
             if t0:
@@ -671,25 +667,23 @@ class LlamaEngine:
                 TRACE["dec0.nsplit"] = att[1] if isinstance(att, tuple) else 1
                 if not isinstance(att, tuple):
                     _trace("dec0.ctx", ctx)
-            if isinstance(att, tuple):  # key slices on separate blocks: the o-proj merges them while loading x
-                po, so = ops.gemv_partials(None, Lw["wo"][0], a_parts=att)
+            if isinstance(att, tuple):  # key slices on separate blocks: the o-proj merges them while building its operand
+                ops.gemv_fused(Lw["wo"][0], M=bs, a_parts=att, resid=h)
             else:
-                po, so = ops.gemv_partials(ctx, Lw["wo"][0])
-            ops.decode_reduce_norm(po, so, h, Lw["n2"], x, self.eps)
+                ops.gemv_fused(Lw["wo"][0], M=bs, x=ctx, resid=h)
             if t0:
-                _trace("dec0.h_attn", h), _trace("dec0.n2", x)
-            ops.gemm(x, Lw["wgu"][0], act=3, out=y, tile=1, splits=(T + 511) // 512,
-                     ws=ops._gemv_ws((T + 511) // 512, bs, 2 * self.I, h.device))
+                _trace("dec0.h_attn", h)
+            ops.gemv_fused(Lw["wgu"][0], M=bs, norm=(h, Lw["n2"], self.eps), swiglu_out=y)
             if t0:
                 _trace("dec0.act", y)
-            part, splits = ops.gemv_partials(y, Lw["wd"][0])
+            ops.gemv_fused(Lw["wd"][0], M=bs, x=y, resid=h)
         if not dyn:
             cache.seq_len = past + 1
-        ops.decode_reduce_norm(part, splits, h, w["norm"], x, self.eps)
         if TRACE is not None and len(w["layers"]) == 1:
-            _trace("dec.h_out", h), _trace("dec.final_norm", x)
-        logits = ops.gemm(x, w["head"], out_f32=True, out=self.decode_logits(bs))
-        return logits.view(bs, 1, self.Vpad)[:, :, : self.V], x
+            _trace("dec.h_out", h)
+        logits = self.decode_logits(bs)
+        ops.gemv_fused(w["head"], M=bs, norm=(h, w["norm"], self.eps), out=logits)
+        return logits.view(bs, 1, self.Vpad)[:, :, : self.V], None
 
 
 class GreedyDecoder:

@@ -500,8 +500,12 @@ class GromaModel:
         # generate() loop, which consumes the views immediately.
         if past_key_values is not None and not _last_logits_only:
             logits = logits.clone()
-        # (precision "ref" holds the normed state as operand pairs: hand out the f32 values they stand for)
-        hidden_states = ((ops.unsplit(hn) if ops.SP() == 2 else hn.clone()).view(bs, -1, self.llm.T),) if output_hidden_states else None
+        hidden_states = None
+        if output_hidden_states:
+            if hn is None:  # decode step: the final norm lives in the head GEMV's prologue; `emb` is the residual stream, updated in place
+                hn = ops.rmsnorm(emb, self.llm.w["norm"], self.llm.eps)
+            # (precision "ref" holds the normed state as operand pairs: hand out the f32 values they stand for)
+            hidden_states = ((ops.unsplit(hn) if ops.SP() == 2 else hn.clone()).view(bs, -1, self.llm.T),)
         if not use_cache and past_key_values is None:
             cache = None  # HF returns past_key_values=None without use_cache; the scratch KV buffer is recycled
         if not return_dict:

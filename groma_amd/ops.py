@@ -274,6 +274,51 @@ def gemv_partials(a, w, M=None, a_parts=None):
     return ws, splits
 
 
+def gemv_fused(w, *, M, x=None, norm=None, a_parts=None, out=None, resid=None, swiglu_out=None, qkv=None):
+    """One decode-step weight stream y[M <= 8, N] = x . w[N,K]^T with its producer and consumer fused (csrc/gemv_fused.hip).
+    Operand (exactly one): x = 16-bit [M,K]; norm = (h f32 [M,K], gamma, eps) -> RMSNorm in the prologue; a_parts = the
+    un-merged output of decode_attention(nsplit > 1).
+    Result (exactly one): out f32 [M,N]; resid f32 [M,N] (+= y in place); swiglu_out 16-bit [M, N/2] (interleaved gate / up rows);
+    qkv = dict(q, k, vt, cos, sin, H, hd, pos0, pos_dev, pos_stride): RoPE + q / K-cache row / V^T-cache column."""
+    lib = _lib.load()
+    _chk(w, H16(), "w")
+    N, K = w.shape
+    d = _lib.GemvDesc()
+    d.W, d.ldw, d.M, d.N, d.K = w.data_ptr(), w.stride(0), M, N, K
+    if norm is not None:
+        h, gamma, eps = norm
+        _chk(h, F32, "h"); _chk(gamma, F32, "gamma")
+        d.x_mode, d.h, d.ldh, d.gamma, d.eps = 1, h.data_ptr(), h.shape[-1], gamma.data_ptr(), eps
+    elif a_parts is not None:
+        parts, nsplit, hd, Mp = a_parts
+        _chk(parts, F32, "a_parts")
+        d.x_mode, d.a_parts, d.a_nsplit, d.a_hd = 2, parts.data_ptr(), nsplit, hd
+    else:
+        _chk(x, H16(), "x")
+        d.x_mode, d.A, d.lda = 0, x.data_ptr(), x.shape[-1]
+    if out is not None:
+        _chk(out, F32, "out")
+        d.epi, d.C, d.ldc = 0, out.data_ptr(), out.shape[-1]
+    elif resid is not None:
+        _chk(resid, F32, "resid")
+        d.epi, d.resid, d.ldr = 1, resid.data_ptr(), resid.shape[-1]
+    elif swiglu_out is not None:
+        _chk(swiglu_out, H16(), "swiglu_out")
+        d.epi, d.C, d.ldc = 2, swiglu_out.data_ptr(), swiglu_out.shape[-1]
+    else:
+        q, k, vt = qkv["q"], qkv["k"], qkv["vt"]
+        _chk(q, H16(), "q"); _chk(k, H16(), "k"); _chk(vt, H16(), "vt")
+        d.epi, d.q, d.kc, d.vt = 3, q.data_ptr(), k.data_ptr(), vt.data_ptr()
+        cos, sin = qkv.get("cos"), qkv.get("sin")
+        d.cosT, d.sinT = (cos.data_ptr() if cos is not None else None), (sin.data_ptr() if sin is not None else None)
+        d.H, d.HD, d.pos0, d.kv_stride = qkv["H"], qkv["hd"], qkv.get("pos0", 0), k.shape[2]
+        pd = qkv.get("pos_dev")
+        if pd is not None:
+            _chk(pd, I32, "pos_dev")
+            d.pos_dev, d.pos_stride = pd.data_ptr(), qkv.get("pos_stride", 0)
+    _lib.check(lib.gr_gemv_fused(ctypes.byref(d), _stream()), "gr_gemv_fused")
+
+
 def decode_reduce_norm(part, splits, h, gamma, x, eps):
     lib = _lib.load()
     _chk(h, F32, "h"); _chk(x, H16(), "x")

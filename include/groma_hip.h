@@ -42,7 +42,7 @@ extern "C" {
 typedef struct ihipStream_t* hipStream_t;
 #endif
 
-#define GROMA_HIP_ABI_VERSION 6
+#define GROMA_HIP_ABI_VERSION 7
 int gr_abi_version(void);
 #define GR_OPERAND_BF16 0
 #define GR_OPERAND_F16 1
@@ -98,6 +98,26 @@ typedef struct gr_gemm_desc {
   int a_nsplit, a_hd;
 } gr_gemm_desc;
 int gr_gemm_bf16(const gr_gemm_desc* d, hipStream_t stream);
+
+/* Decode-step weight streaming with fused prologue / epilogue (gemv_fused.hip): y[M <= 8, N] = x[M,K] . W[N,K]^T where a
+ * workgroup owns whole rows of W (no split-K partials leave the kernel) -- 5 launches per LLaMA layer at L = 1
+ * (R: groma/model/groma.py:376-379 -> HF LlamaDecoderLayer).  K % 64 == 0.
+ *   x_mode 0: A bf16 [M,K] (lda).
+ *   x_mode 1: x = bf16(gamma * h * rsqrt(mean(h^2) + eps)) from the f32 residual rows h [M,K] (ldh): HF LlamaRMSNorm fused.
+ *   x_mode 2: x = the merge of gr_decode_attention's key slices a_parts (see gr_gemm_desc.a_parts), rounded to bf16.
+ *   epi 0: C f32 [M,N] (ldc) = y.                 epi 1: resid f32 [M,N] (ldr) += y (in place residual update).
+ *   epi 2: C bf16 [M, N/2] (ldc) = silu(y[2j]) * y[2j+1] (SwiGLU over interleaved (gate, up) rows of W).
+ *   epi 3: W = fused QKV [3*H*HD, K]: y rounded to bf16, HF rotate_half RoPE at position pos (cosT / sinT [pos, HD/2], or
+ *          NULL), then q -> q [M,H,HD], k -> kc [M,H,kv_stride,HD] row pos, v -> vt [M,H,HD,kv_stride] column pos;
+ *          pos = pos_dev ? pos_dev[m * pos_stride] : pos0 (device-resident for hipGraph replay / ragged rows). */
+typedef struct gr_gemv_desc {
+  const void* W; long ldw; int M, N, K;
+  int x_mode; const void* A; long lda; const float* h; long ldh; const float* gamma; float eps;
+  const float* a_parts; int a_nsplit, a_hd;
+  int epi; void* C; long ldc; float* resid; long ldr;
+  void* q; void* kc; void* vt; const float* cosT; const float* sinT; int H, HD, pos0, kv_stride; const int* pos_dev; int pos_stride;
+} gr_gemv_desc;
+int gr_gemv_fused(const gr_gemv_desc* d, hipStream_t stream);
 
 /* exact fp32 GEMM (f32-input MFMA): C = act(A.W^T + bias) (+ resid); K % 16 == 0.  DDETR linears
  * (HF 4.32 DeformableDetr* layers used from groma/model/ddetr_transformer.py:299-359). act: 0 | 2 (ReLU) */

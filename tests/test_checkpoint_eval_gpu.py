@@ -26,7 +26,7 @@ def test_from_pretrained_on_device_matches_state_dict_model_and_oracle(dev, tmp_
     for i in range(3):
         part = keys[i * third:(i + 1) * third] if i < 2 else keys[2 * third:]
         save_file({k: sd[k].contiguous() for k in part}, str(d / f"model-{i + 1:05d}-of-00003.safetensors"))
-    model = GromaModel.from_pretrained(str(d), torch_dtype=torch.float32).cuda()   # eval_rec.py:69 form
+    model = GromaModel.from_pretrained(str(d)).cuda()   # eval_rec.py:69 form (no torch_dtype): the default bf16 operand build
     model.init_special_token_id(constants.SyntheticTokenizer())
     ref_model = util.device_model(cfg, sd)
     images, ids = synth.make_inputs(cfg, tk, bs=2, seed=99)
@@ -40,6 +40,17 @@ def test_from_pretrained_on_device_matches_state_dict_model_and_oracle(dev, tmp_
     ref = O.groma_forward(sd, cfg.to_dict(), util.tok_dict(tk), ids.clone(), images, hidden_states=tuple(dev_h))
     assert torch.equal(model._last_aux["nms_keep"][0], ref["nms_inds"][0])
     assert util.relerr(outs[0].logits, ref["logits"]) < 2e-2
+    # an EXPLICIT torch_dtype=torch.float32 asks for the reference's fp32 arithmetic: the reference-precision build (operand pairs)
+    m32 = GromaModel.from_pretrained(str(d), torch_dtype=torch.float32)
+    m32.init_special_token_id(constants.SyntheticTokenizer())
+    assert m32.precision == "ref" and model.precision == "bf16"
+    torch.manual_seed(4)
+    o32 = m32.forward(input_ids=ids.clone(), images=images, return_dict=True)
+    torch.manual_seed(4)
+    ref32 = O.groma_forward(sd, cfg.to_dict(), util.tok_dict(tk), ids.clone(), images)   # unchained: the oracle's own ViT
+    assert torch.equal(m32._last_aux["nms_keep"][0], ref32["nms_inds"][0]) and torch.equal(m32._last_aux["input_ids"], ref32["input_ids"])
+    assert util.relerr(o32.logits, ref32["logits"]) < 1e-4
+    del m32
     # .bin shards load the same
     d2 = tmp_path / "bin"
     cfg.save_pretrained(d2)

@@ -461,6 +461,93 @@ def test_decode_reduce_norm(dev, M, N, splits):
         assert torch.equal(h2, h)  # plain norm: the residual stream is not rewritten
 
 
+@pytest.mark.parametrize("M", [1, 3, 4, 8])
+@pytest.mark.parametrize("N,K", [(4096, 4096), (512, 11008), (32128, 4096), (24, 192)])
+def test_gemv_fused_operand_and_epilogue_modes(dev, M, N, K):
+    """gr_gemv_fused (the decode step's weight stream, round 4): every operand source x every consumer against float64 built
+    from the same 16-bit inputs.  K = 11008 / 192 end in a partial 512-wide slice; N = 24 / 512 leave most workgroups' rows
+    clamped; M = 1, 3 run the 4-row instantiation with padding rows."""
+    ops = _ops()
+    w = rnd((N, K), dev, 0.05, seed=1).bfloat16()
+    x = rnd((M, K), dev, seed=2).bfloat16()
+    y = x.double() @ w.double().t()
+    # plain 16-bit operand -> f32 out / in-place f32 residual
+    out = torch.full((M, N), 7.0, device=dev)
+    ops.gemv_fused(w, M=M, x=x, out=out)
+    assert relerr(out, y.float()) < 2e-6
+    res = rnd((M, N), dev, 3.0, seed=3)
+    want = (res.double() + y).float()
+    ops.gemv_fused(w, M=M, x=x, resid=res)
+    assert relerr(res, want) < 2e-6
+    # RMSNorm prologue (HF LlamaRMSNorm, x rounded to 16 bits) -> SwiGLU over interleaved (gate, up) rows
+    if K <= 8192:
+        h = rnd((M, K), dev, 2.0, seed=4)
+        g = rnd((K,), dev, seed=5)
+        xn = (g * (h * torch.rsqrt(h.pow(2).mean(-1, keepdim=True) + 1e-5))).bfloat16()
+        z = xn.double() @ w.double().t()
+        act = torch.empty((M, N // 2), dtype=torch.bfloat16, device=dev)
+        ops.gemv_fused(w, M=M, norm=(h, g, 1e-5), swiglu_out=act)
+        assert relerr(act, (F.silu(z[:, 0::2]) * z[:, 1::2]).float()) < 5e-3     # one 16-bit rounding of the output + rare flips of x
+        out2 = torch.empty((M, N), device=dev)
+        ops.gemv_fused(w, M=M, norm=(h, g, 1e-5), out=out2)
+        assert relerr(out2, z.float()) < 2e-3   # (x differs from torch's by an occasional 1-ulp flip: summation order of mean(h^2))
+
+
+@pytest.mark.parametrize("hd,use_dev_pos,B", [(64, False, 4), (128, True, 4), (128, True, 7)])
+def test_gemv_fused_qkv_rope_matches_prefill_split(dev, hd, use_dev_pos, B):
+    """fused QKV stream (norm prologue, RoPE + q / K row / V^T column epilogue) == RMSNorm -> GEMM -> qkv_split at L = 1, the
+    sequence the prefill runs, up to fp32 summation order before the 16-bit rounding"""
+    ops = _ops()
+    H, T, stride = 5, 1024, 128
+    w = rnd((3 * H * hd, T), dev, 0.05, seed=1).bfloat16()
+    h = rnd((B, T), dev, 2.0, seed=2)
+    g = rnd((T,), dev, seed=3)
+    inv = 1.0 / (10000 ** (torch.arange(0, hd, 2, device=dev).float() / hd))
+    fr = torch.outer(torch.arange(256, device=dev).float(), inv)
+    cos, sin = fr.cos().contiguous(), fr.sin().contiguous()
+    pos = torch.tensor([7, 30, 0, 99, 5, 64, 127][:B], dtype=torch.int32, device=dev)
+    outs = []
+    for fused in (True, False):
+        q = torch.zeros((B, H, 1, hd), dtype=torch.bfloat16, device=dev)
+        k = torch.zeros((B, H, stride, hd), dtype=torch.bfloat16, device=dev)
+        vt = torch.zeros((B, H, hd, stride), dtype=torch.bfloat16, device=dev)
+        kw = dict(pos_dev=pos, pos_stride=1) if use_dev_pos else dict(pos0=11)
+        if fused:
+            ops.gemv_fused(w, M=B, norm=(h, g, 1e-5), qkv=dict(q=q, k=k, vt=vt, cos=cos, sin=sin, H=H, hd=hd, **kw))
+        else:
+            xn = ops.rmsnorm(h, g, 1e-5)
+            qkv = ops.gemm(xn, w, tile=128)
+            ops.qkv_split(qkv, q, k, vt, B=B, H=H, L=1, hd=hd, cos=cos, sin=sin, **kw)
+        outs.append((q, k, vt))
+    for a, b in zip(*outs):
+        assert (a != 0).any()
+        assert relerr(a, b) < 4e-3   # <= 1 ulp flips of the 16-bit roundings (summation order)
+    # nothing but the addressed cache row / column was touched
+    p0 = int(pos[0]) if use_dev_pos else 11
+    kk = outs[0][1].clone()
+    kk[0, :, p0] = 0
+    assert float(kk[0].abs().max()) == 0.0
+
+
+def test_gemv_fused_merges_attention_key_slices(dev):
+    """x_mode 2: the o-proj stream builds its operand from decode_attention's un-merged key slices == the nsplit = 1 context"""
+    ops = _ops()
+    B, H, hd, S = 2, 8, 128, 300
+    stride = 384
+    q = rnd((B, H, 1, hd), dev, seed=1).bfloat16()
+    k = rnd((B, H, stride, hd), dev, seed=2).bfloat16()
+    vt = rnd((B, H, hd, stride), dev, seed=3).bfloat16()
+    ctx = torch.empty((B, H * hd), dtype=torch.bfloat16, device=dev)
+    ops.decode_attention(q, k, vt, ctx, Smax=S, q_pos0=S - 1, nsplit=1)
+    r = ops.decode_attention(q, k, vt, torch.empty_like(ctx), Smax=S, q_pos0=S - 1, nsplit=3)
+    assert isinstance(r, tuple)
+    w = rnd((512, H * hd), dev, 0.05, seed=4).bfloat16()
+    a, b = torch.zeros((B, 512), device=dev), torch.zeros((B, 512), device=dev)
+    ops.gemv_fused(w, M=B, x=ctx, resid=a)
+    ops.gemv_fused(w, M=B, a_parts=r, resid=b)
+    assert relerr(b, a) < 3e-3 and relerr(a, ctx.double() @ w.double().t()) < 2e-6
+
+
 @pytest.mark.parametrize("hd,use_dev_pos", [(64, False), (128, True)])
 def test_decode_qkv_rope_matches_prefill_split(dev, hd, use_dev_pos):
     """decode consumer of the qkv partials == (reduce -> bf16 -> qkv_split at L=1), the path the prefill uses"""

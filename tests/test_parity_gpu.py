@@ -38,7 +38,10 @@ def gen_setup(dev):
     sd["extra_lm_head.weight"] = w
     model = util.device_model(cfg, sd)
     from groma_amd import synth
-    images, ids = synth.make_inputs(cfg, tk, bs=2, seed=1234)
+    # input seed 1239: of the seeds 1234..1273 scanned on the CPU oracle (6 greedy steps x 2 rows, also with row 1 right-padded)
+    # the one whose smallest top-2 margin is largest (2.0 / 2.1 logits; seed 1234 has 6e-3 and 9e-3 steps, inside the bf16 band,
+    # and which side of such a tie the device lands on changes with any re-ordering of an fp32 sum)
+    images, ids = synth.make_inputs(cfg, tk, bs=2, seed=1239)
     return cfg, sd, tk, model, images, ids
 
 
