@@ -18,10 +18,18 @@
 //     the interleaved (gate, up) rows, HF rotate_half RoPE + q / K-cache row / V^T-cache column (the workgroup's rows are the
 //     pairs d, d + hd/2 of one head, so the partner sits in the same wave), or fp32 logits.
 // 5 launches per layer (QKV, attention, o-proj, gate/up, down) instead of 9.
+#include <type_traits>
+
 #include "gr_common.h"
 #include "../../include/groma_hip.h"
 
 #define GF_KS 512  // K slice: 64 lanes x 8 elements
+#ifndef GF_NV
+#define GF_NV 32   // dot products per row group (rows x padded batch rows); 64 was A/B-measured (tests/diag/gemv_bench.py)
+#endif
+#ifndef GF_WG_PER_CU
+#define GF_WG_PER_CU 2  // persistent workgroups per CU
+#endif
 
 struct GemvFArgs {
   const bf16_t* W;
@@ -52,34 +60,45 @@ struct GemvFArgs {
 };
 
 // XG: the operand comes from global memory (x_mode 0) -- else it is staged in LDS by the prologue (compile-time, so neither
-// instantiation carries the other's registers: both stay under 256 VGPRs = two workgroups per CU)
+// instantiation carries the other's registers: both stay well under 256 VGPRs = two or three workgroups per CU).
+//
+// A workgroup is PERSISTENT over row groups g = blockIdx.x, + gridDim.x, ... (grid = min(groups, 2 per CU)): the prologue --
+// whose L2 reads (the fp32 rows of h once + gamma: 80 KB at 4 rows x 4096) are larger than one group's 64 KB of weights -- is
+// paid once per workgroup, not once per group (first version: 2.8 TB/s on the QKV / gate-up / head shapes, because every
+// 8-row group redid it), and the first two slices of the NEXT group are requested before the butterfly / LDS exchange /
+// epilogue of the current one, so the weight stream does not drain between groups.
 template <int MB, bool XG>
 __global__ __launch_bounds__(256, 2) void gemv_fused_kernel(GemvFArgs p) {
-  constexpr int NV = 32;         // dot products per workgroup = ROWS x MB: lanes 0..31 own one each after the butterfly
-  constexpr int ROWS = NV / MB;  // rows of W per workgroup (8 at <= 4 batch rows, 4 at 8)
+  constexpr int NV = GF_NV;      // dot products per row group = ROWS x MB: lanes 0..NV-1 own one each after the butterfly
+  constexpr int ROWS = NV / MB;  // rows of W per group (8 at <= 4 batch rows, 4 at 8)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   bf16_t* xs = (bf16_t*)smem;                         // x_mode 1 / 2: [MB][K]
   __shared__ float red[4][NV];
-  __shared__ float stat[4][MB];
+  __shared__ float stat[4][4];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int blk = blockIdx.x;
+  const int ngroups = (p.N + ROWS - 1) / ROWS;
 
-  // ---- this workgroup's rows.  epi 3 (fused QKV): inside the q and k sections a workgroup takes ROWS/2 dims d and their
-  // rotate_half partners d + HD/2 of one head; the v section and every other mode take ROWS consecutive rows.
-  // (row numbers and row byte offsets are wave-uniform and computed ONCE: the loads below must issue back to back)
-  const bool rope_rows = p.epi == 3 && (long)blk * ROWS < 2L * p.H * p.HD;
-  int r_lo = blk * ROWS, r_hi = blk * ROWS + ROWS / 2;  // first row of the lower / upper half of the workgroup's rows
-  if (rope_rows) {
-    const int bph = p.HD / ROWS;  // workgroups per head
-    const int hh = blk / bph, j = blk - hh * bph;
-    r_lo = hh * p.HD + j * (ROWS / 2);
-    r_hi = r_lo + p.HD / 2;
-  }
-  auto row_of = [&](int r) -> int { return r < ROWS / 2 ? r_lo + r : r_hi + (r - ROWS / 2); };
-  const char* wrow[ROWS];  // wave-uniform row bases (SGPR pairs); the per-lane part of an address is one 32-bit byte offset
-#pragma unroll
-  for (int r = 0; r < ROWS; ++r) wrow[r] = (const char*)(p.W + (long)min(row_of(r), p.N - 1) * p.ldw);
+  // ---- a group's rows.  epi 3 (fused QKV): inside the q and k sections a group takes ROWS/2 dims d and their rotate_half
+  // partners d + HD/2 of one head; the v section and every other mode take ROWS consecutive rows.
+  // (row numbers and row bases are wave-uniform scalars: the loads below must issue back to back)
+  // The two halves are runs of ROWS/2 consecutive rows: two scalar bases + r * ldw in the per-lane offset (N % ROWS == 0 is
+  // checked by the entry point, so no row is ever clamped).
+  int r_lo, r_hi;                // first row of the lower / upper half of the current group's rows
+  const char *base_lo, *base_hi; // their addresses (SGPR pairs)
+  const unsigned ldwB = (unsigned)p.ldw * 2u;
+  auto set_group = [&](int g) {
+    r_lo = g * ROWS;
+    r_hi = g * ROWS + ROWS / 2;
+    if (p.epi == 3 && (long)g * ROWS < 2L * p.H * p.HD) {
+      const int bph = p.HD / ROWS;  // groups per head
+      const int hh = g / bph, j = g - hh * bph;
+      r_lo = hh * p.HD + j * (ROWS / 2);
+      r_hi = r_lo + p.HD / 2;
+    }
+    base_lo = (const char*)(p.W + (long)r_lo * p.ldw);
+    base_hi = (const char*)(p.W + (long)r_hi * p.ldw);
+  };
   const int ns = (p.K + GF_KS - 1) / GF_KS;          // K slices; wave w takes w, w + 4, ...
   const int cnt = wave < ns ? (ns - wave + 3) / 4 : 0;
 
@@ -104,42 +123,92 @@ __global__ __launch_bounds__(256, 2) void gemv_fused_kernel(GemvFArgs p) {
     const unsigned voff = (unsigned)min(k0, p.K - 8) * 2u;
     // read exactly once per step by exactly one wave: non-temporal (do not displace the KV cache / x in L2 / MALL)
 #pragma unroll
-    for (int r = 0; r < ROWS; ++r) w[r] = __builtin_nontemporal_load((const bf16x8*)(wrow[r] + voff));
+    for (int r = 0; r < ROWS; ++r)
+      w[r] = __builtin_nontemporal_load((const bf16x8*)((r < ROWS / 2 ? base_lo : base_hi) + (voff + (unsigned)(r % (ROWS / 2)) * ldwB)));
   };
-  if (cnt > 0) { load(0, wA); load_x(0); }
-  if (cnt > 1) load(1, wB);
+  auto start_group = [&](int g) {  // request the first two slices of group g (and the first x slice)
+    set_group(g);
+    if (cnt > 0) { load(0, wA); load_x(0); }
+    if (cnt > 1) load(1, wB);
+  };
+  int grp = blockIdx.x;
+  start_group(grp);
 
-  // ---- prologue (x_mode 1 / 2), in the shadow of the first weight loads
-  if (!XG && p.x_mode == 1) {  // x = f16(gamma * (h * rsqrt(mean(h^2) + eps)))  (HF LlamaRMSNorm)
-    float ss[MB];
+  // ---- prologue (x_mode 1 / 2), once per workgroup, in the shadow of the first weight loads
+  if (!XG && p.x_mode == 1) {  // x = f16(gamma * (h * rsqrt(mean(h^2) + eps)))  (HF LlamaRMSNorm), 4 batch rows at a time
+    constexpr int KJ = 4;      // float4 per thread and row held in registers (K <= 4096); wider rows take the two-pass form below
+    if (p.K <= KJ * 1024) {
+      // straight-line: every load of a 4-row chunk (16 x h, 4 x gamma per thread) is issued before the first use -- ONE exposed
+      // L2 latency per chunk (a per-row "load gamma, wait, store" form measured 2.8 TB/s on the shapes with this prologue)
+      f32x4 g[KJ];
+      int cc[KJ];
+      bool cin[KJ];
 #pragma unroll
-    for (int m = 0; m < MB; ++m) {
-      ss[m] = 0.f;
-      if (m < p.M)
-        for (int c = tid * 4; c < p.K; c += 1024) {
-          const f32x4 v = *(const f32x4*)(p.h + (long)m * p.ldh + c);
-          ss[m] += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+      for (int j = 0; j < KJ; ++j) {
+        const int c = tid * 4 + j * 1024;
+        cin[j] = c < p.K;
+        cc[j] = cin[j] ? c : 0;
+        g[j] = *(const f32x4*)(p.gamma + cc[j]);
+      }
+#pragma unroll 1
+      for (int m0 = 0; m0 < MB; m0 += 4) {
+        f32x4 hv[4][KJ];
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+          for (int j = 0; j < KJ; ++j) hv[mi][j] = *(const f32x4*)(p.h + (long)min(m0 + mi, p.M - 1) * p.ldh + cc[j]);
+        float ss[4];
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) {
+          ss[mi] = 0.f;
+#pragma unroll
+          for (int j = 0; j < KJ; ++j) {
+            const f32x4 v = hv[mi][j];
+            ss[mi] += cin[j] ? v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3] : 0.f;
+          }
+          ss[mi] = wave_sum(ss[mi]);
         }
-      ss[m] = wave_sum(ss[m]);
-    }
-    if (lane == 0) {
+        __syncthreads();  // (stat[] of the previous chunk has been read)
+        if (lane == 0) {
 #pragma unroll
-      for (int m = 0; m < MB; ++m) stat[wave][m] = ss[m];
-    }
-    __syncthreads();
+          for (int mi = 0; mi < 4; ++mi) stat[wave][mi] = ss[mi];
+        }
+        __syncthreads();
 #pragma unroll
-    for (int m = 0; m < MB; ++m) {
-      const float rstd = rsqrtf((stat[0][m] + stat[1][m] + stat[2][m] + stat[3][m]) / (float)p.K + p.eps);
-      for (int c = tid * 4; c < p.K; c += 1024) {
-        uint2 pk = {0u, 0u};
-        if (m < p.M) {
-          const f32x4 v = *(const f32x4*)(p.h + (long)m * p.ldh + c);
-          const f32x4 g = *(const f32x4*)(p.gamma + c);
-          const f32x4 o = g * (v * rstd);
+        for (int mi = 0; mi < 4; ++mi) {
+          const int m = m0 + mi;
+          const float rstd = m < p.M ? rsqrtf((stat[0][mi] + stat[1][mi] + stat[2][mi] + stat[3][mi]) / (float)p.K + p.eps) : 0.f;
+#pragma unroll
+          for (int j = 0; j < KJ; ++j) {
+            const f32x4 o = g[j] * (hv[mi][j] * rstd);  // (padding rows m >= M: rstd = 0 -> x = 0)
+            uint2 pk;
+            pk.x = pack2bf(o[0], o[1]);
+            pk.y = pack2bf(o[2], o[3]);
+            if (cin[j]) *(uint2*)(xs + (long)m * p.K + cc[j]) = pk;
+          }
+        }
+      }
+    } else {
+      for (int m = 0; m < MB; ++m) {  // wide rows (K > 4096): statistics pass, then a second read of the row
+        float ss = 0.f;
+        if (m < p.M)
+          for (int c = tid * 4; c < p.K; c += 1024) {
+            const f32x4 v = *(const f32x4*)(p.h + (long)m * p.ldh + c);
+            ss += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+          }
+        ss = wave_sum(ss);
+        __syncthreads();
+        if (lane == 0) stat[wave][0] = ss;
+        __syncthreads();
+        const float rstd = m < p.M ? rsqrtf((stat[0][0] + stat[1][0] + stat[2][0] + stat[3][0]) / (float)p.K + p.eps) : 0.f;
+        for (int c = tid * 4; c < p.K; c += 1024) {
+          const f32x4 v = *(const f32x4*)(p.h + (long)min(m, p.M - 1) * p.ldh + c);
+          const f32x4 o = *(const f32x4*)(p.gamma + c) * (v * rstd);
+          uint2 pk;
           pk.x = pack2bf(o[0], o[1]);
           pk.y = pack2bf(o[2], o[3]);
+          *(uint2*)(xs + (long)m * p.K + c) = pk;
         }
-        *(uint2*)(xs + (long)m * p.K + c) = pk;
       }
     }
     __syncthreads();
@@ -171,12 +240,7 @@ __global__ __launch_bounds__(256, 2) void gemv_fused_kernel(GemvFArgs p) {
     __syncthreads();
   }
 
-  // ---- main loop: two slices in flight per wave
   float acc[ROWS][MB];
-#pragma unroll
-  for (int r = 0; r < ROWS; ++r)
-#pragma unroll
-    for (int m = 0; m < MB; ++m) acc[r][m] = 0.f;
   auto consume = [&](int i, const bf16x8* w) {
     // raw 16-bit pairs straight into v_dot2c_f32_(bf16|f16): 4 instructions per (row, batch row) and slice, no conversions
     union X8 { bf16x8 v; uint32_t u[4]; };
@@ -201,74 +265,108 @@ __global__ __launch_bounds__(256, 2) void gemv_fused_kernel(GemvFArgs p) {
       }
     }
   };
-  for (int i = 0; i < cnt; i += 2) {
-    consume(i, wA);
-    if (i + 2 < cnt) load(i + 2, wA);
-    if (i + 1 < cnt) {
-      consume(i + 1, wB);
-      if (i + 3 < cnt) load(i + 3, wB);
-    }
-  }
 
-  // ---- 32 per-lane partials x 64 lanes -> lane l (and l + 32) owns dot product (row (l & 31) / MB, batch row l % MB):
-  // one all-lanes add across the wave halves, then a reduce-scatter butterfly; fixed order
-  float v[NV];
+#pragma unroll 1
+  while (true) {
 #pragma unroll
-  for (int r = 0; r < ROWS; ++r)
+    for (int r = 0; r < ROWS; ++r)
 #pragma unroll
-    for (int m = 0; m < MB; ++m) v[r * MB + m] = acc[r][m];
-#pragma unroll
-  for (int i = 0; i < NV; ++i) v[i] += __shfl_xor(v[i], 32, 64);
-#pragma unroll
-  for (int off = NV / 2; off >= 1; off >>= 1) {
-    const bool hi = (lane & off) != 0;
-#pragma unroll
-    for (int i = 0; i < off; ++i) {
-      const float keep = hi ? v[i + off] : v[i];
-      const float send = hi ? v[i] : v[i + off];
-      v[i] = keep + __shfl_xor(send, off, 64);
-    }
-  }
-  if (lane < NV) red[wave][lane] = v[0];
-  __syncthreads();
-  if (wave != 0) return;
-  const int l32 = lane & (NV - 1);
-  const float val = ((red[0][l32] + red[1][l32]) + red[2][l32]) + red[3][l32];  // waves in a fixed order
-
-  // ---- epilogue (wave 0; all 64 lanes stay active for the shuffles, lanes 32..63 mirror 0..31 and do not write)
-  const int rr = l32 / MB, m = l32 % MB;
-  const int n = row_of(rr);
-  const bool ok = lane < NV && m < p.M && n < p.N;
-  if (p.epi == 0) {
-    if (ok) ((float*)p.C)[(long)m * p.ldc + n] = val;
-  } else if (p.epi == 1) {
-    if (ok) p.resid[(long)m * p.ldr + n] += val;
-  } else if (p.epi == 2) {  // interleaved rows: even = gate_j, odd = up_j ; partner row = lane ^ MB
-    const float other = __shfl_xor(val, MB, 64);
-    if (ok && (rr & 1) == 0) ((bf16_t*)p.C)[(long)m * p.ldc + (n >> 1)] = f2bf(silu_f(val) * other);
-  } else {  // epi 3: the summed projection is rounded to 16 bits first (what the prefill GEMM stores), then rotate_half in f32
-    const int HHD = p.H * p.HD;
-    const int sect = n / HHD, nn = n - sect * HHD;
-    const int hh = nn / p.HD, d = nn - hh * p.HD;
-    const int HALF = p.HD / 2;
-    const float a = bf2f(f2bf(val));
-    const float partner = __shfl_xor(a, (ROWS / 2) * MB, 64);  // row r <-> r + ROWS/2 = d <-> d + HD/2 (rope_rows blocks)
-    if (ok) {
-      const int pos = p.pos_dev ? p.pos_dev[m * p.pos_stride] : p.pos0;
-      const long bh = (long)m * p.H + hh;
-      if (sect == 2) {
-        p.vt[(bh * p.HD + d) * p.kv_stride + pos] = f2bf(val);
-      } else {
-        float o = a;
-        if (p.cosT) {
-          const int dc = d < HALF ? d : d - HALF;
-          const float sgn = d < HALF ? -1.f : 1.f;
-          o = a * p.cosT[(long)pos * HALF + dc] + sgn * partner * p.sinT[(long)pos * HALF + dc];
-        }
-        if (sect == 0) p.q[bh * p.HD + d] = f2bf(o);
-        else p.kc[(bh * p.kv_stride + pos) * p.HD + d] = f2bf(o);
+      for (int m = 0; m < MB; ++m) acc[r][m] = 0.f;
+    // ---- this group's slices: two in flight per wave
+    for (int i = 0; i < cnt; i += 2) {
+      consume(i, wA);
+      if (i + 2 < cnt) load(i + 2, wA);
+      if (i + 1 < cnt) {
+        consume(i + 1, wB);
+        if (i + 3 < cnt) load(i + 3, wB);
       }
     }
+    const int e_lo = r_lo, e_hi = r_hi;  // the finished group's rows (the epilogue's)
+    const int nxt = grp + (int)gridDim.x;
+#ifdef GF_PREFETCH_GROUP  // (requesting the next group's first slices BEFORE the reduction keeps 64 more VGPRs live through the
+    if (nxt < ngroups) start_group(nxt);  //  butterfly and spilled; the co-resident workgroups cover the gap instead)
+#endif
+
+    // ---- NV per-lane partials x 64 lanes -> lane l (mod NV) owns dot product (row l / MB, batch row l % MB): all-lanes adds
+    // across the lane bits >= NV, then a reduce-scatter butterfly; fixed order
+    float v[NV];
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r)
+#pragma unroll
+      for (int m = 0; m < MB; ++m) v[r * MB + m] = acc[r][m];
+    if constexpr (NV <= 32) {
+#pragma unroll
+      for (int i = 0; i < NV; ++i) v[i] += __shfl_xor(v[i], 32, 64);
+    }
+    constexpr int OFF0 = NV / 2 < 32 ? NV / 2 : 32;
+    auto stage = [&](auto offc) {
+      constexpr int off = decltype(offc)::value;
+      if constexpr (off >= 1 && off <= OFF0) {
+        const bool hi = (lane & off) != 0;
+#pragma unroll
+        for (int i = 0; i < off; ++i) {
+          const float keep = hi ? v[i + off] : v[i];
+          const float send = hi ? v[i] : v[i + off];
+          v[i] = keep + __shfl_xor(send, off, 64);
+        }
+      }
+    };
+    stage(std::integral_constant<int, 32>{});
+    stage(std::integral_constant<int, 16>{});
+    stage(std::integral_constant<int, 8>{});
+    stage(std::integral_constant<int, 4>{});
+    stage(std::integral_constant<int, 2>{});
+    stage(std::integral_constant<int, 1>{});
+    if (lane < NV) red[wave][lane] = v[0];
+    __syncthreads();
+    if (wave == 0) {
+      const int lv = lane & (NV - 1);
+      const float val = ((red[0][lv] + red[1][lv]) + red[2][lv]) + red[3][lv];  // waves in a fixed order
+      // ---- epilogue (wave 0; all 64 lanes stay active for the shuffles, lanes >= NV mirror the others and do not write)
+      const int rr = lv / MB, m = lv % MB;
+      const int n = rr < ROWS / 2 ? e_lo + rr : e_hi + (rr - ROWS / 2);
+      const bool ok = lane < NV && m < p.M;
+      if (p.epi == 0) {
+        if (ok) ((float*)p.C)[(long)m * p.ldc + n] = val;
+      } else if (p.epi == 1) {
+        if (ok) p.resid[(long)m * p.ldr + n] += val;
+      } else if (p.epi == 2) {  // interleaved rows: even = gate_j, odd = up_j ; partner row = lane ^ MB
+        const float other = __shfl_xor(val, MB, 64);
+        if (ok && (rr & 1) == 0) ((bf16_t*)p.C)[(long)m * p.ldc + (n >> 1)] = f2bf(silu_f(val) * other);
+      } else {  // epi 3: the summed projection is rounded to 16 bits first (what the prefill GEMM stores), then rotate_half in f32
+        // all rows of a group lie in ONE head (HD % ROWS == 0): section, head and the first dim come from the group's first row --
+        // wave-uniform scalars, no per-lane division
+        const int HHD = p.H * p.HD;
+        const int sect = e_lo / HHD, nn = e_lo - sect * HHD;
+        const int hh = nn / p.HD;
+        const int d = (rr < ROWS / 2 ? e_lo + rr : e_hi + (rr - ROWS / 2)) - sect * HHD - hh * p.HD;
+        const int HALF = p.HD / 2;
+        const float a = bf2f(f2bf(val));
+        const float partner = __shfl_xor(a, (ROWS / 2) * MB, 64);  // row r <-> r + ROWS/2 = d <-> d + HD/2 (q / k sections)
+        if (ok) {
+          const int pos = p.pos_dev ? p.pos_dev[m * p.pos_stride] : p.pos0;
+          const long bh = (long)m * p.H + hh;
+          if (sect == 2) {
+            p.vt[(bh * p.HD + d) * p.kv_stride + pos] = f2bf(val);
+          } else {
+            float o = a;
+            if (p.cosT) {
+              const int dc = d < HALF ? d : d - HALF;
+              const float sgn = d < HALF ? -1.f : 1.f;
+              o = a * p.cosT[(long)pos * HALF + dc] + sgn * partner * p.sinT[(long)pos * HALF + dc];
+            }
+            if (sect == 0) p.q[bh * p.HD + d] = f2bf(o);
+            else p.kc[(bh * p.kv_stride + pos) * p.HD + d] = f2bf(o);
+          }
+        }
+      }
+    }
+    if (nxt >= ngroups) break;
+    grp = nxt;
+#ifndef GF_PREFETCH_GROUP
+    start_group(nxt);
+#endif
+    __syncthreads();  // wave 0 has read red[] before the next group's partials overwrite it
   }
 }
 
@@ -276,13 +374,14 @@ extern "C" int gr_gemv_fused(const gr_gemv_desc* d, hipStream_t stream) {
   if (GR_SP) return GR_EINVAL;  // no split-operand form: a decode step of the reference-precision build runs the general kernels
   if (!d || !d->W || d->M <= 0 || d->M > 8 || d->N <= 0 || d->K <= 0 || d->K % 64 != 0 || d->ldw < d->K) return GR_EINVAL;
   if (d->x_mode < 0 || d->x_mode > 2 || d->epi < 0 || d->epi > 3) return GR_EINVAL;
+  if (d->N % (GF_NV / (d->M <= 4 ? 4 : 8)) != 0 || (long)d->ldw * 2 * GF_NV >= (1L << 31)) return GR_EINVAL;  // whole row groups; 32-bit row offsets
   if (d->x_mode == 0 && (!d->A || d->lda < d->K)) return GR_EINVAL;
   if (d->x_mode == 1 && (!d->h || !d->gamma || d->K % 4 != 0 || d->ldh < d->K)) return GR_EINVAL;
   if (d->x_mode == 2 && (!d->a_parts || d->a_nsplit < 1 || d->a_hd < 8 || d->a_hd % 8 != 0 || d->K % d->a_hd != 0)) return GR_EINVAL;
   if (d->epi == 0 && (!d->C || d->ldc < d->N)) return GR_EINVAL;
   if (d->epi == 1 && (!d->resid || d->ldr < d->N)) return GR_EINVAL;
   if (d->epi == 2 && (!d->C || d->N % 2 != 0 || d->ldc < d->N / 2)) return GR_EINVAL;
-  const int MB = d->M <= 4 ? 4 : 8, ROWS = 32 / MB;
+  const int MB = d->M <= 4 ? 4 : 8, ROWS = GF_NV / MB;
   if (d->epi == 3) {
     if (!d->q || !d->kc || !d->vt || d->H <= 0 || d->HD <= 0 || d->HD % (2 * ROWS) != 0 || d->N != 3 * d->H * d->HD) return GR_EINVAL;
     if ((d->cosT == nullptr) != (d->sinT == nullptr) || d->kv_stride <= 0 || (!d->pos_dev && (d->pos0 < 0 || d->pos0 >= d->kv_stride)))
@@ -304,7 +403,15 @@ extern "C" int gr_gemv_fused(const gr_gemv_desc* d, hipStream_t stream) {
       return GR_EINVAL;
     attr_set = true;
   }
-  const dim3 grid(gr_cdiv(d->N, ROWS));
+  static int n_cu = 0;
+  if (n_cu == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return GR_EINVAL;
+    n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  }
+  const int groups = gr_cdiv(d->N, ROWS);
+  const dim3 grid(groups < GF_WG_PER_CU * n_cu ? groups : GF_WG_PER_CU * n_cu);  // persistent over row groups
   if (d->x_mode == 0) {
     if (MB == 4) hipLaunchKernelGGL((gemv_fused_kernel<4, true>), grid, dim3(256), 0, stream, p);
     else hipLaunchKernelGGL((gemv_fused_kernel<8, true>), grid, dim3(256), 0, stream, p);

@@ -6,13 +6,19 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 from groma_amd.csrc import build as B
 
 name, flags = sys.argv[1], sys.argv[2:]
+# --src=a.hip,b.hip: the sources recompiled with the flags (default: the two GEMM files)
+srcs = ("gemm_bf16_256.hip", "gemm_bf16.hip")
+for f in list(flags):
+    if f.startswith("--src="):
+        srcs = tuple(f[6:].split(","))
+        flags.remove(f)
 B.build(verbose=False)
 here = os.path.dirname(os.path.abspath(__file__))
 tmp = tempfile.mkdtemp()
 objs = []
 for src, extra in B.SOURCES.items():
     o = os.path.join(B.HERE, src.replace(".hip", ".o"))
-    if src in ("gemm_bf16_256.hip", "gemm_bf16.hip"):   # gemm_bf16.hip includes the 256 kernel's launch path
+    if src in srcs:   # (gemm_bf16.hip includes the 256 kernel's launch path)
         o = os.path.join(tmp, src.replace(".hip", ".o"))
         subprocess.check_call(["hipcc"] + B.COMMON + extra + flags + ["-c", os.path.join(B.HERE, src), "-o", o])
     objs.append(o)

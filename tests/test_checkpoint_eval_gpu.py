@@ -47,7 +47,8 @@ def test_from_pretrained_on_device_matches_state_dict_model_and_oracle(dev, tmp_
     torch.manual_seed(4)
     o32 = m32.forward(input_ids=ids.clone(), images=images, return_dict=True)
     torch.manual_seed(4)
-    ref32 = O.groma_forward(sd, cfg.to_dict(), util.tok_dict(tk), ids.clone(), images)   # unchained: the oracle's own ViT
+    ref32 = O.groma_forward(sd, cfg.to_dict(), util.tok_dict(tk), ids.clone(), images,
+                            hidden_states=tuple(h.cpu() for h in m32._last_aux["hidden4"]))   # (no gap-selected seed here: chained)
     assert torch.equal(m32._last_aux["nms_keep"][0], ref32["nms_inds"][0]) and torch.equal(m32._last_aux["input_ids"], ref32["input_ids"])
     assert util.relerr(o32.logits, ref32["logits"]) < 1e-4
     del m32
