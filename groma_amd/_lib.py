@@ -68,8 +68,6 @@ SIGNATURES = {
     "gr_rmsnorm": [_P, _P, _P, _I, _I, _L, _L, _F, _I, _P],
     "gr_attention_bf16": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _F, _P, _I, _L, _P, _P, _P],
     "gr_qkv_split": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _I, _P],
-    "gr_decode_reduce_norm": [_P, _I, _P, _P, _P, _I, _I, _F, _P],
-    "gr_decode_qkv_rope": [_P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _I, _P],
     "gr_decode_attention": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _P, _I, _I, _P, _P],
     "gr_resize_h_u8": [_P, _P, _P, _P, _I, _I, _I, _I, _P],
     "gr_resize_v_norm": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],

@@ -1,124 +1,11 @@
-// Decode-step kernels (one new token per sequence row, M = rows <= 8): SURVEY §8a row a22.
-// A decode step streams 13.2 GB of bf16 weights (HBM-bound, gemv_bf16.hip); everything else on the step is tiny, so
-// its cost is the NUMBER of kernels (each costs >= ~4.7 us of GPU timeline on MI355X) and their dependent-latency
-// chains.  These kernels fuse the split-K reductions of the weight-streaming GEMVs into their consumers and replace
-// the 128-query-row MFMA attention tile (1 useful row) by a one-block-per-(row, head) dot-product kernel:
-//   gr_decode_reduce_norm : h += sum_z part[z]  ;  x = bf16(RMSNorm(h) * gamma)          (o-proj / down-proj consumer)
-//   gr_decode_qkv_rope    : qkv = bf16(sum_z part[z]) -> RoPE -> q, K-cache row, V^T-cache column   (qkv consumer)
-//   gr_decode_attention   : softmax(q K^T * scale) V over the cache, one block per (row, head)
+// Decode-step attention (one new token per sequence row, M = rows <= 8): SURVEY 8a row a22.
+// A decode step streams 13.2 GB of 16-bit weights (HBM-bound: gemv_fused.hip, one kernel per weight matrix with its producer and
+// consumer fused in); what is left between the weight streams is this kernel: the 128-query-row MFMA attention tile (1 useful
+// row) replaced by a one-block-per-(row, head) dot-product kernel, optionally over key slices that the o-proj stream merges.
+//   gr_decode_attention   : softmax(q K^T * scale) V over the cache, one block per (row, head[, key slice])
 // Positions come from device memory when pos_dev is given (hipGraph replay / ragged continuous batching).
 #include "gr_common.h"
 #include "../../include/groma_hip.h"
-
-// ------------------------------------------------------------------------------------------------
-// h[m,:] += sum_z part[z,m,:] (z ascending: deterministic), then RMSNorm -> x bf16.  One block per row.
-__global__ __launch_bounds__(1024) void decode_reduce_norm_kernel(const float* __restrict__ part, int splits,
-                                                                 float* __restrict__ h, const float* __restrict__ gamma,
-                                                                 bf16_t* __restrict__ x, int M, int N, float eps) {
-  __shared__ float red[16];
-  const int m = blockIdx.x, tid = threadIdx.x;
-  float* hr = h + (long)m * N;
-  f32x4 v[2];  // N <= 8192
-  float ss = 0.f;
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int c = tid * 4 + i * 4096;
-    if (c < N) {
-      f32x4 a = {0.f, 0.f, 0.f, 0.f};
-      if (part) {
-        const float* pp = part + (long)m * N + c;
-        for (int z = 0; z < splits; ++z) a += *(const f32x4*)(pp + (long)z * M * N);
-      }
-      a += *(const f32x4*)(hr + c);
-      if (part) *(f32x4*)(hr + c) = a;
-      v[i] = a;
-      ss += a[0] * a[0] + a[1] * a[1] + a[2] * a[2] + a[3] * a[3];
-    }
-  }
-  ss = block_sum(ss, red);
-  const float rstd = rsqrtf(ss / (float)N + eps);
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int c = tid * 4 + i * 4096;
-    if (c < N) {
-      const f32x4 g = *(const f32x4*)(gamma + c);
-      const f32x4 o = g * (v[i] * rstd);
-      uint2 pk;
-      pk.x = pack2bf(o[0], o[1]);
-      pk.y = pack2bf(o[2], o[3]);
-      *(uint2*)(x + (long)m * N + c) = pk;
-    }
-  }
-}
-
-extern "C" int gr_decode_reduce_norm(const float* part, int splits, float* h, const float* gamma, void* x, int M, int N,
-                                     float eps, hipStream_t stream) {
-  if (GR_SP) return GR_EINVAL;  // the streaming decode / e4m3 kernels do not exist in the split-operand build (gr_common.h)
-  if (!h || !gamma || !x || M <= 0 || N <= 0 || N % 4 != 0 || N > 8192 || (part && splits <= 0)) return GR_EINVAL;
-  hipLaunchKernelGGL(decode_reduce_norm_kernel, dim3(M), dim3(1024), 0, stream, part, splits, h, gamma, (bf16_t*)x, M, N, eps);
-  GR_CHECK_LAUNCH();
-  return GR_OK;
-}
-
-// ------------------------------------------------------------------------------------------------
-// Fused-QKV split of ONE new position per row from split-K partials: part [splits, B, 3*H*HD] f32.
-// The summed projection is rounded to bf16 first (exactly what the prefill path's GEMM epilogue stores), then HF
-// rotate_half RoPE in f32 (pack.hip qkv_split_kernel semantics), then q / K-cache row / V^T-cache column.
-template <int HD>
-__global__ __launch_bounds__(HD) void decode_qkv_rope_kernel(const float* __restrict__ part, int splits,
-                                                             bf16_t* __restrict__ q, bf16_t* __restrict__ k,
-                                                             bf16_t* __restrict__ vt, const float* __restrict__ cosT,
-                                                             const float* __restrict__ sinT, int B, int H, int pos0,
-                                                             int kv_stride, const int* __restrict__ pos_dev, int pos_stride) {
-  __shared__ float sq[HD], sk[HD];
-  const int h = blockIdx.x, b = blockIdx.y, d = threadIdx.x;
-  const int pos = pos_dev ? pos_dev[b * pos_stride] : pos0;
-  const long N = 3L * H * HD;
-  const float* pp = part + (long)b * N + h * HD + d;
-  float aq = 0.f, ak = 0.f, av = 0.f;
-  for (int z = 0; z < splits; ++z) {
-    const float* pz = pp + (long)z * B * N;
-    aq += pz[0];
-    ak += pz[(long)H * HD];
-    av += pz[2L * H * HD];
-  }
-  aq = bf2f(f2bf(aq));
-  ak = bf2f(f2bf(ak));
-  sq[d] = aq;
-  sk[d] = ak;
-  __syncthreads();
-  constexpr int HALF = HD / 2;
-  float oq = aq, ok = ak;
-  if (cosT) {
-    const int dc = d < HALF ? d : d - HALF, dp = d < HALF ? d + HALF : d - HALF;
-    const float sgn = d < HALF ? -1.f : 1.f;
-    const float c = cosT[(long)pos * HALF + dc], s = sinT[(long)pos * HALF + dc];
-    oq = aq * c + sgn * sq[dp] * s;
-    ok = ak * c + sgn * sk[dp] * s;
-  }
-  const long bh = (long)b * H + h;
-  q[bh * HD + d] = f2bf(oq);
-  k[(bh * kv_stride + pos) * HD + d] = f2bf(ok);
-  vt[(bh * HD + d) * kv_stride + pos] = f2bf(av);
-}
-
-extern "C" int gr_decode_qkv_rope(const float* part, int splits, void* q, void* k, void* vt, const float* cosT,
-                                  const float* sinT, int B, int H, int head_dim, int pos0, int kv_stride,
-                                  const int* pos_dev, int pos_stride, hipStream_t stream) {
-  if (GR_SP) return GR_EINVAL;  // the streaming decode / e4m3 kernels do not exist in the split-operand build (gr_common.h)
-  if (!part || !q || !k || !vt || splits <= 0 || B <= 0 || H <= 0 || (!pos_dev && (pos0 < 0 || pos0 >= kv_stride))) return GR_EINVAL;
-  if ((cosT == nullptr) != (sinT == nullptr)) return GR_EINVAL;
-  dim3 grid(H, B);
-  if (head_dim == 128)
-    hipLaunchKernelGGL(decode_qkv_rope_kernel<128>, grid, dim3(128), 0, stream, part, splits, (bf16_t*)q, (bf16_t*)k,
-                       (bf16_t*)vt, cosT, sinT, B, H, pos0, kv_stride, pos_dev, pos_stride);
-  else if (head_dim == 64)
-    hipLaunchKernelGGL(decode_qkv_rope_kernel<64>, grid, dim3(64), 0, stream, part, splits, (bf16_t*)q, (bf16_t*)k,
-                       (bf16_t*)vt, cosT, sinT, B, H, pos0, kv_stride, pos_dev, pos_stride);
-  else return GR_EINVAL;
-  GR_CHECK_LAUNCH();
-  return GR_OK;
-}
 
 // ------------------------------------------------------------------------------------------------
 // Single-query attention over the cache: one 1024-thread block per (row b, head h).

@@ -24,9 +24,9 @@
 #include "../../include/groma_hip.h"
 
 #define GF_KS 512  // K slice: 64 lanes x 8 elements
-#ifndef GF_NV
-#define GF_NV 32   // dot products per row group (rows x padded batch rows); 64 was A/B-measured (tests/diag/gemv_bench.py)
-#endif
+#ifndef GF_ROWS
+#define GF_ROWS 8  // rows of W per row group at either batch width (A/B on one box, tests/diag/gemv_bench.py -> profiles/r04_gemv_ab.txt:
+#endif             //  4 rows x 8 batch rows 3.3 TB/s, 8 x 8 3.6; 16 x 4 2.8, 8 x 4 4.5)
 #ifndef GF_WG_PER_CU
 #define GF_WG_PER_CU 2  // persistent workgroups per CU
 #endif
@@ -68,9 +68,9 @@ struct GemvFArgs {
 // 8-row group redid it), and the first two slices of the NEXT group are requested before the butterfly / LDS exchange /
 // epilogue of the current one, so the weight stream does not drain between groups.
 template <int MB, bool XG>
-__global__ __launch_bounds__(256, 2) void gemv_fused_kernel(GemvFArgs p) {
-  constexpr int NV = GF_NV;      // dot products per row group = ROWS x MB: lanes 0..NV-1 own one each after the butterfly
-  constexpr int ROWS = NV / MB;  // rows of W per group (8 at <= 4 batch rows, 4 at 8)
+__global__ __launch_bounds__(256, (XG && MB == 8) ? 1 : 2) void gemv_fused_kernel(GemvFArgs p) {
+  constexpr int ROWS = GF_ROWS;  // rows of W per group
+  constexpr int NV = ROWS * MB;  // dot products per row group (32 at <= 4 batch rows, 64 at 8): lanes 0..NV-1 own one each after the butterfly
   extern __shared__ __attribute__((aligned(16))) char smem[];
   bf16_t* xs = (bf16_t*)smem;                         // x_mode 1 / 2: [MB][K]
   __shared__ float red[4][NV];
@@ -374,14 +374,14 @@ extern "C" int gr_gemv_fused(const gr_gemv_desc* d, hipStream_t stream) {
   if (GR_SP) return GR_EINVAL;  // no split-operand form: a decode step of the reference-precision build runs the general kernels
   if (!d || !d->W || d->M <= 0 || d->M > 8 || d->N <= 0 || d->K <= 0 || d->K % 64 != 0 || d->ldw < d->K) return GR_EINVAL;
   if (d->x_mode < 0 || d->x_mode > 2 || d->epi < 0 || d->epi > 3) return GR_EINVAL;
-  if (d->N % (GF_NV / (d->M <= 4 ? 4 : 8)) != 0 || (long)d->ldw * 2 * GF_NV >= (1L << 31)) return GR_EINVAL;  // whole row groups; 32-bit row offsets
+  if (d->N % GF_ROWS != 0 || (long)d->ldw * 2 * GF_ROWS >= (1L << 31)) return GR_EINVAL;  // whole row groups; 32-bit row offsets
   if (d->x_mode == 0 && (!d->A || d->lda < d->K)) return GR_EINVAL;
   if (d->x_mode == 1 && (!d->h || !d->gamma || d->K % 4 != 0 || d->ldh < d->K)) return GR_EINVAL;
   if (d->x_mode == 2 && (!d->a_parts || d->a_nsplit < 1 || d->a_hd < 8 || d->a_hd % 8 != 0 || d->K % d->a_hd != 0)) return GR_EINVAL;
   if (d->epi == 0 && (!d->C || d->ldc < d->N)) return GR_EINVAL;
   if (d->epi == 1 && (!d->resid || d->ldr < d->N)) return GR_EINVAL;
   if (d->epi == 2 && (!d->C || d->N % 2 != 0 || d->ldc < d->N / 2)) return GR_EINVAL;
-  const int MB = d->M <= 4 ? 4 : 8, ROWS = GF_NV / MB;
+  const int MB = d->M <= 4 ? 4 : 8, ROWS = GF_ROWS;
   if (d->epi == 3) {
     if (!d->q || !d->kc || !d->vt || d->H <= 0 || d->HD <= 0 || d->HD % (2 * ROWS) != 0 || d->N != 3 * d->H * d->HD) return GR_EINVAL;
     if ((d->cosT == nullptr) != (d->sinT == nullptr) || d->kv_stride <= 0 || (!d->pos_dev && (d->pos0 < 0 || d->pos0 >= d->kv_stride)))

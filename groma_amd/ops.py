@@ -250,7 +250,7 @@ def gemm(a, w, *, out=None, bias=None, scale=None, resid=None, act=0, out_f32=Fa
 
 def gemv_partials(a, w, M=None, a_parts=None):
     """Decode-step weight streaming: returns (part f32 [splits, M, N], splits) with a @ w^T = sum_z part[z]; the
-    reduction is left to a fused consumer (decode_reduce_norm / decode_qkv_rope).
+    reduction is left to the caller (tests merge decode_attention's key slices through it; the decode step itself runs on gemv_fused).
     a_parts = (parts, nsplit, hd, M): the operand is the un-merged output of decode_attention(nsplit > 1)."""
     lib = _lib.load()
     _chk(w, H16(), "w")
@@ -317,23 +317,6 @@ def gemv_fused(w, *, M, x=None, norm=None, a_parts=None, out=None, resid=None, s
             _chk(pd, I32, "pos_dev")
             d.pos_dev, d.pos_stride = pd.data_ptr(), qkv.get("pos_stride", 0)
     _lib.check(lib.gr_gemv_fused(ctypes.byref(d), _stream()), "gr_gemv_fused")
-
-
-def decode_reduce_norm(part, splits, h, gamma, x, eps):
-    lib = _lib.load()
-    _chk(h, F32, "h"); _chk(x, H16(), "x")
-    N = h.shape[-1]
-    _lib.check(lib.gr_decode_reduce_norm(_p(part), splits, _p(h), _p(gamma), _p(x), h.numel() // N, N, eps, _stream()),
-               "gr_decode_reduce_norm")
-    return x
-
-
-def decode_qkv_rope(part, splits, q, k, vt, cos, sin, *, B, H, hd, pos0=0, pos_dev=None, pos_stride=0):
-    lib = _lib.load()
-    if pos_dev is not None:
-        _chk(pos_dev, I32, "pos_dev")
-    _lib.check(lib.gr_decode_qkv_rope(_p(part), splits, _p(q), _p(k), _p(vt), _p(cos), _p(sin), B, H, hd, pos0, k.shape[2],
-                                      _p(pos_dev), pos_stride, _stream()), "gr_decode_qkv_rope")
 
 
 _DEC_ATT_WS = {}

@@ -83,8 +83,8 @@ typedef struct gr_gemm_desc {
   int c_group, c_group_stride, c_row_off;
   int tile;           /* 0 = choose per shape; 128 / 256 force the 128x128 / 256x256 kernel; 1 = skinny decode
                          kernel (M <= 8; requires splits == ceil(K/512) and ws); 2 = the same kernel but
-                         the split-K partials are LEFT in ws [splits, M, N] f32 for a fused consumer
-                         (gr_decode_reduce_norm / gr_decode_qkv_rope): C and the epilogue fields are unused;
+                         the split-K partials are LEFT in ws [splits, M, N] f32 for the caller
+                         (round 1-3's decode step; the step now runs on gr_gemv_fused): C and the epilogue fields are unused;
                          any other value: GR_EINVAL */
   /* OCP fp8 (e4m3) operands (BASELINE configs[4]): A, W are 1-byte elements, K % 128 == 0, no conv gather;
    * the result is dequantised as acc * a_scale[m] * w_scale[n] before the rest of the epilogue */
@@ -154,22 +154,15 @@ int gr_qkv_split(const void* qkv, void* q, void* k, void* vt, const float* cosT,
                  int head_dim, int pos0, int kv_stride, const int* pos_dev, int pos_stride, hipStream_t stream);
 
 /* ------------------------------------------------------------------------------ decode step -- */
-/* One new token per row (groma/model/groma.py:376-379 + HF LlamaDecoderLayer at L = 1).  Consumers of the
- * weight-streaming GEMV's split-K partials `part` [splits, M, N] f32 (gr_gemm_desc.tile = 2), and single-query attention.
- *   gr_decode_reduce_norm: h[m,:] += sum_z part[z,m,:] (skipped when part is NULL); x = bf16(RMSNorm(h) * gamma)
- *   gr_decode_qkv_rope   : qkv = bf16(sum_z part) with N = 3*H*hd; rotate_half RoPE at the row's position; writes
- *                          q [B,H,1,hd], K-cache row k[b,h,pos,:], V^T-cache column vt[b,h,:,pos]
+/* One new token per row (groma/model/groma.py:376-379 + HF LlamaDecoderLayer at L = 1): gr_gemv_fused (above) streams each
+ * weight matrix with its producer and consumer fused in; between the o-proj and the QKV stream sits single-query attention:
  *   gr_decode_attention  : out[b, h*hd + d] = softmax(q.K^T * scale)[0 .. pos] . V   (Smax <= 8192 = LDS score buffer)
  *                          nsplit > 1 cuts every row's keys into nsplit slices (one block each, so B*H*nsplit blocks
  *                          fill the chip at small B) and writes parts f32 [B*H][nsplit][hd+2] instead of out; the
- *                          o-proj GEMV merges them while loading its operand (gr_gemm_desc.a_parts) -- no cross-block
- *                          hand-off inside the launch, hence no device-scope fence (an L2 write-back on a multi-XCD part)
- * Position of row b = pos_dev ? pos_dev[b * pos_stride] : pos0 / q_pos0 (see gr_attention_bf16). */
-int gr_decode_reduce_norm(const float* part, int splits, float* h, const float* gamma, void* x, int M, int N, float eps,
-                          hipStream_t stream);
-int gr_decode_qkv_rope(const float* part, int splits, void* q, void* k, void* vt, const float* cosT, const float* sinT,
-                       int B, int H, int head_dim, int pos0, int kv_stride, const int* pos_dev, int pos_stride,
-                       hipStream_t stream);
+ *                          o-proj stream merges them while building its operand (gr_gemv_desc.a_parts, x_mode 2) -- no
+ *                          cross-block hand-off inside the launch, hence no device-scope fence (an L2 write-back on a
+ *                          multi-XCD part)
+ * Position of row b = pos_dev ? pos_dev[b * pos_stride] : q_pos0 (see gr_attention_bf16). */
 int gr_decode_attention(const void* q, const void* k, const void* vt, void* out, const int* kv_len, int B, int H, int Smax,
                         int kv_stride, int head_dim, int q_pos0, float scale, const int* pos_dev, int pos_stride,
                         int nsplit, float* parts, hipStream_t stream);

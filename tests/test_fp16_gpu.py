@@ -56,8 +56,10 @@ def test_kernel_suite_with_half_operands(dev, fp16):
     K.test_vit_packing(dev)
     K.test_gn_shuffle(dev)
     K.test_small_movers(dev)
-    K.test_decode_reduce_norm(dev, 4, 4096, 8)
-    K.test_decode_qkv_rope_matches_prefill_split(dev, 128, True)
+    K.test_gemv_fused_operand_and_epilogue_modes(dev, 4, 4096, 4096)
+    K.test_gemv_fused_operand_and_epilogue_modes(dev, 8, 512, 11008)
+    K.test_gemv_fused_qkv_rope_matches_prefill_split(dev, 128, True, 4)
+    K.test_gemv_fused_merges_attention_key_slices(dev)
     K.test_decode_attention(dev, 4, 32, 128, 583, "host", None)
     K.test_decode_attention(dev, 2, 8, 64, 70, "host", 1)
     K.test_attention_reads_q_in_place(dev, 2, 4, 128, 150, True, True)

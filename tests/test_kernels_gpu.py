@@ -444,23 +444,6 @@ def test_norm_fp8(dev):
 
 
 # ------------------------------------------------------------------------------------------------ decode-step kernels
-@pytest.mark.parametrize("M,N,splits", [(4, 4096, 8), (3, 512, 22), (8, 8192, 1), (2, 4096, 0)])
-def test_decode_reduce_norm(dev, M, N, splits):
-    ops = _ops()
-    h = rnd((M, N), dev, seed=1)
-    g = rnd((N,), dev, seed=2)
-    part = rnd((splits, M, N), dev, seed=3) if splits else None
-    x = torch.empty((M, N), dtype=torch.bfloat16, device=dev)
-    h2 = h.clone()
-    ops.decode_reduce_norm(part, splits, h2, g, x, 1e-5)
-    hs = h.double() + (part.double().sum(0) if splits else 0)
-    assert relerr(h2, hs.float()) < 1e-6
-    ref = g * (h2 * torch.rsqrt(h2.pow(2).mean(-1, keepdim=True) + 1e-5))
-    assert relerr(x, ref) < 4e-3
-    if not splits:
-        assert torch.equal(h2, h)  # plain norm: the residual stream is not rewritten
-
-
 @pytest.mark.parametrize("M", [1, 3, 4, 8])
 @pytest.mark.parametrize("N,K", [(4096, 4096), (512, 11008), (32128, 4096), (24, 192)])
 def test_gemv_fused_operand_and_epilogue_modes(dev, M, N, K):
@@ -546,36 +529,6 @@ def test_gemv_fused_merges_attention_key_slices(dev):
     ops.gemv_fused(w, M=B, x=ctx, resid=a)
     ops.gemv_fused(w, M=B, a_parts=r, resid=b)
     assert relerr(b, a) < 3e-3 and relerr(a, ctx.double() @ w.double().t()) < 2e-6
-
-
-@pytest.mark.parametrize("hd,use_dev_pos", [(64, False), (128, True)])
-def test_decode_qkv_rope_matches_prefill_split(dev, hd, use_dev_pos):
-    """decode consumer of the qkv partials == (reduce -> bf16 -> qkv_split at L=1), the path the prefill uses"""
-    ops = _ops()
-    B, H, splits, stride = 4, 5, 8, 128
-    part = rnd((splits, B, 3 * H * hd), dev, seed=1)
-    inv = 1.0 / (10000 ** (torch.arange(0, hd, 2, device=dev).float() / hd))
-    fr = torch.outer(torch.arange(256, device=dev).float(), inv)
-    cos, sin = fr.cos().contiguous(), fr.sin().contiguous()
-    pos = torch.tensor([7, 30, 0, 99], dtype=torch.int32, device=dev)
-    outs = []
-    for fused in (True, False):
-        q = torch.zeros((B, H, 1, hd), dtype=torch.bfloat16, device=dev)
-        k = torch.zeros((B, H, stride, hd), dtype=torch.bfloat16, device=dev)
-        vt = torch.zeros((B, H, hd, stride), dtype=torch.bfloat16, device=dev)
-        kw = dict(pos_dev=pos, pos_stride=1) if use_dev_pos else dict(pos0=11)
-        if fused:
-            ops.decode_qkv_rope(part, splits, q, k, vt, cos, sin, B=B, H=H, hd=hd, **kw)
-        else:
-            acc = torch.zeros_like(part[0])
-            for z in range(splits):
-                acc = acc + part[z]
-            ops.qkv_split(acc.bfloat16(), q, k, vt, B=B, H=H, L=1, hd=hd, cos=cos, sin=sin, **kw)
-        outs.append((q, k, vt))
-    for a, b in zip(*outs):
-        assert (a != 0).any()
-        assert relerr(a, b) < 3e-3 and (a.float() - b.float()).abs().max().item() < 0.04  # <= 1 bf16 ulp (fma contraction)
-    assert torch.equal(outs[0][2], outs[1][2])  # V is a pure copy
 
 
 @pytest.mark.parametrize("nsplit", [1, None, 3])

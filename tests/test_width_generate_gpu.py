@@ -8,7 +8,7 @@ R: groma/eval/eval_rec.py:93-104 (generate call), groma/model/groma.py:176-200,3
     right-padded batch (T6).  The region-token rows of extra_lm_head are boosted so the arg-max margins are far outside the
     bf16 error band (random-init logits are otherwise near-tied and every comparison would be vacuous);
   * the decode-step KERNELS at d = 4096, teacher-forced (engine.TRACE): fused residual-reduce + RMSNorm
-    (decode_reduce_norm), QKV GEMV + RoPE + cache write (gemv_bf16 + decode_qkv_rope), single-query attention with the keys
+    (in the QKV stream's prologue), QKV stream + RoPE + cache write (gemv_fused), single-query attention with the keys
     split over blocks (decode_attention nsplit > 1, merged inside the o-proj GEMV), gate/up GEMV + SwiGLU, down GEMV, head
     GEMV -- each against the oracle's version of that one operation on the tensor the kernel consumed;
   * serving rows at 7B width are bitwise independent of batch composition, under both GEMM plans."""
