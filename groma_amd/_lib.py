@@ -61,7 +61,6 @@ SIGNATURES = {
     "gr_prof_read_launches": [_L, _P, _P, _P],
     "gr_gemm_bf16": [ctypes.POINTER(GemmDesc), _P],
     "gr_gemv_fused": [ctypes.POINTER(GemvDesc), _P],
-    "gr_prefetch": [_P, _L, _I, _P],
     "gr_gemm_f32": [_P, _P, _P, _P, _P, _I, _I, _I, _L, _L, _L, _I, _P],
     "gr_quant_rows_fp8": [_P, _I, _P, _P, _I, _I, _L, _P],
     "gr_norm_fp8": [_P, _P, _P, _P, _P, _I, _I, _F, _I, _P],

@@ -610,26 +610,6 @@ extern "C" int gr_scatter_rows_f32(const float* src, const int* row_idx, float* 
 }
 
 // ---------------------------------------------------------------------------------------
-// Advisory read-ahead of a weight range into the memory-side cache (256 MB Infinity Cache): launched on a second stream beside
-// the decode step's attention kernel, whose 16 us leave HBM almost idle, so that the weight stream that follows finds its first
-// bytes there (engine.LlamaEngine._decode_forward).  Reads and discards; never writes.
-__global__ __launch_bounds__(256) void prefetch_kernel(const uint4* __restrict__ p, long n16, unsigned* __restrict__ sink) {
-  unsigned acc = 0;
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n16; i += (long)gridDim.x * 256) {
-    const uint4 v = p[i];
-    acc ^= v.x ^ v.y ^ v.z ^ v.w;
-  }
-  if (acc == 0x9E3779B9u && sink) *sink = acc;  // (keeps the loads alive; sink is NULL in practice)
-}
-extern "C" int gr_prefetch(const void* p, long bytes, int blocks, hipStream_t stream) {
-  if (!p || bytes < 0 || blocks <= 0) return GR_EINVAL;
-  if (bytes < 16) return GR_OK;
-  hipLaunchKernelGGL(prefetch_kernel, dim3(blocks), dim3(256), 0, stream, (const uint4*)p, bytes / 16, (unsigned*)nullptr);
-  GR_CHECK_LAUNCH();
-  return GR_OK;
-}
-
-// ---------------------------------------------------------------------------------------
 // Greedy next-token: argmax over logits f32 [rows, ld] restricted to [0, V); first maximal index wins.
 __global__ __launch_bounds__(1024) void argmax_kernel(const float* __restrict__ x, long* __restrict__ out, int V, long ld) {
   const int row = blockIdx.x, tid = threadIdx.x;

@@ -19,9 +19,6 @@ H16 = ops.H16  # dtype of the active 16-bit operand type (bf16 / fp16: ops.preci
 
 
 Q_IN_PLACE = True  # prefill attention reads q (and applies RoPE) straight from the fused QKV projection
-# decode step: MB of the o-proj / gate-up weights read ahead into the memory-side cache on a second stream while the
-# single-query attention (HBM nearly idle for ~16 us) runs; 0 = off.  A/B: tests/diag/bench_variant.py ... DECODE_PREFETCH_MB=80
-DECODE_PREFETCH_MB = 0
 
 
 def _ru(x, m):
@@ -642,12 +639,6 @@ class LlamaEngine:
         logits = ops.gemm(hn, w["head"], out_f32=True)
         return logits.view(bs, L, self.Vpad)[:, :, : self.V], hn
 
-    def _prefetch_stream(self, device):
-        s = getattr(self, "_pf_stream", None)
-        if s is None:
-            s = self._pf_stream = torch.cuda.Stream(device=device)
-        return s
-
     def decode_logits(self, bs):
         """the padded f32 [bs, Vpad] buffer every single-position step (either path) leaves its logits in: a dedicated tensor,
         so a captured decode graph and its sampler keep addressing the same memory"""
@@ -669,18 +660,8 @@ class LlamaEngine:
             ops.gemv_fused(Lw["wqkv"][0], M=bs, norm=(h, Lw["n1"], self.eps),
                            qkv=dict(q=q, k=cache.k[i], vt=cache.vt[i], cos=w["cos"], sin=w["sin"], H=H, hd=hd, pos0=past,
                                     pos_dev=pos_dev, pos_stride=pos_stride))
-            if DECODE_PREFETCH_MB:
-                main = torch.cuda.current_stream()
-                side = self._prefetch_stream(h.device)
-                side.wait_stream(main)
-                with torch.cuda.stream(side):
-                    nb = DECODE_PREFETCH_MB << 20
-                    ops.prefetch(Lw["wo"][0], nb)
-                    ops.prefetch(Lw["wgu"][0], nb - Lw["wo"][0].numel() * Lw["wo"][0].element_size())
             att = ops.decode_attention(q, cache.k[i], cache.vt[i], ctx, Smax=cache.smax if dyn else past + 1, q_pos0=past,
                                        kv_len=kv_len, pos_dev=pos_dev, pos_stride=pos_stride)
-            if DECODE_PREFETCH_MB:
-                main.wait_stream(side)
             if t0:
                 _trace("dec0.q", q)
                 TRACE["dec0.nsplit"] = att[1] if isinstance(att, tuple) else 1

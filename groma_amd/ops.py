@@ -320,15 +320,6 @@ def gemv_fused(w, *, M, x=None, norm=None, a_parts=None, out=None, resid=None, s
 
 
 _DEC_ATT_WS = {}
-DEC_ATT_BLOCKS = 128  # decode_attention: key slices per (row, head) are added until at least this many blocks exist (<= 4 slices)
-
-
-def prefetch(t, nbytes=None, blocks=128):
-    """advisory read-ahead of the first `nbytes` of tensor t into the memory-side cache, on the current stream"""
-    n = t.numel() * t.element_size()
-    n = n if nbytes is None else max(0, min(int(nbytes), n))
-    if n >= 16:
-        _lib.check(_lib.load().gr_prefetch(_p(t), n, blocks, _stream()), "gr_prefetch")
 
 
 def decode_attention(q, k, vt, out, *, Smax, q_pos0=0, kv_len=None, scale=None, pos_dev=None, pos_stride=0, nsplit=None):
@@ -348,7 +339,7 @@ def decode_attention(q, k, vt, out, *, Smax, q_pos0=0, kv_len=None, scale=None, 
         # measured on MI355X (tests/diag/dec_attn_bench.py): one block per (row, head) streams the cache at ~4.2 TB/s
         # marginal once B*H >= 128; slicing only pays when fewer blocks than that exist (the consumer-side merge costs
         # ~5 us in the o-proj GEMV).  Independent of S, so eager and graph-replayed steps slice identically.
-        nsplit = 1 if B * H >= DEC_ATT_BLOCKS else max(1, min(4, DEC_ATT_BLOCKS // (B * H)))
+        nsplit = 1 if B * H >= 128 else max(1, min(4, 128 // (B * H)))
     parts = None
     if nsplit > 1:
         key = (B * H, nsplit, hd, str(q.device))

@@ -163,8 +163,6 @@ int gr_qkv_split(const void* qkv, void* q, void* k, void* vt, const float* cosT,
  *                          cross-block hand-off inside the launch, hence no device-scope fence (an L2 write-back on a
  *                          multi-XCD part)
  * Position of row b = pos_dev ? pos_dev[b * pos_stride] : q_pos0 (see gr_attention_bf16). */
-/* advisory read-ahead of [p, p + bytes) into the memory-side cache with `blocks` workgroups (reads and discards) */
-int gr_prefetch(const void* p, long bytes, int blocks, hipStream_t stream);
 int gr_decode_attention(const void* q, const void* k, const void* vt, void* out, const int* kv_len, int B, int H, int Smax,
                         int kv_stride, int head_dim, int q_pos0, float scale, const int* pos_dev, int pos_stride,
                         int nsplit, float* parts, hipStream_t stream);

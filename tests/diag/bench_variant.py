@@ -7,10 +7,6 @@ args = sys.argv[2:]
 import groma_amd.engine as e
 while args and "=" in args[0] and not args[0].startswith("-"):
     name, val = args.pop(0).split("=")
-    if name.startswith("ops."):   # e.g. ops.DEC_ATT_BLOCKS=256
-        import groma_amd.ops as o
-        setattr(o, name[4:], int(val))
-    else:
-        setattr(e, name, int(val) if int(val) > 1 else bool(int(val)))
+    setattr(e, name, bool(int(val)))
 sys.argv = [os.path.join(_variant.ROOT, "bench.py")] + args
 runpy.run_path(sys.argv[0], run_name="__main__")
