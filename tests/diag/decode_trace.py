@@ -2,7 +2,7 @@
 import csv, collections, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
-idx = [i for i, r in enumerate(rows) if r['Kernel_Name'].startswith('argmax')]
+idx = [i for i, r in enumerate(rows) if r['Kernel_Name'].startswith(('sample_rows', 'argmax'))]  # the step's sampler
 a, b = idx[-2], idx[-1]
 agg = collections.OrderedDict()
 t0 = int(rows[a + 1]['Start_Timestamp']); t1 = int(rows[b]['End_Timestamp'])
