@@ -22,6 +22,15 @@
 // time of one 256^2 K-step on a CU relative to one 128^2 K-step of two co-resident blocks (4x the MACs of one
 // block = 2x the work per CU-interval, executed ~1.45x faster per flop)
 #define G256_COST 1.41
+// the 192- / 128-row forms of the ping-pong kernel (round 4): per-K-step cost and per-tile overhead of a round, and the margin by
+// which a smaller tile must win before it is chosen over the 256-row form
+#ifndef PP192_C
+#define PP192_C 1.16
+#define PP192_O 11.0
+#define PP128_C 0.90
+#define PP128_O 9.0
+#define PP_MARGIN 0.97
+#endif
 
 __global__ __launch_bounds__(NTHREADS) void gemm_bf16_kernel(GemmArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -291,22 +300,33 @@ extern "C" int gr_gemm_bf16(const gr_gemm_desc* d, hipStream_t stream) {
   p.c_group = d->c_group; p.c_group_stride = d->c_group_stride; p.c_row_off = d->c_row_off;
   // ---- kernel choice: estimated time = rounds x per-slot tile time (slots: 512 for 128^2 at 2 blocks/CU, 256 for
   // 256^2 at 1 block/CU; per-CU throughput ratio measured on MI355X) ----
-  bool use256 = false;
+  bool use256 = false;  // the ping-pong kernel (gemm_bf16_256.hip), with row tiles of pp_rows
+  int pp_rows = 256;
   const bool gemv = d->tile == 1 || d->tile == 2;  // decode-step shape: weights streamed once, no MFMA (gemv_bf16.hip)
   const bool partials_only = d->tile == 2;         // the caller's next kernel consumes ws[splits, M, N] (decode.hip)
   if (gemv && (p.M > 8 || p.conv_C > 0 || splits != gr_cdiv(p.K, 512) || !p.ws)) return GR_EINVAL;
-  if (d->tile != 0 && d->tile != 1 && d->tile != 2 && d->tile != 128 && d->tile != 256) return GR_EINVAL;
+  if (d->tile != 0 && d->tile != 1 && d->tile != 2 && d->tile != 128 && d->tile != 256 && d->tile != GR_TILE_PP192 && d->tile != GR_TILE_PP128)
+    return GR_EINVAL;
   if (d->tile == 256 || d->fp8) use256 = true;  // fp8 exists for the 256x256 kernel only
+  else if (d->tile == GR_TILE_PP192 || d->tile == GR_TILE_PP128) { use256 = true; pp_rows = d->tile == GR_TILE_PP192 ? 192 : 128; }
   else if (d->tile == 0) {
-    const long t128 = (long)gr_cdiv(p.M, 128) * gr_cdiv(p.N, 128), t256 = (long)gr_cdiv(p.M, 256) * gr_cdiv(p.N, 256);
+    const long t128 = (long)gr_cdiv(p.M, 128) * gr_cdiv(p.N, 128);
+    const long tn256 = gr_cdiv(p.N, 256);
     const double ksteps = (double)(p.K / 64) / splits;
-    // fitted on MI355X at M = 14350 / 8148 (tests/gemm_microbench2.py): one round of 512 128^2-tiles costs
-    // 0.96 us x (ksteps + 5), one round of 256 256^2-tiles 1.35 us x (ksteps + 9)
+    // Estimated time = rounds x per-round cost, in units of one K-step of a round of 512 128^2-tiles.  Fitted on MI355X
+    // (tests/gemm_microbench2.py at M = 14350 / 8148; tests/diag/gemm_tile_rows.py at M = 2328 / 582 -> profiles/r04_gemm_tile_rows.txt):
+    // a round of 256 ping-pong tiles costs (ksteps x c + o) with c / o = 1.41 / 13 at 256 rows, PP192_C / PP192_O at 192, PP128_C /
+    // PP128_O at 128 (the MFMA segments shrink with the rows, the 8 LDS-DMA issues per wave and K-tile do not).  All four kernels
+    // produce the same bits, so choosing by M is free of side effects.
     const double e128 = (double)((t128 * splits + 511) / 512) * (ksteps * 1.00 + 5.0);         // 2 tiles of 128^2 per CU
-    const double e256 = (double)((t256 * splits + 255) / 256) * (ksteps * 1.00 * G256_COST + 13.0);
-    use256 = e256 < e128;
+    auto e_pp = [&](int rows, double c, double o) { return (double)(((long)gr_cdiv(p.M, rows) * tn256 * splits + 255) / 256) * (ksteps * c + o); };
+    const double e256 = e_pp(256, G256_COST, 13.0), e192 = e_pp(192, PP192_C, PP192_O), e1p = e_pp(128, PP128_C, PP128_O);
+    double best = e128;
+    if (e256 < best) { best = e256; use256 = true; pp_rows = 256; }
+    if (e192 < best * PP_MARGIN) { best = e192; use256 = true; pp_rows = 192; }
+    if (e1p < best * PP_MARGIN) { best = e1p; use256 = true; pp_rows = 128; }
   }
-  p.tiles_m = gr_cdiv(p.M, use256 ? 256 : BM);
+  p.tiles_m = gr_cdiv(p.M, use256 ? pp_rows : BM);
   p.tiles_n = gr_cdiv(p.N, use256 ? 256 : BN);
   static bool attr_set = false;
   if (!attr_set) {
@@ -327,7 +347,7 @@ extern "C" int gr_gemm_bf16(const gr_gemm_desc* d, hipStream_t stream) {
     const int rc = gr_launch_gemv(p, stream);
     if (rc != GR_OK) return rc;
   } else if (use256) {
-    const int rc = d->fp8 ? gr_launch_gemm256_fp8(p, stream) : gr_launch_gemm256(p, stream);
+    const int rc = d->fp8 ? gr_launch_gemm256_fp8(p, stream) : gr_launch_gemm256(p, stream, pp_rows);
     if (rc != GR_OK) return rc;
   } else {
     hipLaunchKernelGGL(gemm_bf16_kernel, grid, dim3(NTHREADS), 65536, stream, p);

@@ -99,8 +99,8 @@ template <int MODE>
 struct EpiModeCols {
   static constexpr int W4 = MODE == EM_SWIGLU ? 4 : (MODE == EM_BF16 || MODE == EM_BF16_RESID) ? 2 : 1;
 };
-template <int MODE, bool FULL>
-__device__ __forceinline__ void epi_tile256(const GemmArgs& p, char* smem, f32x4 (&acc)[8][4], int tid, int wm, int wn, int fr,
+template <int MODE, bool FULL, int MT>
+__device__ __forceinline__ void epi_tile256(const GemmArgs& p, char* smem, f32x4 (&acc)[MT][4], int tid, int wm, int wn, int fr,
                                             int fg, int m0, int n0, int z) {
   constexpr int W4 = EpiModeCols<MODE>::W4;
   constexpr bool DEQ = G256_FP8 != 0;
@@ -117,9 +117,9 @@ __device__ __forceinline__ void epi_tile256(const GemmArgs& p, char* smem, f32x4
       for (int j = 0; j < 4; ++j) stage_write4<T256>(buf, wm * 32 + e * 16 + fr, wn * 16 + j * 4 + fg, acc[2 * q + e][j]);
     __syncthreads();
     CLK_MARK(3 + 2 * q)
-    // staged row sr of this pass -> tile row (sr>>5)*128 + q*32 + (sr&31)
+    // staged row sr of this pass -> tile row (sr>>5)*H + q*32 + (sr&31), H = 16*MT rows per wave-row half of the tile
     auto rm = [&](int it) { return it * (NT / TPR) + tid / TPR; };
-    auto mm = [&](int it) { const int sr = it * (NT / TPR) + tid / TPR; return m0 + (sr >> 5) * 128 + q * 32 + (sr & 31); };
+    auto mm = [&](int it) { const int sr = it * (NT / TPR) + tid / TPR; return m0 + (sr >> 5) * (16 * MT) + q * 32 + (sr & 31); };
     const int c4 = (tid % TPR) * W4;
     if constexpr (MODE == EM_SPLITK) epi_rows_splitk<T256, NR, FULL>(p, buf, c4, n0, z, rm, mm);
     else if constexpr (MODE == EM_SWIGLU) epi_rows_swiglu<T256, NR, DEQ, FULL>(p, buf, c4, n0, ec, rm, mm);
@@ -129,11 +129,23 @@ __device__ __forceinline__ void epi_tile256(const GemmArgs& p, char* smem, f32x4
   };
   pass(std::integral_constant<int, 0>{});
   pass(std::integral_constant<int, 1>{});
-  pass(std::integral_constant<int, 2>{});
-  pass(std::integral_constant<int, 3>{});
+  if constexpr (MT >= 6) pass(std::integral_constant<int, 2>{});
+  if constexpr (MT >= 8) pass(std::integral_constant<int, 3>{});
 }
 
+// MT = 16-row m-tiles per wave: the tile is (32*MT) x 256 -- 256 rows (MT 8: the kernel of rounds 1-3), 192 (MT 6) or 128 (MT 4).
+// Round 4: at 4 images per call (M = 2328) the N = 4096 GEMMs are 10 x 16 = 160 tiles of 256 rows on 256 CUs; 13 x 16 = 208 tiles
+// of 192 rows do 0.75 of the work each in the same single round, and at one image (M = 582) 5 x 48 tiles of 128 rows fill the
+// chip where 3 x 48 of 256 leave it 44 % idle.  Everything scales with MT through the wave-row height H = 16*MT: each wave
+// still owns MT x 4 MFMA tiles in two phases of MT/2 m-tiles, each A half-tile is still TWO LDS-DMA instructions per wave -- with
+// 8*MT of the 64 lanes active, MT rows of 8 chunks -- so the counted vmcnt waits are unchanged; the epilogue runs MT/2 passes.
+// An output element's K order is identical in all three (and in the 128x128 kernel): results are bitwise equal whatever tile
+// the launcher picks, so the choice may depend on M without touching batch independence.
+template <int MT>
 __global__ __launch_bounds__(NT) void G256_KERNEL(GemmArgs p) {
+  constexpr int H = 16 * MT;    // rows of the tile owned by one wave row (wm)
+  constexpr int BM = 2 * H;     // tile rows
+  constexpr int MTX = MT / 2;   // m-tiles per phase
   extern __shared__ __attribute__((aligned(16))) char smem[];
   CLK_MARK(0)
 
@@ -158,7 +170,7 @@ __global__ __launch_bounds__(NT) void G256_KERNEL(GemmArgs p) {
   if (vb != (int)blockIdx.x) __syncthreads();  // the previous tile's epilogue has finished reading the stage buffers
   int tm, tn;
   tile_of_block(vb, total_tiles, p.tiles_m, p.tiles_n, tm, tn);
-  const int m0 = tm * T256, n0 = tn * T256;
+  const int m0 = tm * BM, n0 = tn * T256;
 
   const int ksteps_total = p.K / KT;
   const int z = blockIdx.y;
@@ -166,17 +178,19 @@ __global__ __launch_bounds__(NT) void G256_KERNEL(GemmArgs p) {
   const int ks_begin = z * ks_per;
   const int nt = min(ksteps_total, ks_begin + ks_per) - ks_begin;
 
-  // ---- staging geometry.  Half-tile = 128 rows x 8 chunks; chunk q = i*512 + tid (i = 0,1): hrow = q>>3.
-  // physical row inside the 256-row region:  A0: (hrow>>6)*128 + (hrow&63)   A1: +64
-  //                                          B0: (hrow>>5)*64  + (hrow&31)   B1: +32
+  // ---- staging geometry.  A half-tile = 2 x (H/2) rows x 8 chunks, B half-tile = 128 rows x 8 chunks; instruction i = 0, 1 of a
+  // half-tile covers, per wave, MT rows of A (lanes with lrow < MT: all 64 at MT = 8) / 8 rows of B.
+  // physical row inside the tile:  A0: i*H + wave*MT + lrow          A1: + H/2
+  //                                B0: (hrow>>5)*64 + (hrow&31)       B1: +32     (hrow = i*64 + wave*8 + lrow)
   const int lrow = lane >> 3, lpos = lane & 7;
+  const bool a_lane_on = lrow < MT;  // this lane takes part in the A instructions (rows beyond the half-tile belong to nobody)
   const char* src[4][2];  // [half-tile][i] : per-lane global source (row base + swizzled 16-B chunk), k-offset added later
   int ldsoff[4][2];         // wave-uniform LDS byte offset inside a stage
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
-    const int ra = i * 128 + wave * 8;                            // A0 row of lane 0
+    const int ra = i * H + wave * MT;                             // A0 row of lane 0
     const int rb = (i * 2 + (wave >> 2)) * 64 + (wave & 3) * 8;   // B0 row of lane 0
-    const int rows[4] = {ra, rb, rb + 32, ra + 64};
+    const int rows[4] = {ra, rb, rb + 32, ra + H / 2};
 #pragma unroll
     for (int h = 0; h < 4; ++h) {
       const int r = rows[h] + lrow;
@@ -236,23 +250,25 @@ __global__ __launch_bounds__(NT) void G256_KERNEL(GemmArgs p) {
     if (tile >= 2) return;
 #endif
     char* st = smem + (tile & 1) * STAGE_BYTES;
-    glds16(src[h][0] + koff * ESZ, st + ldsoff[h][0]);
-    glds16(src[h][1] + koff * ESZ, st + ldsoff[h][1]);
+    if (MT == 8 || (h != HT_A0 && h != HT_A1) || a_lane_on) {  // (A instructions of the 192- / 128-row tiles: 8*MT lanes active)
+      glds16(src[h][0] + koff * ESZ, st + ldsoff[h][0]);
+      glds16(src[h][1] + koff * ESZ, st + ldsoff[h][1]);
+    }
   };
   auto issue = [&](int h, int tile) {  // prologue form (offset from the tile index)
     const bool isA = (h == HT_A0 || h == HT_A1);
     issue_at(h, tile, (isA && !G256_FP8) ? a_k_off(p, ks_begin + tile) : (long)(ks_begin + tile) * KT);
   };
 
-  f32x4 acc[8][4];  // [mi][ni]
+  f32x4 acc[MT][4];  // [mi][ni]
 #pragma unroll
-  for (int i = 0; i < 8; ++i)
+  for (int i = 0; i < MT; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   const int fr = lane & 15, fg = lane >> 4;
   const int off0 = (fg ^ (fr & 7)) << 4;  // chunk fg of a row with (row&7) == (fr&7); the kk=1 chunk is off0 ^ 64
-  const int a_lane = (wm * 128 + fr) * 128;
+  const int a_lane = (wm * H + fr) * 128;
   const int b_lane = B_OFF + (wn * 64 + fr) * 128;
 
   // ---- prologue: P(0) = {A0,B0,B1}(0), Q(0) = {A1}(0), P(1) ; P(0) must have landed before the first reads
@@ -268,7 +284,7 @@ __global__ __launch_bounds__(NT) void G256_KERNEL(GemmArgs p) {
     if (steady) asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory");   \
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               \
   } while (0)
-  bf16x8 af[4][2];
+  bf16x8 af[MTX][2];
 
   PH_DECL
   // Two 32-MFMA phases per K-tile instead of four 16-MFMA ones: every phase boundary costs ~80 clk of barrier round
@@ -288,13 +304,13 @@ __global__ __launch_bounds__(NT) void G256_KERNEL(GemmArgs p) {
 #if GR_SP && !G256_FP8
 #define PHASE_MFMAS(I0)                                                                                   \
   _Pragma("unroll") for (int pp = 0; pp < 3; ++pp)                                                        \
-    _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                         \
+    _Pragma("unroll") for (int i = 0; i < MTX; ++i)                                                       \
       _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                       \
         acc[I0 + i][j] = ABL_MFMA(bfr[j][pp == 1], af[i][pp == 2], acc[I0 + i][j]);
 #else
 #define PHASE_MFMAS(I0)                                                                                   \
   _Pragma("unroll") for (int kk = 0; kk < 2; ++kk)                                                        \
-    _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                         \
+    _Pragma("unroll") for (int i = 0; i < MTX; ++i)                                                       \
       _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                       \
         acc[I0 + i][j] = ABL_MFMA(bfr[j][kk], af[i][kk], acc[I0 + i][j]);
 #endif
@@ -324,7 +340,7 @@ __global__ __launch_bounds__(NT) void G256_KERNEL(GemmArgs p) {
       bfr[j][1] = *(const bf16x8*)(st + b_lane + j * 2048 + (off0 ^ 64));
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < MTX; ++i) {
       af[i][0] = *(const bf16x8*)(st + a_lane + i * 2048 + off0);
       af[i][1] = *(const bf16x8*)(st + a_lane + i * 2048 + (off0 ^ 64));
     }
@@ -340,9 +356,9 @@ __global__ __launch_bounds__(NT) void G256_KERNEL(GemmArgs p) {
 #endif
     {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      af[i][0] = *(const bf16x8*)(st + a_lane + (4 + i) * 2048 + off0);
-      af[i][1] = *(const bf16x8*)(st + a_lane + (4 + i) * 2048 + (off0 ^ 64));
+    for (int i = 0; i < MTX; ++i) {
+      af[i][0] = *(const bf16x8*)(st + a_lane + (MTX + i) * 2048 + off0);
+      af[i][1] = *(const bf16x8*)(st + a_lane + (MTX + i) * 2048 + (off0 ^ 64));
     }
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -352,7 +368,7 @@ __global__ __launch_bounds__(NT) void G256_KERNEL(GemmArgs p) {
     issue_at(HT_B1, t + 2, (long)(ks_begin + t + 2) * KT);
     advance();
     DRAIN_READS
-    PHASE32(1, 4)
+    PHASE32(1, MTX)
   }
   PH_FLUSH
   if (wm == 0) __builtin_amdgcn_s_barrier();  // re-align the groups (same barrier count for every wave)
@@ -362,12 +378,12 @@ __global__ __launch_bounds__(NT) void G256_KERNEL(GemmArgs p) {
   CLK_MARK(1)
   {
     // tile-uniform: interior tile of a plain row-major output -> guard-free, division-free straight-line passes
-    const bool full = m0 + T256 <= p.M && n0 + T256 <= p.N && p.c_group == 0 && p.resid_mod == 0;
+    const bool full = m0 + BM <= p.M && n0 + T256 <= p.N && p.c_group == 0 && p.resid_mod == 0;
 #define EPI_GO(MODE)                                                                                          \
   do {                                                                                                        \
-    if (full) epi_tile256<MODE, true>(p, smem, acc, tid, wm, wn, fr, fg, m0, n0, z);                          \
+    if (full) epi_tile256<MODE, true, MT>(p, smem, acc, tid, wm, wn, fr, fg, m0, n0, z);                      \
     else {                                                                                                    \
-      epi_tile256<MODE, false>(p, smem, acc, tid, wm, wn, fr, fg, m0, n0, z);                                 \
+      epi_tile256<MODE, false, MT>(p, smem, acc, tid, wm, wn, fr, fg, m0, n0, z);                             \
       __builtin_amdgcn_s_waitcnt(0x0F70); /* vmcnt(0): see below */                                           \
     }                                                                                                         \
   } while (0)
@@ -387,11 +403,20 @@ __global__ __launch_bounds__(NT) void G256_KERNEL(GemmArgs p) {
   CLK_MARK(2)
 }
 
+#if G256_FP8
 int G256_LAUNCH(const GemmArgs& p, hipStream_t stream) {
+  const int tile_rows = 256;
+#else
+int G256_LAUNCH(const GemmArgs& p, hipStream_t stream, int tile_rows) {  // tile_rows: 256 | 192 | 128 (p.tiles_m counts tiles of that height)
+#endif
+  if (tile_rows != 256 && tile_rows != 192 && tile_rows != 128) return GR_EINVAL;
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)G256_KERNEL, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       2 * STAGE_BYTES);
+    hipError_t e = hipFuncSetAttribute((const void*)G256_KERNEL<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES);
+#if !G256_FP8
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)G256_KERNEL<6>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)G256_KERNEL<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES);
+#endif
     if (e != hipSuccess) return (int)e;
     attr_set = true;
   }
@@ -410,7 +435,12 @@ int G256_LAUNCH(const GemmArgs& p, hipStream_t stream) {
 #endif
   const int tiles = p.tiles_m * p.tiles_n;
   dim3 grid(persist_off ? tiles : (tiles < n_cu ? tiles : n_cu), p.splits);
-  hipLaunchKernelGGL(G256_KERNEL, grid, dim3(NT), 2 * STAGE_BYTES, stream, p);
+#if !G256_FP8
+  if (tile_rows == 192) hipLaunchKernelGGL(G256_KERNEL<6>, grid, dim3(NT), 2 * STAGE_BYTES, stream, p);
+  else if (tile_rows == 128) hipLaunchKernelGGL(G256_KERNEL<4>, grid, dim3(NT), 2 * STAGE_BYTES, stream, p);
+  else
+#endif
+    hipLaunchKernelGGL(G256_KERNEL<8>, grid, dim3(NT), 2 * STAGE_BYTES, stream, p);
   GR_CHECK_LAUNCH();
   return GR_OK;
 }
