@@ -22,15 +22,15 @@
 // time of one 256^2 K-step on a CU relative to one 128^2 K-step of two co-resident blocks (4x the MACs of one
 // block = 2x the work per CU-interval, executed ~1.45x faster per flop)
 #define G256_COST 1.41
-// the 192- / 128-row forms of the ping-pong kernel (round 4): per-K-step cost and per-tile overhead of a round, and the margin by
-// which a smaller tile must win before it is chosen over the 256-row form
-#ifndef PP192_C
-#define PP192_C 1.16
-#define PP192_O 11.0
-#define PP128_C 0.90
-#define PP128_O 9.0
+// the 192-row form of the ping-pong kernel (round 4): per-K-step cost and per-tile overhead of a round relative to the 256-row
+// form's 1.41 / 13, and the margin by which it must win before it is chosen.  Measured (profiles/r04_gemm_tile_rows.txt): the
+// K loop of a 192-row tile is only 3.5 % shorter than that of a 256-row tile (0.99 vs 1.03 us per K-tile at M = 2328: the loop
+// is bound by its load side -- B staging, DMA issue -- which does not shrink with the rows), the epilogue a third shorter.
+#define PP192_C 1.36
+#define PP192_O 9.0
 #define PP_MARGIN 0.97
-#endif
+// one round of <= 256 128^2-tiles runs ONE workgroup per CU instead of two co-resident ones: 0.70-0.72 of the per-tile time
+#define E128_SOLO 0.72
 
 __global__ __launch_bounds__(NTHREADS) void gemm_bf16_kernel(GemmArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -305,26 +305,25 @@ extern "C" int gr_gemm_bf16(const gr_gemm_desc* d, hipStream_t stream) {
   const bool gemv = d->tile == 1 || d->tile == 2;  // decode-step shape: weights streamed once, no MFMA (gemv_bf16.hip)
   const bool partials_only = d->tile == 2;         // the caller's next kernel consumes ws[splits, M, N] (decode.hip)
   if (gemv && (p.M > 8 || p.conv_C > 0 || splits != gr_cdiv(p.K, 512) || !p.ws)) return GR_EINVAL;
-  if (d->tile != 0 && d->tile != 1 && d->tile != 2 && d->tile != 128 && d->tile != 256 && d->tile != GR_TILE_PP192 && d->tile != GR_TILE_PP128)
-    return GR_EINVAL;
+  if (d->tile != 0 && d->tile != 1 && d->tile != 2 && d->tile != 128 && d->tile != 256 && d->tile != GR_TILE_PP192) return GR_EINVAL;
   if (d->tile == 256 || d->fp8) use256 = true;  // fp8 exists for the 256x256 kernel only
-  else if (d->tile == GR_TILE_PP192 || d->tile == GR_TILE_PP128) { use256 = true; pp_rows = d->tile == GR_TILE_PP192 ? 192 : 128; }
+  else if (d->tile == GR_TILE_PP192) { use256 = true; pp_rows = 192; }
   else if (d->tile == 0) {
     const long t128 = (long)gr_cdiv(p.M, 128) * gr_cdiv(p.N, 128);
     const long tn256 = gr_cdiv(p.N, 256);
     const double ksteps = (double)(p.K / 64) / splits;
     // Estimated time = rounds x per-round cost, in units of one K-step of a round of 512 128^2-tiles.  Fitted on MI355X
     // (tests/gemm_microbench2.py at M = 14350 / 8148; tests/diag/gemm_tile_rows.py at M = 2328 / 582 -> profiles/r04_gemm_tile_rows.txt):
-    // a round of 256 ping-pong tiles costs (ksteps x c + o) with c / o = 1.41 / 13 at 256 rows, PP192_C / PP192_O at 192, PP128_C /
-    // PP128_O at 128 (the MFMA segments shrink with the rows, the 8 LDS-DMA issues per wave and K-tile do not).  All four kernels
-    // produce the same bits, so choosing by M is free of side effects.
-    const double e128 = (double)((t128 * splits + 511) / 512) * (ksteps * 1.00 + 5.0);         // 2 tiles of 128^2 per CU
+    // a round of 256 ping-pong tiles costs (ksteps x c + o) with c / o = 1.41 / 13 at 256 rows, PP192_C / PP192_O at 192 rows.  The
+    // three kernels produce the same bits, so choosing by M is free of side effects.  (A 128-row x 256-column form of the ping-pong
+    // kernel was built and measured too: never the best -- the 128x128 kernel wins at small M, 192 / 256 rows above -- and removed.)
+    double e128 = (double)((t128 * splits + 511) / 512) * (ksteps * 1.00 + 5.0);         // 2 tiles of 128^2 per CU
+    if (t128 * splits <= 256) e128 *= E128_SOLO;
     auto e_pp = [&](int rows, double c, double o) { return (double)(((long)gr_cdiv(p.M, rows) * tn256 * splits + 255) / 256) * (ksteps * c + o); };
-    const double e256 = e_pp(256, G256_COST, 13.0), e192 = e_pp(192, PP192_C, PP192_O), e1p = e_pp(128, PP128_C, PP128_O);
+    const double e256 = e_pp(256, G256_COST, 13.0), e192 = e_pp(192, PP192_C, PP192_O);
     double best = e128;
     if (e256 < best) { best = e256; use256 = true; pp_rows = 256; }
     if (e192 < best * PP_MARGIN) { best = e192; use256 = true; pp_rows = 192; }
-    if (e1p < best * PP_MARGIN) { best = e1p; use256 = true; pp_rows = 128; }
   }
   p.tiles_m = gr_cdiv(p.M, use256 ? pp_rows : BM);
   p.tiles_n = gr_cdiv(p.N, use256 ? 256 : BN);

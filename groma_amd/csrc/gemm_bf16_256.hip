@@ -129,14 +129,15 @@ __device__ __forceinline__ void epi_tile256(const GemmArgs& p, char* smem, f32x4
   };
   pass(std::integral_constant<int, 0>{});
   pass(std::integral_constant<int, 1>{});
-  if constexpr (MT >= 6) pass(std::integral_constant<int, 2>{});
+  if constexpr (MT >= 6) pass(std::integral_constant<int, 2>{});  // (MT = 6: three passes)
   if constexpr (MT >= 8) pass(std::integral_constant<int, 3>{});
 }
 
-// MT = 16-row m-tiles per wave: the tile is (32*MT) x 256 -- 256 rows (MT 8: the kernel of rounds 1-3), 192 (MT 6) or 128 (MT 4).
+// MT = 16-row m-tiles per wave: the tile is (32*MT) x 256 -- 256 rows (MT 8: the kernel of rounds 1-3) or 192 (MT 6).
 // Round 4: at 4 images per call (M = 2328) the N = 4096 GEMMs are 10 x 16 = 160 tiles of 256 rows on 256 CUs; 13 x 16 = 208 tiles
-// of 192 rows do 0.75 of the work each in the same single round, and at one image (M = 582) 5 x 48 tiles of 128 rows fill the
-// chip where 3 x 48 of 256 leave it 44 % idle.  Everything scales with MT through the wave-row height H = 16*MT: each wave
+// of 192 rows do 0.75 of the work each in the same single round (measured: o-proj 89.6 -> 78.6 us, down-proj 196.4 -> 181.7:
+// the K loop itself is load-bound and barely shortens, the fp32-residual epilogue does; a 128-row form, MT 4, was measured too
+// and lost to the 128x128 kernel at every shape it was meant for).  Everything scales with MT through the wave-row height H = 16*MT: each wave
 // still owns MT x 4 MFMA tiles in two phases of MT/2 m-tiles, each A half-tile is still TWO LDS-DMA instructions per wave -- with
 // 8*MT of the 64 lanes active, MT rows of 8 chunks -- so the counted vmcnt waits are unchanged; the epilogue runs MT/2 passes.
 // An output element's K order is identical in all three (and in the 128x128 kernel): results are bitwise equal whatever tile
@@ -407,15 +408,14 @@ __global__ __launch_bounds__(NT) void G256_KERNEL(GemmArgs p) {
 int G256_LAUNCH(const GemmArgs& p, hipStream_t stream) {
   const int tile_rows = 256;
 #else
-int G256_LAUNCH(const GemmArgs& p, hipStream_t stream, int tile_rows) {  // tile_rows: 256 | 192 | 128 (p.tiles_m counts tiles of that height)
+int G256_LAUNCH(const GemmArgs& p, hipStream_t stream, int tile_rows) {  // tile_rows: 256 | 192 (p.tiles_m counts tiles of that height)
 #endif
-  if (tile_rows != 256 && tile_rows != 192 && tile_rows != 128) return GR_EINVAL;
+  if (tile_rows != 256 && tile_rows != 192) return GR_EINVAL;
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)G256_KERNEL<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES);
 #if !G256_FP8
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)G256_KERNEL<6>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES);
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)G256_KERNEL<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES);
 #endif
     if (e != hipSuccess) return (int)e;
     attr_set = true;
@@ -437,7 +437,6 @@ int G256_LAUNCH(const GemmArgs& p, hipStream_t stream, int tile_rows) {  // tile
   dim3 grid(persist_off ? tiles : (tiles < n_cu ? tiles : n_cu), p.splits);
 #if !G256_FP8
   if (tile_rows == 192) hipLaunchKernelGGL(G256_KERNEL<6>, grid, dim3(NT), 2 * STAGE_BYTES, stream, p);
-  else if (tile_rows == 128) hipLaunchKernelGGL(G256_KERNEL<4>, grid, dim3(NT), 2 * STAGE_BYTES, stream, p);
   else
 #endif
     hipLaunchKernelGGL(G256_KERNEL<8>, grid, dim3(NT), 2 * STAGE_BYTES, stream, p);

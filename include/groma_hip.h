@@ -82,9 +82,8 @@ typedef struct gr_gemm_desc {
   /* output row remap: row(m) = (m / c_group)*c_group_stride + c_row_off + m % c_group (c_group > 0) */
   int c_group, c_group_stride, c_row_off;
 #define GR_TILE_PP192 192 /* ping-pong kernel with 192-row tiles */
-#define GR_TILE_PP128 129 /* ping-pong kernel with 128-row (x 256-column) tiles; 128 is the 128x128 kernel */
   int tile;           /* 0 = choose per shape (all MFMA kernels produce the same bits); 128 / 256 force the 128x128 / 256x256
-                         kernel, GR_TILE_PP192 / GR_TILE_PP128 the 192- / 128-row forms of the latter; 1 = skinny decode
+                         kernel, GR_TILE_PP192 the 192-row form of the latter; 1 = skinny decode
                          kernel (M <= 8; requires splits == ceil(K/512) and ws); 2 = the same kernel but
                          the split-K partials are LEFT in ws [splits, M, N] f32 for the caller
                          (round 1-3's decode step; the step now runs on gr_gemv_fused): C and the epilogue fields are unused;

@@ -44,7 +44,7 @@ def test_kernel_suite_with_half_operands(dev, fp16):
             K.test_gemm_plain(dev, M, N, Kd, tile)
     for shape in [(582, 4096, 11008), (512, 256, 1280), (300, 512, 1216)]:
         K.test_gemm_fp32_residual_large_shapes(dev, *shape)
-    for tile in (128, 256, 192, 129):
+    for tile in (128, 256, 192):
         K.test_gemm_epilogues(dev, tile)
         K.test_gemm_conv3x3(dev, 3, 14, 64, 64, 3, tile)
     K.test_gemm_decode_shape(dev, 4, 32128, 4096)

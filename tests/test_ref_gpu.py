@@ -63,7 +63,7 @@ def test_split_gemm_vs_float64(dev, ref, M, N, K, tile):
     assert e32 < TOL and e16 < TOL
 
 
-@pytest.mark.parametrize("tile", [128, 256, 192, 129])
+@pytest.mark.parametrize("tile", [128, 256, 192])
 def test_split_gemm_epilogues_vs_float64(dev, ref, tile):
     g = torch.Generator().manual_seed(5)
     M, N, K = 700, 512, 1024
@@ -93,7 +93,7 @@ def test_split_gemm_epilogues_vs_float64(dev, ref, tile):
     assert rel64(out.view(7, 101, N)[:, 1:], want) < TOL and float(out.view(7, 101, N)[:, 0].abs().max()) == 0.0
 
 
-@pytest.mark.parametrize("tile", [128, 256, 192, 129])
+@pytest.mark.parametrize("tile", [128, 256, 192])
 def test_split_conv3x3_vs_float64(dev, ref, tile):
     """implicit-GEMM 3x3 conv over a zero-bordered NHWC map of operand pairs, two summed segments (the per-ROI conv's form)"""
     g = torch.Generator().manual_seed(11)
