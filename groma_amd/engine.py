@@ -534,8 +534,10 @@ class LlamaEngine:
     def new_cache(self, bs, smax, device):
         return KVCache(len(self.w["layers"]), bs, self.H, self.hd, _ru(smax, 64), device)
 
-    def forward(self, h, bs, L, cache, kv_len=None, all_logits=True, pos_dev=None, pos_stride=0):
+    def forward(self, h, bs, L, cache, kv_len=None, all_logits=True, pos_dev=None, pos_stride=0, states=None):
         """h: f32 [bs*L, T] input embeddings (consumed as the residual stream, updated in place).
+        states: a list that receives a copy of the residual stream in front of every layer (HF `all_hidden_states`, R:
+        groma/model/groma.py:389-397 with output_hidden_states=True); the launches then run eagerly.
         Appends L positions to `cache`.  Returns logits f32 [bs, L or 1, V] (view into a Vpad-wide buffer).
         pos_dev (i32, device): the append position is read on the device (row b: pos_dev[b*pos_stride]) instead of
         cache.seq_len -- no host value enters the kernel arguments, so the step can be captured in a hipGraph; the
@@ -546,7 +548,7 @@ class LlamaEngine:
         past = 0 if dyn else cache.seq_len
         if not dyn and past + L > cache.smax:
             cache.grow(_ru(past + L + 64, 64))
-        if L == 1 and M <= 8 and not w["fp8"] and T <= 8192 and cache.smax <= 8192 and ops.SP() == 1:
+        if L == 1 and M <= 8 and not w["fp8"] and T <= 8192 and cache.smax <= 8192 and ops.SP() == 1 and states is None:
             return self._decode_forward(h, bs, cache, kv_len, pos_dev, pos_stride, past)
         # A decode step that does not fit the weight-streaming path (more than 8 rows, e4m3 operands, > 8192 keys) runs the
         # general kernels below.  Its scratch may be baked into GreedyDecoder's captured hipGraph, so -- like _decode_forward --
@@ -565,7 +567,7 @@ class LlamaEngine:
         skw = buf("llm_splitk", (n_sk,), F32) if n_sk else None  # caller-owned split-K workspace: see VitEngine.forward
         # a prefill whose shape and memory repeat is replayed from a captured hipGraph (GraphPool): everything the launches
         # bake in goes into the key; the ragged-row lengths are staged into a buffer of our own
-        graph = not dec and not fp8 and TRACE is None and GraphPool.enabled
+        graph = not dec and not fp8 and TRACE is None and GraphPool.enabled and states is None
         if graph and kv_len is not None:
             kvl = ws.get("llm_kvlen", (bs,), I32)
             kvl.copy_(kv_len)
@@ -594,6 +596,8 @@ class LlamaEngine:
                 t0 = TRACE is not None and i == 0
                 if t0:
                     _trace("llm0.h_in", h)
+                if states is not None:
+                    states.append(h.view(bs, L, T).clone())
                 qkv = lin(h, Lw["n1"], Lw["wqkv"], tag="llm0.n1" if t0 else None, out=qkv_b)
                 ops.qkv_split(qkv, q, cache.k[i], cache.vt[i], B=bs, H=H, L=L, hd=hd, pos0=past,
                               cos=w["cos"], sin=w["sin"], pos_dev=pos_dev, pos_stride=pos_stride)

@@ -83,6 +83,11 @@ class GromaModel:
             raise ValueError("fp8=True and precision='ref' are exclusive")
         self.precision = precision
         self.decode_graph = True  # generate(): replay one captured hipGraph per token (False = eager per-kernel launches)
+        # output_hidden_states=True: False = hidden_states[0] is the 1-tuple (final normed state,) -- every reference caller only
+        # reads hidden_states[-1]['pred_boxes'] and passes the flag for that (R: groma/eval/eval_rec.py:93-101), so the 33
+        # per-layer copies (305 MB per image at Groma-7B) are not made by default; True = the reference's full tuple (embeddings,
+        # the residual stream after layers 1..n-1, the final normed state), R: groma/model/groma.py:389-397,421-427
+        self.all_hidden_states = False
         # proposer chain (input_proj -> DDETR encoder x6 -> two-stage top-300 -> decoder x6 -> heads -> score fusion -> NMS,
         # ~330 launches of fp32 kernels that are launch-latency-bound) captured once per batch size and replayed
         self.proposer_graph = True
@@ -488,7 +493,8 @@ class GromaModel:
                 else:
                     emb = inputs_embeds.to(dev, F32).reshape(bs * L, -1).contiguous()
                 kv_len = None  # the reference rebuilds an all-ones mask over past+1 (groma.py:376-379, T6): every cached key is visible
-            logits, hn = self.llm.forward(emb, bs, L, cache, kv_len=kv_len, all_logits=not _last_logits_only)
+            states = [] if (output_hidden_states and self.all_hidden_states) else None
+            logits, hn = self.llm.forward(emb, bs, L, cache, kv_len=kv_len, all_logits=not _last_logits_only, states=states)
 
         loss = None
         if labels is not None:  # groma.py:404-415 (training-side convenience; not on the inference hot path)
@@ -505,7 +511,7 @@ class GromaModel:
             if hn is None:  # decode step: the final norm lives in the head GEMV's prologue; `emb` is the residual stream, updated in place
                 hn = ops.rmsnorm(emb, self.llm.w["norm"], self.llm.eps)
             # (precision "ref" holds the normed state as operand pairs: hand out the f32 values they stand for)
-            hidden_states = ((ops.unsplit(hn) if ops.SP() == 2 else hn.clone()).view(bs, -1, self.llm.T),)
+            hidden_states = tuple(states or ()) + ((ops.unsplit(hn) if ops.SP() == 2 else hn.clone()).view(bs, -1, self.llm.T),)
         if not use_cache and past_key_values is None:
             cache = None  # HF returns past_key_values=None without use_cache; the scratch KV buffer is recycled
         if not return_dict:

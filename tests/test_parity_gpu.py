@@ -119,6 +119,35 @@ def test_full_forward_chained(setup):
     assert util.relerr(pkv[0][0], ref["past"][0][0]) < 2e-2 and util.relerr(pkv[0][1], ref["past"][0][1]) < 2e-2
 
 
+def test_all_hidden_states_tuple_matches_reference_packaging(setup):
+    """output_hidden_states=True with model.all_hidden_states: the reference's tuple (R: groma/model/groma.py:389-397,421-427 =
+    HF LlamaModel all_hidden_states): the embeddings, the residual stream after layers 1..n-1, and the final NORMED state --
+    n + 1 entries of [bs, L, T]; by default only the last entry is produced (no reference caller reads the others)."""
+    cfg, sd, tk, model, images, ids = setup
+    n = cfg.llm_cfg.num_hidden_layers
+    model.all_hidden_states, model.capture_embeds = True, True
+    try:
+        torch.manual_seed(77)
+        out = model.forward(input_ids=ids.clone(), images=images, return_dict=True, output_hidden_states=True)
+        emb = model._last_aux["inputs_embeds"].cpu()
+        L = emb.shape[1]
+    finally:
+        model.all_hidden_states, model.capture_embeds = False, False
+    hs = out.hidden_states[0]
+    assert len(hs) == n + 1 and all(tuple(h.shape) == (2, L, cfg.llm_cfg.hidden_size) for h in hs)
+    assert torch.equal(hs[0].cpu(), emb)                     # entry 0 = the (injected) input embeddings, bit for bit
+    per_layer = {}
+    mask = (model._last_aux["input_ids"] != tk.pad_token_id).float()
+    with torch.no_grad():
+        final, _ = O.llama_forward(sd, cfg.to_dict(), emb, mask, layer_hook=lambda i, h: per_layer.__setitem__(i, h.clone()))
+    for i in range(1, n):
+        assert util.relerr(hs[i], per_layer[i - 1]) < 2e-2, i   # residual stream after layer i (bf16 operands, chained)
+    assert util.relerr(hs[n], final) < 2e-2
+    torch.manual_seed(77)
+    dflt = model.forward(input_ids=ids.clone(), images=images, return_dict=True, output_hidden_states=True)
+    assert len(dflt.hidden_states[0]) == 1 and torch.equal(dflt.hidden_states[0][0], hs[n])   # eager == graph-replayed, same bits
+
+
 def test_forward_with_refer_and_ground_boxes(setup):
     """<refer_box>/<ground_box>/<refer_feat> rewriting (groma.py:283-309, a13) + ragged region counts + padding."""
     cfg, sd, tk, model, images, ids = setup
