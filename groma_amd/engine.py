@@ -409,9 +409,24 @@ class RegionEngine:
         self.img = cfg.image_size
         if self.rc.num_levels != 3:
             raise NotImplementedError("3 pyramid levels (reference: MLVLROIQueryModule(num_levels=3))")
+        self.graphs = GraphPool(cap=4)
 
     def fuse(self, hidden3):
-        """MLVLFuseModule: 3 ViT hidden states -> 3 NHWC bf16 maps [bs,S,S,D], S = 4G, 2G, G."""
+        """MLVLFuseModule: 3 ViT hidden states -> 3 NHWC bf16 maps [bs,S,S,D], S = 4G, 2G, G.
+        The ~100 launches of the pyramid (shape-static, no host value in any argument) are replayed from a captured hipGraph once a
+        batch shape repeats, like the ViT / LLaMA-prefill layers (GraphPool): the inputs are the ViT's arena views and the outputs
+        the `reg_feat*` arenas, whose addresses key the graph; everything allocated in between belongs to the graph's pool."""
+        ws, rc, D, G = self.ws, self.rc, self.D, self.G
+        bs = hidden3[0].shape[0]
+        S = [G * 4, G * 2, G]
+        feats = [ws.get(f"reg_feat{l}", h16(bs, S[l], S[l], D), H16()) for l in range(3)]
+        pads = [ws.get(f"reg_pad{l}", h16(bs, S[l] + 2, S[l] + 2, D), H16(), zero=True) for l in range(3)]
+        bufs = list(hidden3) + feats + pads + [ws.get(f"reg_in{l}", h16(bs * S[l] * S[l], D), H16()) for l in range(3)] + \
+            [ws.get(f"reg_conv{l}_{r}", h16(bs * S[l] * S[l], D), H16()) for l in range(3) for r in range(min(2, rc.num_fuse))]
+        self.graphs.run(("fuse", bs, ops._PLAN[0]) + tuple(t.data_ptr() for t in bufs), lambda: self._fuse_launch(hidden3))
+        return feats, S
+
+    def _fuse_launch(self, hidden3):
         w, ws, rc, D, G = self.w, self.ws, self.rc, self.D, self.G
         bs = hidden3[0].shape[0]
         S = [G * 4, G * 2, G]
@@ -442,7 +457,6 @@ class RegionEngine:
             if rc.num_fuse == 1:  # then maps[l] is the traced round-0 conv output: feat = ReLU(GN(conv))
                 _trace(f"reg.feat{l}", f)
             feats.append(f)
-        return feats, S
 
     def extract(self, feats, S, boxes, img_idx):
         """MlvlRoIExtractor: boxes f32 [R,4] normalised cxcywh (device), img_idx f32 [R] -> region tokens f32 [R, T]."""
