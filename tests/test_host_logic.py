@@ -259,21 +259,37 @@ def test_graph_pool_policy(monkeypatch):
         def __init__(self):
             self.fn = None
 
+        def capture_begin(self, capture_error_mode="global"):
+            assert capture_error_mode == "thread_local"   # a capture must not police other threads' streams
+            log.append("capture")
+
+        def capture_end(self):
+            pass
+
         def replay(self):
             log.append("replay")
             if self.fn is not None:
                 self.fn()
 
-    @contextlib.contextmanager
-    def fake_capture(g):
-        log.append("capture")
-        g.capturing = True
-        yield
-        g.capturing = False
+    class FakeStream:
+        device = "fake"
 
+        def __init__(self, device=None):
+            pass
+
+        def synchronize(self):
+            log_sync.append("stream")
+
+        def wait_stream(self, other):
+            pass
+
+    log_sync, reserved = [], [0]
     monkeypatch.setattr(torch.cuda, "CUDAGraph", FakeGraph)
-    monkeypatch.setattr(torch.cuda, "graph", fake_capture)
-    monkeypatch.setattr(torch.cuda, "synchronize", lambda *a, **k: None)
+    monkeypatch.setattr(torch.cuda, "Stream", FakeStream)
+    monkeypatch.setattr(torch.cuda, "current_stream", lambda *a, **k: FakeStream())
+    monkeypatch.setattr(torch.cuda, "stream", lambda s: contextlib.nullcontext())
+    monkeypatch.setattr(torch.cuda, "memory_reserved", lambda *a, **k: reserved[0])
+    monkeypatch.setattr(torch.cuda, "synchronize", lambda *a, **k: log_sync.append("device"))
     monkeypatch.setattr(torch.cuda, "is_current_stream_capturing", lambda: False)
     pool = engine.GraphPool(cap=2)
     runs = []
@@ -295,6 +311,7 @@ def test_graph_pool_policy(monkeypatch):
         run("a", mk("a"))
     # sightings 1, 2: eager; 3: captured (launch runs once under the fake capture) then replayed; 4, 5: replayed
     assert log == ["capture", "replay", "replay", "replay"] and pool.captures == 1 and pool.replays == 2
+    assert log_sync == ["stream"]                  # a capture waits for the caller's stream only, never for the whole device
     assert runs.count("a") == 2 + 1 + 2          # (the real capture records instead of running; the first replay of the fake is empty)
     for k in ("b", "c"):
         for _ in range(3):
@@ -315,6 +332,20 @@ def test_graph_pool_policy(monkeypatch):
     run("b", mk("b"))
     assert log == ["replay"]
     monkeypatch.setattr(engine, "TRACE", None)
+    # byte budget: what a capture reserved is measured around it; the least recently used graphs go when the total exceeds it
+    small = engine.GraphPool(cap=8, byte_budget=100)
+    for k, grow in (("x", 40), ("y", 40), ("z", 40)):
+        for i in range(3):
+            if i == 2:
+                orig = reserved[0]
+                monkeypatch.setattr(torch.cuda, "memory_reserved", lambda *a, _c=[0], _o=orig, _g=grow, **kw: (_c.__setitem__(0, _c[0] + 1), _o + (_g if _c[0] > 1 else 0))[1])
+            small.run(k, mk(k))
+        reserved[0] += grow
+        monkeypatch.setattr(torch.cuda, "memory_reserved", lambda *a, **k: reserved[0])
+    assert list(small._graphs) == ["y", "z"] and sum(small._bytes.values()) == 80
+    # warm(): capture at admission time, not on the third live request
+    small.warm("w", mk("w"))
+    assert "w" in small._graphs and small.captures == 4
     # a key is everything baked into the launches: cache_addresses() changes when a cache grows
     class C:
         pass
