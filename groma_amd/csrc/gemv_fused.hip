@@ -31,30 +31,6 @@
 #define GF_WG_PER_CU 2  // persistent workgroups per CU
 #endif
 
-// lane ^ OFF exchange inside the VALU (DPP quad / row permutes, permlane swaps across the 16- and 32-lane halves) instead of
-// __shfl_xor, which this compiler turns into ds_bpermute_b32 -- an LDS-crossbar round trip -- for every distance: the
-// reduce-scatter butterfly below is 63 exchanges per row group and wave.  Same values, same sums.
-template <int OFF>
-__device__ __forceinline__ float lane_xor(float v, int lane) {
-#ifdef GF_DPP_BUTTERFLY
-  auto dpp = [](float x, auto ctrl) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), decltype(ctrl)::value, 0xf, 0xf, true));
-  };
-  if constexpr (OFF == 1) return dpp(v, std::integral_constant<int, 0xB1>{});        // quad_perm [1,0,3,2]
-  else if constexpr (OFF == 2) return dpp(v, std::integral_constant<int, 0x4E>{});   // quad_perm [2,3,0,1]
-  else if constexpr (OFF == 4) return dpp(dpp(v, std::integral_constant<int, 0x141>{}), std::integral_constant<int, 0x1B>{});  // half mirror o quad reverse
-  else if constexpr (OFF == 8) return dpp(v, std::integral_constant<int, 0x128>{});  // row_ror 8
-  else {
-    float a, b;
-    if constexpr (OFF == 16) xswap16(v, a, b);
-    else xswap32(v, a, b);
-    return (lane & OFF) ? a : b;
-  }
-#else
-  return __shfl_xor(v, OFF, 64);
-#endif
-}
-
 struct GemvFArgs {
   const bf16_t* W;
   long ldw;
@@ -320,7 +296,7 @@ __global__ __launch_bounds__(256, (XG && MB == 8) ? 1 : 2) void gemv_fused_kerne
       for (int m = 0; m < MB; ++m) v[r * MB + m] = acc[r][m];
     if constexpr (NV <= 32) {
 #pragma unroll
-      for (int i = 0; i < NV; ++i) v[i] += lane_xor<32>(v[i], lane);
+      for (int i = 0; i < NV; ++i) v[i] += __shfl_xor(v[i], 32, 64);
     }
     constexpr int OFF0 = NV / 2 < 32 ? NV / 2 : 32;
     auto stage = [&](auto offc) {
@@ -331,7 +307,7 @@ __global__ __launch_bounds__(256, (XG && MB == 8) ? 1 : 2) void gemv_fused_kerne
         for (int i = 0; i < off; ++i) {
           const float keep = hi ? v[i + off] : v[i];
           const float send = hi ? v[i] : v[i + off];
-          v[i] = keep + lane_xor<off>(send, lane);
+          v[i] = keep + __shfl_xor(send, off, 64);
         }
       }
     };
