@@ -283,9 +283,9 @@ __global__ __launch_bounds__(256, (XG && MB == 8) ? 1 : 2) void gemv_fused_kerne
     }
     const int e_lo = r_lo, e_hi = r_hi;  // the finished group's rows (the epilogue's)
     const int nxt = grp + (int)gridDim.x;
-#ifdef GF_PREFETCH_GROUP  // (requesting the next group's first slices BEFORE the reduction keeps 64 more VGPRs live through the
-    if (nxt < ngroups) start_group(nxt);  //  butterfly and spilled; the co-resident workgroups cover the gap instead)
-#endif
+    // (the next group's first slices are requested AFTER the reduction: requesting them before it, and doing the 63 lane exchanges of
+    //  the butterfly with DPP / permlane swaps instead of ds_bpermute, were both built and measured 1.5 % SLOWER end to end --
+    //  profiles/r04_decode_ab_rejected.txt; the co-resident workgroup covers the gap)
 
     // ---- NV per-lane partials x 64 lanes -> lane l (mod NV) owns dot product (row l / MB, batch row l % MB): all-lanes adds
     // across the lane bits >= NV, then a reduce-scatter butterfly; fixed order
@@ -363,9 +363,7 @@ __global__ __launch_bounds__(256, (XG && MB == 8) ? 1 : 2) void gemv_fused_kerne
     }
     if (nxt >= ngroups) break;
     grp = nxt;
-#ifndef GF_PREFETCH_GROUP
     start_group(nxt);
-#endif
     __syncthreads();  // wave 0 has read red[] before the next group's partials overwrite it
   }
 }
