@@ -17,7 +17,10 @@
 #define DEC_SMAX 8192
 #define DEC_U 11  // chunks in flight per thread and round (K and V^T): 11 x 64 = 704 keys per round at hd 128; 12 spills
 
-template <int HD>
+// DS = blocks per (row, head[, key slice]) along the OUTPUT dims (round 4): every block computes all scores and the soft-max of its
+// keys, but only HD / DS rows of V^T.  At 4 rows x 32 heads that is 256 blocks on 256 CUs instead of 128, each streaming 224 KB
+// instead of 300 KB, and -- unlike key slices -- nothing to merge: a block writes its dims of the context directly.
+template <int HD, int DS>
 __global__ __launch_bounds__(1024) void decode_attention_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
                                                                const bf16_t* __restrict__ vt, bf16_t* __restrict__ out,
                                                                const int* __restrict__ kv_len, int H, int kv_stride,
@@ -42,9 +45,10 @@ __global__ __launch_bounds__(1024) void decode_attention_kernel(const bf16_t* __
   // DEC_U x 64 keys, for K and for V^T together): a decode block is a pure latency chain otherwise.
   constexpr int LPK = HD / 8;          // lanes per key (16 for hd 128, 8 for hd 64)
   constexpr int KPI = 1024 / LPK;      // keys per pass of the block
-  constexpr int TPD = 1024 / HD;       // threads per output dim (8 / 16)
+  constexpr int HDB = HD / DS;         // output dims of this block
+  constexpr int TPD = 1024 / HDB;      // threads per output dim (8 / 16; twice that with DS = 2)
   const int j = tid % LPK, g = tid / LPK;
-  const int d = tid / TPD, part = tid % TPD;
+  const int d = (int)blockIdx.z * HDB + tid / TPD, part = tid % TPD;
   const bf16_t* vrow = Vp + (long)d * kv_stride;
   const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
   float qf[8];
@@ -132,7 +136,7 @@ __global__ __launch_bounds__(1024) void decode_attention_kernel(const bf16_t* __
   // order while loading its operand (gemv_bf16.hip) -- kernel boundaries provide the visibility, no fences here
   float* wo = ws + ((long)bh * nsplit + z) * (HD + 2);
   if (part == 0) wo[d] = acc;
-  if (tid == 0) { wo[HD] = mx; wo[HD + 1] = denom; }
+  if (tid == 0 && blockIdx.z == 0) { wo[HD] = mx; wo[HD + 1] = denom; }
 }
 
 extern "C" int gr_decode_attention(const void* q, const void* k, const void* vt, void* out, const int* kv_len, int B, int H,
@@ -143,15 +147,18 @@ extern "C" int gr_decode_attention(const void* q, const void* k, const void* vt,
   if (nsplit < 1 || nsplit > 16 || (nsplit > 1 && !parts)) return GR_EINVAL;
   if (kv_stride % 64 != 0 || kv_stride < Smax || (!pos_dev && q_pos0 + 1 > Smax)) return GR_EINVAL;
   const size_t lds = (size_t)((Smax + 63) & ~63) * sizeof(float);
-  if (head_dim == 128)
-    hipLaunchKernelGGL(decode_attention_kernel<128>, dim3(B * H, nsplit), dim3(1024), lds, stream, (const bf16_t*)q,
-                       (const bf16_t*)k, (const bf16_t*)vt, (bf16_t*)out, kv_len, H, kv_stride, q_pos0, scale, pos_dev,
-                       pos_stride, parts);
-  else if (head_dim == 64)
-    hipLaunchKernelGGL(decode_attention_kernel<64>, dim3(B * H, nsplit), dim3(1024), lds, stream, (const bf16_t*)q,
-                       (const bf16_t*)k, (const bf16_t*)vt, (bf16_t*)out, kv_len, H, kv_stride, q_pos0, scale, pos_dev,
-                       pos_stride, parts);
+#ifndef DA_DSPLIT_MAX_BLOCKS
+#define DA_DSPLIT_MAX_BLOCKS 128
+#endif
+  const int ds = B * H * nsplit <= DA_DSPLIT_MAX_BLOCKS ? 2 : 1;  // fewer blocks than half the CUs: two per (row, head) along the output dims
+#define LAUNCH_DA(HDV, DSV)                                                                                                    \
+  hipLaunchKernelGGL((decode_attention_kernel<HDV, DSV>), dim3(B * H, nsplit, DSV), dim3(1024), lds, stream, (const bf16_t*)q, \
+                     (const bf16_t*)k, (const bf16_t*)vt, (bf16_t*)out, kv_len, H, kv_stride, q_pos0, scale, pos_dev,         \
+                     pos_stride, parts)
+  if (head_dim == 128) { if (ds == 2) LAUNCH_DA(128, 2); else LAUNCH_DA(128, 1); }
+  else if (head_dim == 64) { if (ds == 2) LAUNCH_DA(64, 2); else LAUNCH_DA(64, 1); }
   else return GR_EINVAL;
+#undef LAUNCH_DA
   GR_CHECK_LAUNCH();
   return GR_OK;
 }
