@@ -355,3 +355,95 @@ def test_graph_pool_policy(monkeypatch):
     assert engine.cache_addresses(c) is a0
     c._addr, c.smax = None, 128
     assert engine.cache_addresses(c) != a0
+
+
+# ---------------------------------------------------------------------------------------- round 4: host logic of the new pieces
+def test_split_pack_layout_matches_the_kernel_side_index_map():
+    """ops.split_pack = the storage of libgroma_hip_ref.so (csrc/gr_common.h: sp_idx): logical element i sits at physical
+    (i / 32) * 64 + i % 32 (hi) and 32 further (lo); hi = f16(x), lo = f16(x - hi); unsplit is exact in fp32"""
+    from groma_amd import ops
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(3, 5, 96, generator=g) * 11
+    s = ops.split_pack(x)
+    assert s.dtype == torch.float16 and tuple(s.shape) == (3, 5, 192)
+    flat, sf = x.reshape(-1), s.reshape(-1)
+    for i in (0, 31, 32, 45, 95, 96, 96 * 7 + 33, flat.numel() - 1):     # the map is a function of the FLAT index (rows are multiples of 32)
+        p = (i // 32) * 64 + i % 32
+        hi = flat[i].to(torch.float16)
+        assert sf[p] == hi and sf[p + 32] == (flat[i] - hi.float()).to(torch.float16)
+    back = ops.unsplit(s)
+    assert (back - x).abs().max().item() <= 2.0 ** -21 * x.abs().max().item()
+    assert torch.equal(ops.unsplit(ops.split_pack(back)), back)           # a pair is a fixed point
+    import pytest
+    with pytest.raises(ValueError):
+        ops.split_pack(torch.zeros(4, 40))                                  # rows must be whole 32-element blocks
+    big = torch.tensor([[1e6] + [0.0] * 31])
+    assert torch.isfinite(ops.split_pack(big)).all()                        # saturates like the device-side conversions, never inf
+    with ops.precision("fp16"):
+        assert torch.isfinite(ops.to_h16(big)).all() and float(ops.to_h16(big)[0, 0]) == 65504.0
+    with ops.precision("ref"):
+        assert ops.SP() == 2 and ops.H16() == torch.float16 and tuple(ops.to_h16(x).shape) == (3, 5, 192)
+    assert ops.SP() == 1 and ops.H16() == torch.bfloat16
+
+
+def test_precision_and_plan_switches_are_per_thread():
+    """two models of different precision / plan served from two threads must not see each other's switch"""
+    import threading
+    from groma_amd import ops
+    seen, go, done = {}, threading.Event(), threading.Event()
+
+    def worker():
+        with ops.precision("ref"), ops.gemm_plan("latency"):
+            seen["inside"] = (ops.SP(), ops.plan_splits(4096, 4096))
+            go.set()
+            done.wait(5)
+        seen["after"] = (ops.SP(), ops.plan_splits(4096, 4096))
+    t = threading.Thread(target=worker)
+    t.start()
+    assert go.wait(5)
+    assert ops.SP() == 1 and ops.plan_splits(4096, 4096) == 1       # this thread still sees the defaults while the other is inside
+    done.set()
+    t.join()
+    assert seen["inside"] == (2, 3) and seen["after"] == (1, 1)
+
+
+def test_plan_workspace_sizes():
+    from groma_amd import ops
+    shapes = [(12288, 4096), (4096, 4096), (22016, 4096), (4096, 11008)]
+    assert ops.plan_ws_elems(582, shapes) == 0                                        # throughput plan: nothing is split
+    need = ops.plan_ws_elems(582, shapes, "latency")
+    assert need == max(ops.plan_splits(N, K, "latency") * 582 * N for N, K in shapes if ops.plan_splits(N, K, "latency") > 1) > 0
+
+
+def test_gemv_desc_mirrors_the_header(tmp_path):
+    """ctypes GemvDesc / GemmDesc == gr_gemv_desc / gr_gemm_desc of include/groma_hip.h as gcc lays them out"""
+    import ctypes, os, subprocess
+    from groma_amd import _lib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / "sz.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "%s"\nint main(){printf("%%zu %%zu %%zu %%zu %%zu %%zu\\n", sizeof(gr_gemv_desc), '
+                   'offsetof(gr_gemv_desc, epi), offsetof(gr_gemv_desc, q), offsetof(gr_gemv_desc, pos_dev), sizeof(gr_gemm_desc), '
+                   'offsetof(gr_gemm_desc, a_parts));return 0;}\n' % os.path.join(root, "include", "groma_hip.h"))
+    exe = tmp_path / "sz"
+    subprocess.run(["gcc", str(src), "-o", str(exe)], check=True)
+    got = [int(x) for x in subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split()]
+    D, G = _lib.GemvDesc, _lib.GemmDesc
+    assert got == [ctypes.sizeof(D), D.epi.offset, D.q.offset, D.pos_dev.offset, ctypes.sizeof(G), G.a_parts.offset]
+
+
+def test_bench_pins_host_threads_per_rank():
+    import importlib.util, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(root, "bench.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    before_aff, before_thr = os.sched_getaffinity(0), torch.get_num_threads()
+    try:
+        assert b.pin_host_threads(0, 1) == before_thr and os.sched_getaffinity(0) == before_aff     # N = 1: untouched
+        n = b.pin_host_threads(1, 2)
+        mine = os.sched_getaffinity(0)
+        cores = sorted(before_aff)
+        assert mine == set(cores[len(cores) // 2: 2 * (len(cores) // 2)]) and n == min(len(mine), 16)
+    finally:
+        os.sched_setaffinity(0, before_aff)
+        torch.set_num_threads(before_thr)
