@@ -38,3 +38,25 @@ def run_smoke():
     assert err < 1e-2, f"logits relative error {err}"
     print(f"smoke ok (Groma-7B width, reduced depth): logits {tuple(a.shape)} rel-L2 vs fp32 oracle {err:.2e}, "
           f"N={ref['pred_boxes'][0].shape[0]} regions, L={ref['input_ids'].shape[1]}")
+    # the same invocation through the reference-precision build (operand pairs, libgroma_hip_ref.so), compared UNCHAINED: the oracle
+    # runs its own fp32 ViT, as the reference computes the path in one pass (R: groma/model/groma.py:222-280,389-402)
+    del model, out
+    torch.cuda.empty_cache()
+    mref = GromaModel.from_state_dict(cfg, sd, "cuda:0", precision="ref")
+    mref.init_special_token_id(tk)
+    torch.manual_seed(3)
+    out = mref.forward(input_ids=ids.clone(), images=images, return_dict=True)
+    torch.cuda.synchronize()
+    torch.manual_seed(3)
+    with torch.no_grad():
+        ref = O.groma_forward(sd, cfg.to_dict(), tok, ids.clone(), images)
+    aux = mref._last_aux
+    a, b = out.logits.float().cpu(), ref["logits"]
+    same_shape = a.shape == b.shape
+    err = ((a - b).norm() / b.norm()).item() if same_shape else float("inf")
+    topk_eq = torch.equal(aux["topk_idx"].cpu().long(), ref["det"]["topk_idx"])
+    nms_eq = torch.equal(aux["nms_keep"][0], ref["nms_inds"][0])
+    ids_eq = torch.equal(aux["input_ids"], ref["input_ids"])
+    assert ids_eq and same_shape and err < 1e-3, f"precision='ref' unchained: spliced ids equal {ids_eq}, logits relative error {err}"
+    print(f"smoke ok (precision='ref', oracle UNCHAINED = its own fp32 ViT): logits rel-L2 {err:.2e} (north star 1e-3), top-300 ids equal "
+          f"{topk_eq}, NMS ids equal {nms_eq}, spliced ids equal {ids_eq}")
