@@ -133,7 +133,7 @@ def cpu_baseline(cfg_name, threads=None, full_reps=1):
                       f"(vit {t_vit * nv:.2f}, ddetr {t_det:.2f}, region {t_fuse * nf + t_roi:.2f}, llm {t_llm * nl + t_head:.2f})"}
 
 
-def measure_traffic(batch, kernel="gemm_bf16_256_kernel"):
+def measure_traffic(batch, kernel="gemm_bf16_256_kernel", extra=()):
     """HBM-side traffic of the dominant kernel, measured NOW: two separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE --
     they do not fit one pass on gfx950) of `bench.py --steps 1 --warmup 1 --batch B` as child processes, exactly the recipe of
     MI355X_MICROARCH.md (cwd /tmp, TMPDIR=/tmp, counters with --kernel-trace only).  Returns bytes per launch with the guide's
@@ -153,7 +153,7 @@ def measure_traffic(batch, kernel="gemm_bf16_256_kernel"):
             out = os.path.join(tmp, ctr)
             cmd = ["rocprofv3", "--pmc", ctr, "--kernel-trace", "--output-format", "csv", "-d", out, "--", sys.executable,
                    os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "1", "--batch", str(batch), "--no-cpu-baseline",
-                   "--no-traffic", "--no-extras"]
+                   "--no-traffic", "--no-extras"] + list(extra)
             subprocess.run(cmd, cwd="/tmp", env=env, timeout=420, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=True)
             tot, n = 0.0, 0
             for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
@@ -558,7 +558,7 @@ def main():
             a[0] += 1
             a[1] += ms
         with open(args.gemm_breakdown, "w") as f:
-            f.write("M N K tag(1=conv,2=splitK,4=256x256 kernel,8=decode kernel) calls_per_step avg_us TFLOPs share_of_gemm_time\n")
+            f.write("M N K tag(1=conv,2=splitK,4=ping-pong kernel,8=decode-step weight stream,16=e4m3,32=fused stream kernel) calls_per_step avg_us TFLOPs share_of_gemm_time\n")
             tot = sum(v[1] for v in agg.values())
             for (M_, N_, K_, tag), (c, ms) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
                 f.write(f"{M_} {N_} {K_} {tag} {c / args.steps:.1f} {ms / c * 1e3:.1f} "
@@ -636,8 +636,14 @@ def main():
                                      "random-init weights, no EOS" % args.new_tokens)
         out["config"]["new_tokens"] = args.new_tokens
         ach = gv_bytes / (gv_ms * 1e-3) / 1e9 if gv_ms > 0 else 0.0
-        out["roofline"] = {"bound": "hbm", "kernel": "gemv_bf16_kernel<M>(GemmArgs) -- decode-step weight streaming",
-                           "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0, "traffic": None,
+        gv_traffic = None
+        if rank == 0 and world == 1 and not args.no_traffic and args.config == "7b" and not fp8:
+            # FETCH_SIZE / WRITE_SIZE of the fused weight-streaming kernel, per launch, from two rocprofv3 --pmc child runs of this
+            # command (the decode steps are graph replays there; the counters see the same kernels)
+            gv_traffic = measure_traffic(args.batch, "gemv_fused_kernel", ["--mode", "generate", "--new-tokens", str(args.new_tokens)])
+        out["roofline"] = {"bound": "hbm", "kernel": "gemv_fused_kernel<MB, XG>(GemvFArgs) -- decode-step weight streaming, one launch per weight matrix",
+                           "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0, "traffic": gv_traffic,
+                           "traffic_note": "bytes/launch at the L2<->fabric boundary (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, gfx950 correction), averaged over the fused-stream launches; algorithmic = bytes_per_launch" if gv_traffic else None,
                            "launches_per_step": len(gv) / max(args.steps, 1),
                            "avg_launch_us": gv_ms * 1e3 / max(len(gv), 1),
                            "bytes_per_launch": gv_bytes / max(len(gv), 1),

@@ -208,6 +208,22 @@ static bool g_prof_on = false;
 struct ProfRec { hipEvent_t a, b; double flops; int M, N, K, tag; };
 static std::vector<ProfRec> g_prof;
 
+// the same hook for launches that do not go through gr_gemm_bf16 (gemv_fused.hip): returns a record index or -1 when the hook is off
+int gr_prof_begin(hipStream_t stream, int M, int N, int K, int tag) {
+  if (!g_prof_on) return -1;
+  ProfRec rec;
+  (void)hipEventCreate(&rec.a);
+  (void)hipEventCreate(&rec.b);
+  rec.flops = 2.0 * M * (double)N * K;
+  rec.M = M; rec.N = N; rec.K = K; rec.tag = tag;
+  (void)hipEventRecord(rec.a, stream);
+  g_prof.push_back(rec);
+  return (int)g_prof.size() - 1;
+}
+void gr_prof_end(hipStream_t stream, int idx) {
+  if (idx >= 0 && idx < (int)g_prof.size()) (void)hipEventRecord(g_prof[idx].b, stream);
+}
+
 extern "C" int gr_abi_version(void) { return GROMA_HIP_ABI_VERSION; }
 #if GR_SP
 extern "C" int gr_operand_type(void) { return GR_OPERAND_SPLIT; }

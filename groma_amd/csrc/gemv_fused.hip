@@ -368,6 +368,10 @@ __global__ __launch_bounds__(256, (XG && MB == 8) ? 1 : 2) void gemv_fused_kerne
   }
 }
 
+// bench.py's HIP-event hook (gemm_bf16.hip): tag 8 = decode-step weight stream, 32 = the fused kernel
+int gr_prof_begin(hipStream_t stream, int M, int N, int K, int tag);
+void gr_prof_end(hipStream_t stream, int idx);
+
 extern "C" int gr_gemv_fused(const gr_gemv_desc* d, hipStream_t stream) {
   if (GR_SP) return GR_EINVAL;  // no split-operand form: a decode step of the reference-precision build runs the general kernels
   if (!d || !d->W || d->M <= 0 || d->M > 8 || d->N <= 0 || d->K <= 0 || d->K % 64 != 0 || d->ldw < d->K) return GR_EINVAL;
@@ -410,6 +414,7 @@ extern "C" int gr_gemv_fused(const gr_gemv_desc* d, hipStream_t stream) {
   }
   const int groups = gr_cdiv(d->N, ROWS);
   const dim3 grid(groups < GF_WG_PER_CU * n_cu ? groups : GF_WG_PER_CU * n_cu);  // persistent over row groups
+  const int prof = gr_prof_begin(stream, d->M, d->N, d->K, 8 | 32);
   if (d->x_mode == 0) {
     if (MB == 4) hipLaunchKernelGGL((gemv_fused_kernel<4, true>), grid, dim3(256), 0, stream, p);
     else hipLaunchKernelGGL((gemv_fused_kernel<8, true>), grid, dim3(256), 0, stream, p);
@@ -417,6 +422,7 @@ extern "C" int gr_gemv_fused(const gr_gemv_desc* d, hipStream_t stream) {
     if (MB == 4) hipLaunchKernelGGL((gemv_fused_kernel<4, false>), grid, dim3(256), lds, stream, p);
     else hipLaunchKernelGGL((gemv_fused_kernel<8, false>), grid, dim3(256), lds, stream, p);
   }
+  gr_prof_end(stream, prof);
   GR_CHECK_LAUNCH();
   return GR_OK;
 }
