@@ -334,7 +334,7 @@ def launch_roofline(m, step, n, kind):
         ms = sum(r[4] for r in gv)
         nbytes = sum(2.0 * r[1] * r[2] for r in gv)
         ach = nbytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
-        return {"bound": "hbm", "kernel": "gemv_bf16_kernel<M>(GemmArgs) -- decode-step weight streaming", "achieved": ach, "peak": 8000.0,
+        return {"bound": "hbm", "kernel": "gemv_fused_kernel<MB, XG>(GemvFArgs) -- decode-step weight streaming, one launch per weight matrix", "achieved": ach, "peak": 8000.0,
                 "unit": "GB/s", "frac": ach / 8000.0, "traffic": None, "launches_per_step": len(gv) / n,
                 "avg_launch_us": ms * 1e3 / max(len(gv), 1), "bytes_per_launch": nbytes / max(len(gv), 1)}
     fp8 = bool(m.fp8)

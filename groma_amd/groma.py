@@ -326,6 +326,30 @@ class GromaModel:
             t = pool[name] = torch.empty((max(n, 1024),), dtype=I64).pin_memory()
         return t
 
+    def _ids_to_host_async(self, input_ids):
+        """Start the D2H copy of the caller's device-resident prompt ids on a copy stream of our own, into pinned memory; returns a
+        callable that waits for it and hands out the host tensor (None for ids that already live on the host).  The forward needs
+        the ids on the host right after the NMS sync; fetched there, `input_ids.cpu()` was a second synchronous round trip inside
+        the one window in which the GPU sits idle (profiles/r04_timeline_b14.txt: 0.6 ms between the two copies)."""
+        if not input_ids.is_cuda or input_ids.dtype != I64:
+            return None
+        cp = self.__dict__.get("_copy_stream")
+        if cp is None:
+            cp = self._copy_stream = torch.cuda.Stream(device=self.device)
+        cur = torch.cuda.current_stream()
+        host = self._pinned("ids_in", input_ids.numel())[: input_ids.numel()].view(input_ids.shape)  # (reused page-locked buffer)
+        cp.wait_stream(cur)        # (whoever produced the ids did so on the caller's stream)
+        with torch.cuda.stream(cp):
+            host.copy_(input_ids, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(cp)
+        input_ids.record_stream(cp)
+
+        def wait():
+            ev.synchronize()
+            return host
+        return wait
+
     def _propose_graph(self, hidden4):
         """Replay (capturing on first use) the hipGraph of the proposer chain + NMS for these input buffers.  The graph
         reads the ViT states in place (workspace arenas: stable addresses) and owns its outputs; thresholds are baked in, so
@@ -388,6 +412,7 @@ class GromaModel:
         with ops.gemm_plan(self.gemm_plan):
             if past_key_values is None:
                 images = images.to(device=dev, dtype=F32).contiguous()
+                ids_early = self._ids_to_host_async(input_ids)  # the prompt ids are needed on the host after the NMS sync: fetch them now
                 hidden4 = self.vit.forward(images)
                 # Two HIP streams: the region-encoder pyramid (5 rounds of MFMA-bound 3x3 convs) and the bridge MLP only
                 # need the ViT states, so they run beside the launch-latency-bound fp32 proposer + NMS + host sync.
@@ -404,24 +429,28 @@ class GromaModel:
                 selected_boxes, aux = self.propose(hidden4, refer_boxes, ground_boxes, seeds=_seeds)
                 main.wait_stream(side)
                 bs = len(selected_boxes)
-                ids_h = input_ids.cpu()
+                ids_h = ids_early() if ids_early is not None else input_ids.cpu()
                 writeback = input_ids.is_cuda
                 if not input_ids.is_cuda and input_ids.is_inference():  # a CPU tensor the caller made under inference mode:
                     ids_h, writeback = ids_h.clone(), True              # edit a copy, write it back under that mode
                 # replace <refer_box>/<ground_box> placeholders by matched <r_k> ids (groma.py:283-309), in place
                 refer_box_inds = []
-                need_boxes = any((self.refer_box_token_id in ids_h[i]) or (self.ground_box_token_id in ids_h[i]) for i in range(bs))
+                # (one vectorised membership test per placeholder kind instead of 2 x bs tensor `in` checks: this code sits between
+                #  the NMS host sync and the first region-extraction launch, where the GPU has nothing queued)
+                has_ref = (ids_h == self.refer_box_token_id).any(dim=1).tolist()
+                has_gnd = (ids_h == self.ground_box_token_id).any(dim=1).tolist()
+                need_boxes = any(has_ref) or any(has_gnd)
                 sel_h = [b.cpu() for b in selected_boxes] if need_boxes else None
                 box_ids = torch.tensor(self.box_idx_token_ids)
                 for i in range(bs):
-                    if self.refer_box_token_id in ids_h[i]:
+                    if has_ref[i]:
                         ious = _box_iou(_c2c(refer_boxes[i].cpu().float()), _c2c(sel_h[i]))
                         matched = torch.max(ious, dim=-1).indices
                         refer_box_inds.append(matched)
                         ids_h[i].masked_scatter_(ids_h[i] == self.refer_box_token_id, box_ids[matched])
                     else:
                         refer_box_inds.append([])
-                    if self.ground_box_token_id in ids_h[i]:
+                    if has_gnd[i]:
                         ious = _box_iou(_c2c(ground_boxes[i].cpu().float()), _c2c(sel_h[i]))
                         matched = torch.max(ious, dim=-1).indices
                         mask = ids_h[i] == self.ground_box_token_id
