@@ -281,12 +281,27 @@ class GromaModel:
                 n_valid = torch.tensor([Q + e for e in n_extra], dtype=I32, device=dev)
             keep, n_keep = ops.nms(boxes_all, scores_all, float(cfg.nms_thres), float(cfg.box_score_thres),
                                    int(cfg.max_region_num), n_valid=n_valid)
+        nmax = boxes_all.shape[1]
+        # Speculation (round 4): the host work between the NMS result and the first region-extraction launch is GPU-idle time
+        # (profiles/r04_timeline_b14.txt: 1.3 ms).  The usual outcome is that every image keeps max_region_num boxes, and then the
+        # CPU-RNG shuffles (T4) need no device value at all: draw them NOW, while the proposer is still running, upload them and
+        # queue the two device gathers behind the NMS kernel; after the sync only the counts are checked.  If any image kept fewer
+        # boxes the global RNG is put back exactly where it was and the ordinary path below runs -- same draws, same results.
+        spec = self._speculate_shuffle(keep, boxes_all, bs, nmax, seeds) if max(n_extra) == 0 else None
         # ONE host round trip: kept indices + counts in one D2H copy (the reference syncs at nms / len / randperm too), the
         # CPU-RNG shuffles (T4), then ONE pinned H2D copy of the flat selection and ONE device gather -- the per-image
         # index_select / .to(device) sequence this replaces cost ~1.2 ms of idle GPU per forward in pageable synchronous copies
         kk_h = torch.cat([keep, n_keep.to(I64)[:, None]], dim=1).cpu()
         keep_h, n_keep_l = kk_h[:, :-1], kk_h[:, -1].tolist()
-        nmax = boxes_all.shape[1]
+        if spec is not None:
+            if all(int(nk) == spec["n"] for nk in n_keep_l):
+                sel = keep_h.gather(1, spec["perms"])                      # [bs, n]: what keep_h[i].index_select(0, perm_i) gives
+                sel_idx = list(sel.unbind(0))
+                aux = dict(pred_boxes=pred_boxes, scores=scores, topk_idx=topk_idx, nms_keep=list(keep_h[:, : spec["n"]].unbind(0)),
+                           sel_idx=sel_idx, boxes_cat=spec["boxes_cat"], img_idx=spec["img_idx"])
+                return list(spec["boxes_cat"].split([spec["n"]] * bs)), aux
+            if spec["rng"] is not None:
+                torch.set_rng_state(spec["rng"])   # mis-speculated: nothing was consumed as far as the ordinary path can tell
         sel_idx = []
         for i, nk in enumerate(n_keep_l):   # (a handful of host ops per image: this loop sits between the sync and the next launch)
             if nk > 0:  # groma.py:273-276 -- torch.randperm on the CPU global RNG (T4)
@@ -315,6 +330,27 @@ class GromaModel:
         aux = dict(pred_boxes=pred_boxes, scores=scores, topk_idx=topk_idx, nms_keep=[keep_h[i, :int(n_keep_h[i])] for i in range(bs)],
                    sel_idx=sel_idx, boxes_cat=boxes_cat, img_idx=sel_dev[R:].to(F32))
         return selected, aux
+
+    def _speculate_shuffle(self, keep, boxes_all, bs, nmax, seeds):
+        """see propose(): per-image torch.randperm(max_region_num) drawn before the NMS result is known, uploaded, and the
+        selection gathered on the device; returns None when speculation is pointless (fewer candidates than max_region_num)"""
+        n = int(self.config.max_region_num)
+        if n <= 0 or n > nmax or keep.shape[1] != n:
+            return None
+        dev = self.device
+        rng = torch.get_rng_state() if (seeds is None or any(s is None for s in seeds)) else None
+        perms = torch.stack([torch.randperm(n, generator=torch.Generator().manual_seed(int(seeds[i])))
+                             if (seeds is not None and seeds[i] is not None) else torch.randperm(n) for i in range(bs)])   # image order (T4)
+        R = bs * n
+        stage = self._pinned("spec", 2 * R)
+        img_of = torch.arange(bs).repeat_interleave(n)
+        torch.add(perms.reshape(-1), img_of, alpha=n, out=stage[:R])      # position of the j-th selected entry inside keep [bs, n]
+        stage[R:2 * R] = img_of
+        sd = stage[:2 * R].to(dev, non_blocking=True)
+        picked = keep.reshape(-1).index_select(0, sd[:R]).clamp_(min=0)   # (-1 padding if an image kept fewer: discarded then, never an OOB read)
+        flat = picked + sd[R:] * nmax
+        boxes_cat = boxes_all.reshape(bs * nmax, 4).index_select(0, flat)  # [R, 4], image-major
+        return dict(n=n, perms=perms, rng=rng, boxes_cat=boxes_cat, img_idx=sd[R:].to(F32))
 
     def _pinned(self, name, n):
         """a reusable page-locked int64 staging buffer (H2D copies from it are asynchronous on the stream).  One buffer per
@@ -429,6 +465,9 @@ class GromaModel:
                 selected_boxes, aux = self.propose(hidden4, refer_boxes, ground_boxes, seeds=_seeds)
                 main.wait_stream(side)
                 bs = len(selected_boxes)
+                # region tokens (groma.py:312-315): launched FIRST -- nothing below changes its inputs, and every host op placed
+                # between the NMS sync and this launch is GPU-idle time
+                region_features = self.region.extract(feats, S, aux["boxes_cat"], aux["img_idx"])  # f32 [R, T]
                 ids_h = ids_early() if ids_early is not None else input_ids.cpu()
                 writeback = input_ids.is_cuda
                 if not input_ids.is_cuda and input_ids.is_inference():  # a CPU tensor the caller made under inference mode:
@@ -461,9 +500,7 @@ class GromaModel:
                 assert len(refer_box_inds) == bs
                 if writeback and need_boxes:
                     engine.inplace_copy(input_ids, ids_h)  # the reference mutates the caller's input_ids (groma.py:295,307)
-                # region tokens (groma.py:312-315)
                 n_reg = [b.shape[0] for b in selected_boxes]
-                region_features = self.region.extract(feats, S, aux["boxes_cat"], aux["img_idx"])  # f32 [R, T]
                 n_img_tok = (self.vit.G // 2) ** 2  # image tokens: groma.py:224-237, :361 (computed on the side stream)
                 # splice placeholders, embed, inject (groma.py:317-369)
                 new_ids_h, mask_h = self._splice(ids_h, n_img_tok, n_reg)

@@ -148,6 +148,37 @@ def test_all_hidden_states_tuple_matches_reference_packaging(setup):
     assert len(dflt.hidden_states[0]) == 1 and torch.equal(dflt.hidden_states[0][0], hs[n])   # eager == graph-replayed, same bits
 
 
+def test_speculative_shuffle_is_invisible(setup, monkeypatch):
+    """propose() draws the per-image torch.randperm (T4) BEFORE the NMS result is on the host, assuming every image keeps
+    max_region_num boxes, and falls back -- global RNG restored -- when one keeps fewer.  Hit or miss, the selection, the logits and
+    the state the CPU RNG is left in must be exactly what the unspeculated path produces."""
+    cfg, sd, tk, model, images, ids = setup
+    from groma_amd.groma import GromaModel
+
+    def run(spec, thres):
+        old = model.config.box_score_thres
+        model.config.box_score_thres = thres
+        if not spec:
+            monkeypatch.setattr(GromaModel, "_speculate_shuffle", lambda self, *a, **k: None)
+        try:
+            torch.manual_seed(123)
+            out = model.forward(input_ids=ids.clone(), images=images, return_dict=True)
+            return out.logits.clone(), [x.clone() for x in model._last_aux["sel_idx"]], torch.get_rng_state().clone()
+        finally:
+            model.config.box_score_thres = old
+            monkeypatch.undo()
+    # hit: threshold 0 -> 100 boxes per image
+    a, b = run(True, 0.0), run(False, 0.0)
+    assert all(len(x) == 100 for x in a[1])
+    assert torch.equal(a[0], b[0]) and all(torch.equal(x, y) for x, y in zip(a[1], b[1])) and torch.equal(a[2], b[2])
+    # miss: a threshold at the median fused score of image 0 leaves it with fewer than 100 boxes
+    thr = float(model._last_aux["scores"][0].median())
+    a, b = run(True, thr), run(False, thr)
+    assert min(len(x) for x in a[1]) < 100, [len(x) for x in a[1]]
+    assert a[0].shape == b[0].shape and torch.equal(a[0], b[0]) and all(torch.equal(x, y) for x, y in zip(a[1], b[1]))
+    assert torch.equal(a[2], b[2])
+
+
 def test_forward_with_refer_and_ground_boxes(setup):
     """<refer_box>/<ground_box>/<refer_feat> rewriting (groma.py:283-309, a13) + ragged region counts + padding."""
     cfg, sd, tk, model, images, ids = setup
