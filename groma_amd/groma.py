@@ -291,7 +291,7 @@ class GromaModel:
         # ONE host round trip: kept indices + counts in one D2H copy (the reference syncs at nms / len / randperm too), the
         # CPU-RNG shuffles (T4), then ONE pinned H2D copy of the flat selection and ONE device gather -- the per-image
         # index_select / .to(device) sequence this replaces cost ~1.2 ms of idle GPU per forward in pageable synchronous copies
-        kk_h = torch.cat([keep, n_keep.to(I64)[:, None]], dim=1).cpu()
+        kk_h = torch.cat([keep, n_keep.to(I64)[:, None]], dim=1).cpu()   # (polling an event instead of this blocking copy measured no gain: profiles/r04_host_sync_ab.txt)
         keep_h, n_keep_l = kk_h[:, :-1], kk_h[:, -1].tolist()
         if spec is not None:
             if all(int(nk) == spec["n"] for nk in n_keep_l):

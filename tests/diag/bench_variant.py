@@ -7,6 +7,10 @@ args = sys.argv[2:]
 import groma_amd.engine as e
 while args and "=" in args[0] and not args[0].startswith("-"):
     name, val = args.pop(0).split("=")
-    setattr(e, name, bool(int(val)))
+    if name.startswith("groma."):   # e.g. groma.SPIN_SYNC=0
+        import groma_amd.groma as gm
+        setattr(gm, name[6:], bool(int(val)))
+    else:
+        setattr(e, name, bool(int(val)))
 sys.argv = [os.path.join(_variant.ROOT, "bench.py")] + args
 runpy.run_path(sys.argv[0], run_name="__main__")
