@@ -39,18 +39,27 @@ enum { HT_A0 = 0, HT_B0 = 1, HT_B1 = 2, HT_A1 = 3 };
 #ifndef G256_FP8
 #define G256_FP8 0
 #endif
+#ifndef G256_FP8_PERSIST
+#define G256_FP8_PERSIST 0
+#endif
 #if G256_FP8
 #define G256_KERNEL gemm_fp8_256_kernel
 #define G256_LAUNCH gr_launch_gemm256_fp8
 #define ESZ 1
-typedef union { bf16x8 v; long h[2]; } frag_u;
-__device__ __forceinline__ f32x4 mfma_fp8x2(bf16x8 a, bf16x8 b, f32x4 c) {
-  frag_u ua, ub;
-  ua.v = a; ub.v = b;
-  c = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(ua.h[0], ub.h[0], c, 0, 0, 0);
-  return __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(ua.h[1], ub.h[1], c, 0, 0, 0);
+// One v_mfma_scale_f32_16x16x128_f8f6f4 per (m-tile, n-tile) and K-tile: the lane's two 16-B chunks of the 128-B row (chunk fg
+// and chunk fg + 4) are the 32 k-values the instruction wants from it, A and B alike, so the fragments are used as they are
+// read.  Both formats e4m3 (cbsz = blgp = 0), both block scales the e8m0 code 127 = 2^0: a plain e4m3 x e4m3 -> f32 product
+// at the MX rate (8 passes for 128 k-values).  The unscaled v_mfma_f32_16x16x32_fp8_fp8 this replaces issues at the bf16
+// rate -- 4 of them, 64 clk, for the same 128 k-values (MI355X_MICROARCH.md: "non-scaled fp8 = bf16 rate; MX-scaled K = 128 is
+// the only path to the low-precision peak").
+typedef __attribute__((ext_vector_type(8))) int i32x8;
+typedef union { struct { bf16x8 c0, c1; } h; i32x8 v; } frag_mx;
+__device__ __forceinline__ f32x4 mfma_mx_e4m3(bf16x8 a0, bf16x8 a1, bf16x8 b0, bf16x8 b1, f32x4 c) {
+  frag_mx ua, ub;
+  ua.h.c0 = a0; ua.h.c1 = a1;
+  ub.h.c0 = b0; ub.h.c1 = b1;
+  return __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(ua.v, ub.v, c, 0, 0, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
 }
-#define MFMA16(a, b, c) mfma_fp8x2(a, b, c)
 #else
 #define G256_KERNEL gemm_bf16_256_kernel
 #define G256_LAUNCH gr_launch_gemm256
@@ -155,7 +164,7 @@ __global__ __launch_bounds__(NT) void G256_KERNEL(GemmArgs p) {
   // one tile's last store to the next tile's first DMA without a workgroup retire / dispatch in between: measured
   // 1093 -> 1079 us on the LLaMA gate-up shape, 610 -> 604 us on QKV (tests/diag/persist_ab.py), neutral on the ViT shapes.
   const int total_tiles = p.tiles_m * p.tiles_n;
-#if G256_FP8  // the e4m3 build has no register headroom for the tile loop (it spilled inside the K loop): one tile per block
+#if G256_FP8 && !G256_FP8_PERSIST  // e4m3 build: one tile per block (the tile loop measured neutral in round 3; -DG256_FP8_PERSIST=1 re-measures it)
   {
   const int vb = blockIdx.x;
 #else
@@ -302,7 +311,12 @@ __global__ __launch_bounds__(NT) void G256_KERNEL(GemmArgs p) {
 // The MFMAs of one phase.  Unsplit operands: both 32-deep k-steps of the K-tile, 32 MFMAs.  Split operands (GR_SPLIT, the
 // reference-precision build): the K-tile's first k-step holds the hi halves of 32 logical k-values and the second their lo
 // halves (gr_common.h), and the phase issues hi.hi, hi(A).lo(W) and lo(A).hi(W): 48 MFMAs on the same fragments.
-#if GR_SP && !G256_FP8
+#if G256_FP8
+#define PHASE_MFMAS(I0)                                                                                   \
+  _Pragma("unroll") for (int i = 0; i < MTX; ++i)                                                         \
+    _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                         \
+      acc[I0 + i][j] = mfma_mx_e4m3(bfr[j][0], bfr[j][1], af[i][0], af[i][1], acc[I0 + i][j]);
+#elif GR_SP
 #define PHASE_MFMAS(I0)                                                                                   \
   _Pragma("unroll") for (int pp = 0; pp < 3; ++pp)                                                        \
     _Pragma("unroll") for (int i = 0; i < MTX; ++i)                                                       \
@@ -431,7 +445,7 @@ int G256_LAUNCH(const GemmArgs& p, hipStream_t stream, int tile_rows) {  // tile
 #ifdef G256_NO_PERSIST  // diagnostic build (tests/diag/build_variant.py name -DG256_NO_PERSIST): one tile per workgroup
   const bool persist_off = true;
 #else
-  const bool persist_off = G256_FP8 != 0;
+  const bool persist_off = G256_FP8 != 0 && !G256_FP8_PERSIST;
 #endif
   const int tiles = p.tiles_m * p.tiles_n;
   dim3 grid(persist_off ? tiles : (tiles < n_cu ? tiles : n_cu), p.splits);
