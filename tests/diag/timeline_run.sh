@@ -8,4 +8,5 @@ cd $R
 F=$(find gpurun_out/$T/prof_$NAME -name "*kernel_trace.csv" | head -1)
 python tests/diag/timeline.py $F > gpurun_out/$T/timeline_$NAME.txt 2>&1
 cp $(find gpurun_out/$T/prof_$NAME -name "*kernel_stats.csv" | head -1) gpurun_out/$T/stats_$NAME.csv
+gzip -c $F > gpurun_out/$T/trace_$NAME.csv.gz   # (a few MB: kept for offline analysis)
 rm -rf gpurun_out/$T/prof_$NAME
