@@ -81,6 +81,7 @@ SIGNATURES = {
     "gr_gn_stats": [_P, _P, _I, _I, _I, _P],
     "gr_gn_finalize": [_P, _P, _P, _P, _I, _I, _I, _I, _F, _P],
     "gr_fuse_shuffle": [_P, _P, _I, _P, _P, _I, _P, _P, _I, _P, _I, _I, _I, _I, _P],
+    "gr_fuse_shuffle_fp8": [_P, _P, _I, _P, _P, _I, _P, _P, _I, _P, _I, _I, _I, _I, _F, _P],
     "gr_cast_f32_bf16": [_P, _P, _P, _L, _P],
     "gr_add_rows_f32": [_P, _P, _P, _L, _I, _I, _P],
     "gr_embed_gather": [_P, _P, _P, _P, _L, _I, _I, _I, _P],
@@ -99,6 +100,7 @@ SIGNATURES = {
     "gr_nms": [_P, _P, _I, _F, _I, _P, _P, _P, _P],
     "gr_roi_align_forward": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _I, _I, _I, _P],
     "gr_roi_align_pack": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _I, _I, _I, _I, _P],
+    "gr_roi_align_pack_fp8": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _I, _I, _I, _F, _P],
 }
 
 _lib = None       # the bf16 build (kept under this name: tests monkeypatch it)
@@ -136,7 +138,7 @@ def _open(path, operand):
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
         fn.argtypes = argtypes
         fn.restype = c_long if name == "gr_nms_workspace_bytes" else c_int
-    if lib.gr_abi_version() != 7:
+    if lib.gr_abi_version() != 8:
         raise RuntimeError(f"{os.path.basename(path)} ABI version mismatch")
     if lib.gr_operand_type() != operand:
         raise RuntimeError(f"{os.path.basename(path)} was built for another 16-bit operand type")

@@ -5,13 +5,6 @@
 #include "gr_common.h"
 #include "../../include/groma_hip.h"
 
-__device__ __forceinline__ uint32_t pack4_fp8(float a, float b, float c, float d) {
-  int v = 0;
-  v = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, v, false);
-  v = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, v, true);
-  return (uint32_t)v;
-}
-
 template <bool F32>
 __global__ __launch_bounds__(256) void quant_rows_fp8_kernel(const void* __restrict__ x, uint8_t* __restrict__ q,
                                                              float* __restrict__ scale, int rows, int K, long ldx) {

@@ -280,7 +280,7 @@ extern "C" int gr_gemm_bf16(const gr_gemm_desc* d, hipStream_t stream) {
     return GR_EINVAL;
   if (d->M <= 0 || d->N <= 0 || d->K <= 0) return GR_EINVAL;
   if (d->K % BK != 0 || d->N % 4 != 0) return GR_EINVAL;
-  if (d->fp8 && (d->K % 128 != 0 || d->conv_C > 0 || !d->w_scale || d->tile == 1 || d->tile == 2)) return GR_EINVAL;
+  if (d->fp8 && (d->K % 128 != 0 || d->conv_C % 128 != 0 || !d->w_scale || d->tile == 1 || d->tile == 2)) return GR_EINVAL;
   if (d->conv_C > 0 && (d->conv_C % BK != 0 || d->K % (9 * d->conv_C) != 0)) return GR_EINVAL;
   const int splits = d->splits > 1 ? d->splits : 1;
   if (splits > 1 && !d->ws) return GR_EINVAL;

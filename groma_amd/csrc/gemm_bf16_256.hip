@@ -221,15 +221,11 @@ __global__ __launch_bounds__(NT) void G256_KERNEL(GemmArgs p) {
 
   // A-operand k offsets of K-tiles t+1 and t+2 are carried incrementally (the conv gather's (segment, tap, channel)
   // decomposition needs integer divisions otherwise -- too slow for the 16-MFMA shadow of a phase)
-#if G256_FP8
-  long aoff1 = (long)(ks_begin + 1) * KT, aoff2 = (long)(ks_begin + 2) * KT;  // fp8: plain GEMM only (no conv gather)
-#else
-  long aoff1 = a_k_off(p, ks_begin + 1), aoff2 = a_k_off(p, ks_begin + 2);
-#endif
+  long aoff1 = a_k_off(p, ks_begin + 1, KT), aoff2 = a_k_off(p, ks_begin + 2, KT);
   int cv_c = 0, cv_kx = 0, cv_ky = 0;
   long cv_base = 0;  // state of tile t+2
   if (p.conv_C > 0) {
-    const long k0 = (long)(ks_begin + 2) * 64;
+    const long k0 = (long)(ks_begin + 2) * KT;
     const int tapc = (int)(k0 / p.conv_C);
     cv_c = (int)(k0 - (long)tapc * p.conv_C);
     const int seg = tapc / 9, tap = tapc - seg * 9;
@@ -240,7 +236,7 @@ __global__ __launch_bounds__(NT) void G256_KERNEL(GemmArgs p) {
   auto advance = [&]() {  // (aoff1, aoff2) <- (aoff2, offset of the following K-tile)
     aoff1 = aoff2;
     if (p.conv_C > 0) {
-      cv_c += 64;
+      cv_c += KT;
       if (cv_c == p.conv_C) {
         cv_c = 0;
         if (++cv_kx == 3) {
@@ -267,7 +263,7 @@ __global__ __launch_bounds__(NT) void G256_KERNEL(GemmArgs p) {
   };
   auto issue = [&](int h, int tile) {  // prologue form (offset from the tile index)
     const bool isA = (h == HT_A0 || h == HT_A1);
-    issue_at(h, tile, (isA && !G256_FP8) ? a_k_off(p, ks_begin + tile) : (long)(ks_begin + tile) * KT);
+    issue_at(h, tile, isA ? a_k_off(p, ks_begin + tile, KT) : (long)(ks_begin + tile) * KT);
   };
 
   f32x4 acc[MT][4];  // [mi][ni]

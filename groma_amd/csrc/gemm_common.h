@@ -70,9 +70,10 @@ __device__ __forceinline__ long a_row_base(const GemmArgs& p, int m) {
   }
   return (long)m * p.lda;
 }
-// A-operand K offset (elements) of K-step ks (64 wide): plain k, or (segment, tap, channel) of the conv gather
-__device__ __forceinline__ long a_k_off(const GemmArgs& p, int ks) {
-  const long k0 = (long)ks * 64;
+// A-operand K offset (elements) of K-step ks (kt elements wide: 64, or 128 in the e4m3 build of the ping-pong kernel): plain k,
+// or (segment, tap, channel) of the conv gather (a K-step never straddles a tap: conv_C % kt == 0)
+__device__ __forceinline__ long a_k_off(const GemmArgs& p, int ks, int kt = 64) {
+  const long k0 = (long)ks * kt;
   if (p.conv_C > 0) {
     const int tapc = (int)(k0 / p.conv_C);  // segment*9 + tap
     const int c0 = (int)(k0 - (long)tapc * p.conv_C);

@@ -229,3 +229,21 @@ static inline int gr_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
     hipError_t e__ = hipGetLastError();        \
     if (e__ != hipSuccess) return (int)e__;    \
   } while (0)
+
+// ---- OCP e4m3 packing (v_cvt_pk_fp8_f32: round-to-nearest-even).  The conversion does not saturate, so a value quantised with a
+// STATIC scale (the conv activations of the e4m3 path) is clamped to the largest finite e4m3 magnitude first; per-row dynamic
+// scales (fp8.hip) map the row maximum to 448 and need no clamp.
+__device__ __forceinline__ uint32_t pack4_fp8(float a, float b, float c, float d) {
+  int v = 0;
+  v = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, v, false);
+  v = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, v, true);
+  return (uint32_t)v;
+}
+__device__ __forceinline__ float sat448(float x) { return fminf(fmaxf(x, -448.f), 448.f); }
+// 8 fp32 values * inv (clamped) -> 8 e4m3 bytes at q[idx .. idx + 7]
+__device__ __forceinline__ void st8q(uint8_t* q, long idx, const float* o, float inv) {
+  uint2 w;
+  w.x = pack4_fp8(sat448(o[0] * inv), sat448(o[1] * inv), sat448(o[2] * inv), sat448(o[3] * inv));
+  w.y = pack4_fp8(sat448(o[4] * inv), sat448(o[5] * inv), sat448(o[6] * inv), sat448(o[7] * inv));
+  *(uint2*)(q + idx) = w;
+}

@@ -461,8 +461,11 @@ __device__ __forceinline__ void load8(const ShufSrc& s, bool norm, const float* 
     for (int i = 0; i < 8; ++i) o[i] = fmaxf(o[i] * a[i] + bb[i], 0.f);
   }
 }
-__global__ __launch_bounds__(256) void fuse_shuffle_kernel(ShufSrc tar, ShufSrc top, ShufSrc down, bf16_t* __restrict__ out,
-                                                           int imgs, int C, int shuffle, int pad) {
+// Q8: the map is written as OCP e4m3 bytes of value * q_inv (clamped to +-448) -- the A operand of an e4m3 implicit-GEMM conv whose
+// activation scale is a constant of the weights (groma_amd/weights.py: conv_act_bound), folded into that GEMM's w_scale.
+template <bool Q8>
+__global__ __launch_bounds__(256) void fuse_shuffle_kernel(ShufSrc tar, ShufSrc top, ShufSrc down, void* __restrict__ out,
+                                                           int imgs, int C, int shuffle, int pad, float q_inv) {
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;  // 8-channel chunk
   const int c8 = C >> 3;
   const int S = tar.S;
@@ -502,7 +505,9 @@ __global__ __launch_bounds__(256) void fuse_shuffle_kernel(ShufSrc tar, ShufSrc 
     }
   }
   const int Sp = S + 2 * pad;
-  st8f(out, (((long)img * Sp + y + pad) * Sp + x + pad) * C + c, o);
+  const long oi = (((long)img * Sp + y + pad) * Sp + x + pad) * C + c;
+  if (Q8) st8q((uint8_t*)out, oi, o, q_inv);
+  else st8f((bf16_t*)out, oi, o);
 }
 extern "C" int gr_fuse_shuffle(const void* tar, const float* tar_coef, int tarS, const void* top, const float* top_coef,
                                int topS, const void* down, const float* down_coef, int downS, void* out, int imgs, int C,
@@ -512,8 +517,22 @@ extern "C" int gr_fuse_shuffle(const void* tar, const float* tar_coef, int tarS,
   ShufSrc a{(const bf16_t*)tar, tar_coef, tarS}, b{(const bf16_t*)top, top_coef, topS},
       c{(const bf16_t*)down, down_coef, downS};
   const long total = (long)imgs * tarS * tarS * (C >> 3);
-  hipLaunchKernelGGL(fuse_shuffle_kernel, dim3(gr_cdiv(total, 256)), dim3(256), 0, stream, a, b, c, (bf16_t*)out, imgs, C,
-                     shuffle, pad);
+  hipLaunchKernelGGL(fuse_shuffle_kernel<false>, dim3(gr_cdiv(total, 256)), dim3(256), 0, stream, a, b, c, out, imgs, C,
+                     shuffle, pad, 0.f);
+  GR_CHECK_LAUNCH();
+  return GR_OK;
+}
+extern "C" int gr_fuse_shuffle_fp8(const void* tar, const float* tar_coef, int tarS, const void* top, const float* top_coef,
+                                   int topS, const void* down, const float* down_coef, int downS, void* out, int imgs, int C,
+                                   int shuffle, int pad, float inv_scale, hipStream_t stream) {
+  if (GR_SP) return GR_EINVAL;  // no e4m3 path in the split-operand build
+  if (!tar || !out || C % 32 != 0 || !(inv_scale > 0.f)) return GR_EINVAL;
+  if (shuffle && (!top || !down)) return GR_EINVAL;
+  ShufSrc a{(const bf16_t*)tar, tar_coef, tarS}, b{(const bf16_t*)top, top_coef, topS},
+      c{(const bf16_t*)down, down_coef, downS};
+  const long total = (long)imgs * tarS * tarS * (C >> 3);
+  hipLaunchKernelGGL(fuse_shuffle_kernel<true>, dim3(gr_cdiv(total, 256)), dim3(256), 0, stream, a, b, c, out, imgs, C,
+                     shuffle, pad, inv_scale);
   GR_CHECK_LAUNCH();
   return GR_OK;
 }

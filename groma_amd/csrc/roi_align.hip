@@ -44,7 +44,7 @@ __device__ __forceinline__ void bilinear8(const bf16_t* __restrict__ fmap, long 
 __global__ __launch_bounds__(256) void roi_align_pack_kernel(const bf16_t* __restrict__ feat, const float* __restrict__ rois,
                                                              void* __restrict__ out, int R, int C, int H, int W, int PH,
                                                              int PW, float spatial_scale, int sampling_ratio, int aligned,
-                                                             int pad, int out_f32) {
+                                                             int pad, int out_f32, float q_inv) {  // out_f32 == 2: e4m3 bytes of value * q_inv
   const int n = blockIdx.x / PH;
   const int ph = blockIdx.x - n * PH;
   const float* r = rois + (long)n * 5;
@@ -85,7 +85,12 @@ __global__ __launch_bounds__(256) void roi_align_pack_kernel(const bf16_t* __res
       }
     }
     const long o = (((long)n * OPH + ph + pad) * OPW + pw + pad) * C + c;
-    if (out_f32) {
+    if (out_f32 == 2) {
+      float r8[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) r8[i] = acc[i] / count;
+      st8q((uint8_t*)out, o, r8, q_inv);
+    } else if (out_f32) {
       float* dst = (float*)out + o;
 #pragma unroll
       for (int i = 0; i < 8; ++i) dst[i] = acc[i] / count;
@@ -107,7 +112,21 @@ extern "C" int gr_roi_align_pack(const void* feat_nhwc, const float* rois, void*
   if (R == 0) return GR_OK;  // empty ROI set: nothing to do (reference: roi_align.py:300)
   if (!feat_nhwc || !rois || !out) return GR_EINVAL;
   hipLaunchKernelGGL(roi_align_pack_kernel, dim3(R * pooled_h), dim3(256), 0, stream, (const bf16_t*)feat_nhwc, rois, out,
-                     R, C, H, W, pooled_h, pooled_w, spatial_scale, sampling_ratio, aligned, pad, out_f32);
+                     R, C, H, W, pooled_h, pooled_w, spatial_scale, sampling_ratio, aligned, pad, out_f32 ? 1 : 0, 0.f);
+  GR_CHECK_LAUNCH();
+  return GR_OK;
+}
+// the same tiles as OCP e4m3 bytes of value * inv_scale (clamped to +-448): the A operand of the e4m3 per-ROI conv
+extern "C" int gr_roi_align_pack_fp8(const void* feat_nhwc, const float* rois, void* out, int R, int C, int H, int W,
+                                     int pooled_h, int pooled_w, float spatial_scale, int sampling_ratio, int aligned,
+                                     int pad, float inv_scale, hipStream_t stream) {
+  if (GR_SP) return GR_EINVAL;
+  if (R < 0 || C <= 0 || C % 8 != 0 || H <= 0 || W <= 0 || pooled_h <= 0 || pooled_w <= 0) return GR_EINVAL;
+  if (pad < 0 || pad > 1 || !(inv_scale > 0.f)) return GR_EINVAL;
+  if (R == 0) return GR_OK;
+  if (!feat_nhwc || !rois || !out) return GR_EINVAL;
+  hipLaunchKernelGGL(roi_align_pack_kernel, dim3(R * pooled_h), dim3(256), 0, stream, (const bf16_t*)feat_nhwc, rois, out,
+                     R, C, H, W, pooled_h, pooled_w, spatial_scale, sampling_ratio, aligned, pad, 2, inv_scale);
   GR_CHECK_LAUNCH();
   return GR_OK;
 }

@@ -86,6 +86,13 @@ def _trace_q8(tag, x8, sx):
         TRACE[tag + ".q8"], TRACE[tag + ".s8"] = x8.detach().clone(), sx.detach().clone()
 
 
+def _zeros(shape, dtype, device):
+    """torch.zeros, with e4m3 buffers made as bytes (0x00 is e4m3 zero; fill kernels for the 8-bit float types are not assumed)"""
+    if dtype == ops.FP8:
+        return torch.zeros(shape, dtype=torch.uint8, device=device).view(ops.FP8)
+    return torch.zeros(shape, dtype=dtype, device=device)
+
+
 class Workspace:
     """Scratch arenas, one per buffer NAME, grown geometrically and handed out as a view of the first prod(shape)
     elements -- so ragged request shapes (L = P + 256 + 2*N_regions changes with every image, R = sum N_i) do not
@@ -106,7 +113,7 @@ class Workspace:
             key = (name, shape, dtype)
             t = self._exact.get(key)
             if t is None:
-                t = self._exact[key] = torch.zeros(shape, dtype=dtype, device=self.device)
+                t = self._exact[key] = _zeros(shape, dtype, self.device)
             return t
         n = math.prod(shape)
         key = (name, dtype)
@@ -115,11 +122,11 @@ class Workspace:
             if buf is not None:
                 torch.cuda.synchronize(self.device)  # the old arena may still be read on the side stream
             cap = n if buf is None else max(n, buf.numel() * 3 // 2)
-            buf = self._arena[key] = torch.zeros((cap,), dtype=dtype, device=self.device)
+            buf = self._arena[key] = _zeros((cap,), dtype, self.device)
             self._zshape[key] = shape
         view = buf[:n].view(shape)
         if zero and self._zshape.get(key) != shape:
-            view.zero_()
+            (view.view(torch.uint8) if dtype == ops.FP8 else view).zero_()
             self._zshape[key] = shape
         elif not zero:
             self._zshape[key] = None
@@ -421,6 +428,8 @@ class RegionEngine:
         S = [G * 4, G * 2, G]
         feats = [ws.get(f"reg_feat{l}", h16(bs, S[l], S[l], D), H16()) for l in range(3)]
         pads = [ws.get(f"reg_pad{l}", h16(bs, S[l] + 2, S[l] + 2, D), H16(), zero=True) for l in range(3)]
+        if self.w["fp8"]:
+            pads += [ws.get(f"reg_pad8{l}", (bs, S[l] + 2, S[l] + 2, D), ops.FP8, zero=True) for l in range(3)]
         bufs = list(hidden3) + feats + pads + [ws.get(f"reg_in{l}", h16(bs * S[l] * S[l], D), H16()) for l in range(3)] + \
             [ws.get(f"reg_conv{l}_{r}", h16(bs * S[l] * S[l], D), H16()) for l in range(3) for r in range(min(2, rc.num_fuse))]
         self.graphs.run(("fuse", bs, ops._PLAN[0]) + tuple(t.data_ptr() for t in bufs), lambda: self._fuse_launch(hidden3))
@@ -439,11 +448,20 @@ class RegionEngine:
             new_maps, new_coef = [], []
             for l in range(3):
                 top, dow = min(l + 1, 2), max(l - 1, 0)
-                pad = ws.get(f"reg_pad{l}", h16(bs, S[l] + 2, S[l] + 2, D), H16(), zero=True)
-                ops.fuse_shuffle((maps[l], sums[l], S[l]), (maps[top], sums[top], S[top]), (maps[dow], sums[dow], S[dow]),
-                                 pad, imgs=bs, C=D, shuffle=True, pad=1)
                 out = ws.get(f"reg_conv{l}_{r & 1}", h16(bs * S[l] * S[l], D), H16())
-                ops.gemm(pad, w["fuse"][r]["w"], conv=(bs, S[l], S[l], D, 0), out=out)
+                srcs = ((maps[l], sums[l], S[l]), (maps[top], sums[top], S[top]), (maps[dow], sums[dow], S[dow]))
+                fw = w["fuse"][r]
+                if "w8" in fw:  # fp8 mode, round >= 1: the shuffled relu(GroupNorm(.)) map is written as e4m3 with the static scale
+                    pad = ws.get(f"reg_pad8{l}", (bs, S[l] + 2, S[l] + 2, D), ops.FP8, zero=True)  # of weights.conv_act_scale
+                    ops.fuse_shuffle(*srcs, pad, imgs=bs, C=D, shuffle=True, pad=1, q_inv=fw["q_inv"])
+                    ops.gemm(pad, fw["w8"], conv=(bs, S[l], S[l], D, 0), out=out, w_scale=fw["ws8"])
+                    if r == 1 and TRACE is not None:  # (tests/test_fp8_width_gpu.py: the quantiser and the e4m3 conv, teacher-forced)
+                        _trace(f"reg8.map{l}", maps[l]), _trace(f"reg8.coef{l}", sums[l])
+                        _trace(f"reg8.pad{l}", pad), _trace(f"reg8.conv{l}", out)
+                else:
+                    pad = ws.get(f"reg_pad{l}", h16(bs, S[l] + 2, S[l] + 2, D), H16(), zero=True)
+                    ops.fuse_shuffle(*srcs, pad, imgs=bs, C=D, shuffle=True, pad=1)
+                    ops.gemm(pad, fw["w"], conv=(bs, S[l], S[l], D, 0), out=out)
                 if r == 0:
                     _trace(f"reg.pad{l}", pad), _trace(f"reg.conv{l}", out)
                 new_maps.append(out)
@@ -456,6 +474,8 @@ class RegionEngine:
             ops.fuse_shuffle((maps[l], sums[l], S[l]), None, None, f, imgs=bs, C=D, shuffle=False, pad=0)
             if rc.num_fuse == 1:  # then maps[l] is the traced round-0 conv output: feat = ReLU(GN(conv))
                 _trace(f"reg.feat{l}", f)
+            if w["fp8"]:
+                _trace(f"reg8.feat{l}", f)
             feats.append(f)
 
     def extract(self, feats, S, boxes, img_idx):
@@ -464,12 +484,18 @@ class RegionEngine:
         R = boxes.shape[0]
         P = rc.roi_size
         rois = torch.cat([img_idx[:, None], boxes * float(self.img)], dim=1).contiguous()  # (idx, "x1,y1,x2,y2") -- T1
-        tiles = ws.get("reg_tiles", h16(3, R, P + 2, P + 2, D), H16(), zero=True)
+        fp8 = w["fp8"]
+        tiles = ws.get("reg_tiles8", (3, R, P + 2, P + 2, D), ops.FP8, zero=True) if fp8 else \
+            ws.get("reg_tiles", h16(3, R, P + 2, P + 2, D), H16(), zero=True)
         for l in range(3):
-            ops.roi_align_pack(feats[l], rois, tiles[l], C=D, H=S[l], W=S[l], ph=P, pw=P,
-                               spatial_scale=1.0 / self.STRIDES[l], sampling_ratio=2, aligned=True, pad=1)
-        pc = ops.gemm(tiles, w["pconv_w"], bias=w["pconv_b"], act=2, conv=(R, P, P, D, R * (P + 2) * (P + 2) * D),
-                      out=ws.get("reg_pc", h16(R * P * P, D), H16()))
+            ops.roi_align_pack(feats[l], rois, tiles[l], C=D, H=S[l], W=S[l], ph=P, pw=P, spatial_scale=1.0 / self.STRIDES[l],
+                               sampling_ratio=2, aligned=True, pad=1, q_inv=w["pconv_q_inv"] if fp8 else None)
+        pc_out = ws.get("reg_pc", h16(R * P * P, D), H16())
+        conv = (R, P, P, D, R * (P + 2) * (P + 2) * D)
+        if fp8:  # e4m3 tiles x e4m3 weights; the tiles' static scale rides in w_scale (weights.pack_region)
+            pc = ops.gemm(tiles, w["pconv_w8"], bias=w["pconv_b"], act=2, conv=conv, out=pc_out, w_scale=w["pconv_ws8"])
+        else:
+            pc = ops.gemm(tiles, w["pconv_w"], bias=w["pconv_b"], act=2, conv=conv, out=pc_out)
         _trace("reg.rois", rois), _trace("reg.tiles", tiles), _trace("reg.pc", pc)
         # pos_embedd(rois) on the UNSCALED cxcywh boxes (roi_align.py:278)
         b16 = torch.zeros((R, 16), dtype=F32, device=boxes.device)
@@ -645,6 +671,19 @@ class LlamaEngine:
         hn = ops.rmsnorm(h, w["norm"], self.eps, out=x_b)
         if len(w["layers"]) == 1:
             _trace("llm.final_norm", hn)
+        if fp8 and "head8" in w:  # a21 in e4m3: the head reads the final norm quantised straight from fp32, like every other norm -> GEMM
+            def head(rows_f32, **kw):
+                x8, sx = ops.norm_fp8(rows_f32, w["norm"], None, self.eps, True)
+                _trace_q8("llm.head_in", x8, sx)
+                return ops.gemm(x8, w["head8"][0], a_scale=sx, w_scale=w["head8"][1], out_f32=True, **kw)
+            if L == 1:
+                logits = head(h, out=self.decode_logits(bs))
+                return logits.view(bs, 1, self.Vpad)[:, :, : self.V], hn
+            if not all_logits:
+                logits = head(h.view(bs, L, T)[:, -1].contiguous())
+                return logits.view(bs, 1, self.Vpad)[:, :, : self.V], hn.view(bs, L, -1)[:, -1].contiguous()
+            logits = head(h)
+            return logits.view(bs, L, self.Vpad)[:, :, : self.V], hn
         if L == 1:  # decode step: the sampler (GreedyDecoder._step, serving) reads this buffer
             logits = ops.gemm(hn, w["head"], out_f32=True, out=self.decode_logits(bs))
             return logits.view(bs, 1, self.Vpad)[:, :, : self.V], hn

@@ -91,7 +91,7 @@ class GromaModel:
         # proposer chain (input_proj -> DDETR encoder x6 -> two-stage top-300 -> decoder x6 -> heads -> score fusion -> NMS,
         # ~330 launches of fp32 kernels that are launch-latency-bound) captured once per batch size and replayed
         self.proposer_graph = True
-        self.fp8 = bool(fp8)  # BASELINE configs[4]: OCP e4m3 operands for the DINOv2 and LLaMA GEMMs (extension)
+        self.fp8 = bool(fp8)  # BASELINE configs[4]: OCP e4m3 operands for the DINOv2 / LLaMA GEMMs, lm_head and the region encoder's 3x3 convs
         # which GEMMs are split along K (ops.plan_splits): "throughput" = none (batched eval / the benchmark), "latency" = a
         # fixed per-(N, K) factor tuned for one request per call.  Either way a function of the layer shape only, so results
         # never depend on batch composition; the two plans differ from each other by fp32 summation order (bf16-noise level).
@@ -124,7 +124,7 @@ class GromaModel:
         self._ws = engine.Workspace(self.device)
         self.vit = engine.VitEngine(weights.pack_vit(source, cfg, self.fp8), cfg, self._ws)
         self.proposer = engine.ProposerEngine(weights.pack_ddetr(source, cfg), cfg, self._ws)
-        self.region = engine.RegionEngine(weights.pack_region(source, cfg), cfg, self._ws)
+        self.region = engine.RegionEngine(weights.pack_region(source, cfg, self.fp8), cfg, self._ws)
         self.bridge = weights.pack_bridge(source, cfg)
         self.llm = engine.LlamaEngine(weights.pack_llm(source, cfg, self.fp8), cfg, self._ws)
         self._loaded = True

@@ -487,10 +487,16 @@ def gn_coef(x, imgs, HW, C, groups, gamma, beta, eps):
     return coef
 
 
-def fuse_shuffle(tar, top, down, out, *, imgs, C, shuffle, pad):
-    """each of tar/top/down = (map bf16 [imgs*S*S, C], coef or None, S)"""
+def fuse_shuffle(tar, top, down, out, *, imgs, C, shuffle, pad, q_inv=None):
+    """each of tar/top/down = (map bf16 [imgs*S*S, C], coef or None, S).  q_inv: write the map as e4m3 bytes of value * q_inv
+    (out is a float8_e4m3fn buffer; the conv that consumes it carries 1 / q_inv in its w_scale)"""
     lib = _lib.load()
     t, tp, dn = tar, top or (None, None, 0), down or (None, None, 0)
+    if q_inv is not None:
+        _chk(out, FP8, "out")
+        _lib.check(lib.gr_fuse_shuffle_fp8(_p(t[0]), _p(t[1]), t[2], _p(tp[0]), _p(tp[1]), tp[2], _p(dn[0]), _p(dn[1]), dn[2],
+                                           _p(out), imgs, C, int(shuffle), pad, float(q_inv), _stream()), "gr_fuse_shuffle_fp8")
+        return out
     _lib.check(lib.gr_fuse_shuffle(_p(t[0]), _p(t[1]), t[2], _p(tp[0]), _p(tp[1]), tp[2], _p(dn[0]), _p(dn[1]), dn[2],
                                    _p(out), imgs, C, int(shuffle), pad, _stream()), "gr_fuse_shuffle")
     return out
@@ -697,9 +703,14 @@ def roi_align_forward(input, rois, output, argmax_y, argmax_x, aligned_height, a
 
 
 def roi_align_pack(feat_nhwc, rois, out, *, C, H, W, ph, pw, spatial_scale, sampling_ratio, aligned=True, pad=1,
-                   out_f32=False):
+                   out_f32=False, q_inv=None):
     lib = _lib.load()
     _chk(feat_nhwc, H16(), "feat"); _chk(rois, F32, "rois")
+    if q_inv is not None:  # e4m3 tiles of value * q_inv (the per-ROI conv's A operand in fp8 mode)
+        _chk(out, FP8, "out")
+        _lib.check(lib.gr_roi_align_pack_fp8(_p(feat_nhwc), _p(rois), _p(out), rois.shape[0], C, H, W, ph, pw, spatial_scale,
+                                             sampling_ratio, int(aligned), pad, float(q_inv), _stream()), "gr_roi_align_pack_fp8")
+        return out
     _lib.check(lib.gr_roi_align_pack(_p(feat_nhwc), _p(rois), _p(out), rois.shape[0], C, H, W, ph, pw, spatial_scale,
                                      sampling_ratio, int(aligned), pad, int(out_f32), _stream()), "gr_roi_align_pack")
     return out

@@ -212,21 +212,52 @@ def pack_ddetr(W, cfg):
     return out
 
 
-def pack_region(W, cfg):
+# e4m3 region-encoder convs (fp8 mode): the A operand of fuse round r >= 1 and of the per-ROI conv is relu(GroupNorm(conv)) of the
+# round before, whose magnitude is bounded by the GroupNorm's own affine parameters: |gamma| * (a normalised deviation) + |beta|.
+# CONV_ACT_SIGMAS normalised deviations are representable; beyond, the value saturates at the bound (e4m3 is a floating-point
+# format, so a generous bound costs no relative precision -- only values below bound * 2^-15 flush).  The scale is therefore a
+# constant of the weights: no reduction pass over the maps, nothing for the GEMM epilogue to look up (it is folded into w_scale),
+# and the oracle restates it exactly (oracle/groma_oracle.py conv_act_scale).  Round 0 reads the raw 1x1-conv outputs of the ViT
+# states, which have no such bound: it keeps 16-bit operands.
+CONV_ACT_SIGMAS = 64.0
+FP8_HEAD = True  # fp8 mode: lm_head (+) extra_lm_head as e4m3 rows (a21 is named by BASELINE configs[4])
+
+
+def conv_act_scale(g, b):
+    """static e4m3 scale of relu(GroupNorm(.)) activations with affine (g, b): value ~= e4m3 * scale"""
+    return max(CONV_ACT_SIGMAS * float(g.abs().max()) + float(b.abs().max()), 1e-20) / 448.0
+
+
+def pack_region(W, cfg, fp8=False):
     rc = cfg.region_cfg
     D = cfg.perceiver_cfg.vis_encoder_cfg.hidden_size
     m, ra = "region_encoder.mlvl_fuse.", "region_encoder.roi_align."
     Cp = _ru(D + 2, 64)
-    out = dict(Cpad=Cp, in_w=[], in_b=[], fuse=[])
+    fp8 = bool(fp8) and D % 128 == 0 and rc.num_fuse >= 1  # (the e4m3 conv gather needs whole 128-deep K-tiles per tap)
+    if fp8 and ops.SP() == 2:
+        raise NotImplementedError("e4m3 operands and the reference-precision build are exclusive")
+    out = dict(Cpad=Cp, in_w=[], in_b=[], fuse=[], fp8=fp8)
     for l in range(rc.num_levels):
         out["in_w"].append(bf(pad_k(W(f"{m}input_conv.{l}.weight").reshape(D, D + 2), Cp)))
         out["in_b"].append(W(f"{m}input_conv.{l}.bias"))
     for r in range(rc.num_fuse):
         w = W(f"{m}fuse_convs.{r}.conv.weight")  # [D, D, 3, 3] -> [D, (ky,kx,c)]
-        out["fuse"].append(dict(w=bf(w.permute(0, 2, 3, 1).reshape(D, 9 * D)), g=W(f"{m}fuse_convs.{r}.gn.weight"),
-                                b=W(f"{m}fuse_convs.{r}.gn.bias")))
+        ent = dict(g=W(f"{m}fuse_convs.{r}.gn.weight"), b=W(f"{m}fuse_convs.{r}.gn.bias"))
+        wk = w.permute(0, 2, 3, 1).reshape(D, 9 * D)
+        if fp8 and r >= 1:  # e4m3 weights, per-output-channel scale x the static scale of this round's input maps
+            s_in = conv_act_scale(out["fuse"][r - 1]["g"], out["fuse"][r - 1]["b"])
+            w8, sw = q8(wk)
+            ent.update(w8=w8, ws8=(sw * s_in).contiguous(), q_inv=1.0 / s_in)
+        else:
+            ent["w"] = bf(wk)
+        out["fuse"].append(ent)
     pw = [W(f"{ra}pconvs.{l}.weight").permute(0, 2, 3, 1).reshape(D, 9 * D) for l in range(rc.num_levels)]
-    out["pconv_w"] = bf(torch.cat(pw, 1))
+    if fp8:  # the RoIAlign tiles are bilinear means of the last round's relu(GroupNorm(.)) maps: same bound
+        s_in = conv_act_scale(out["fuse"][-1]["g"], out["fuse"][-1]["b"])
+        w8, sw = q8(torch.cat(pw, 1))
+        out["pconv_w8"], out["pconv_ws8"], out["pconv_q_inv"] = w8, (sw * s_in).contiguous(), 1.0 / s_in
+    else:
+        out["pconv_w"] = bf(torch.cat(pw, 1))
     out["pconv_b"] = sum(W(f"{ra}pconvs.{l}.bias") for l in range(rc.num_levels)).contiguous()
     P2 = rc.roi_size ** 2
     fw = W(ra + "flatten_linear.weight")  # [mid, D*P2] with k = c*P2 + hw  ->  k' = hw*D + c
@@ -265,6 +296,11 @@ def pack_llm(W, cfg, fp8=False):
     head[: lc.vocab_size] = bf(W("llm.lm_head.weight"))
     head[lc.vocab_size: V] = bf(W("extra_lm_head.weight"))
     out["head"], out["V"], out["Vpad"] = head, V, Vp
+    if fp8 and FP8_HEAD:  # BASELINE configs[4] names a21: lm_head (+) extra_lm_head as e4m3 rows with per-output-channel scales (padding rows: zeros)
+        hf = torch.zeros((Vp, T), dtype=F32, device=W.device)
+        hf[: lc.vocab_size] = W("llm.lm_head.weight").float()
+        hf[lc.vocab_size: V] = W("extra_lm_head.weight").float()
+        out["head8"] = q8(hf)
     hd = T // lc.num_attention_heads
     inv = 1.0 / (lc.rope_theta ** (torch.arange(0, hd, 2, dtype=F32) / hd))
     fr = torch.outer(torch.arange(lc.max_position_embeddings, dtype=F32), inv)

@@ -42,7 +42,7 @@ extern "C" {
 typedef struct ihipStream_t* hipStream_t;
 #endif
 
-#define GROMA_HIP_ABI_VERSION 7
+#define GROMA_HIP_ABI_VERSION 8
 int gr_abi_version(void);
 #define GR_OPERAND_BF16 0
 #define GR_OPERAND_F16 1
@@ -88,7 +88,7 @@ typedef struct gr_gemm_desc {
                          the split-K partials are LEFT in ws [splits, M, N] f32 for the caller
                          (round 1-3's decode step; the step now runs on gr_gemv_fused): C and the epilogue fields are unused;
                          any other value: GR_EINVAL */
-  /* OCP fp8 (e4m3) operands (BASELINE configs[4]): A, W are 1-byte elements, K % 128 == 0, no conv gather;
+  /* OCP fp8 (e4m3) operands (BASELINE configs[4]): A, W are 1-byte elements, K % 128 == 0 (conv gather: conv_C % 128 == 0);
    * the result is dequantised as acc * a_scale[m] * w_scale[n] before the rest of the epilogue */
   int fp8;
   const float* a_scale; /* [M] per-row scale of A, or NULL (= 1)                                     */
@@ -202,6 +202,12 @@ int gr_gn_finalize(const float* sums, const float* gamma, const float* beta, flo
 int gr_fuse_shuffle(const void* tar, const float* tar_coef, int tarS, const void* top, const float* top_coef, int topS,
                     const void* down, const float* down_coef, int downS, void* out, int imgs, int C, int shuffle, int pad,
                     hipStream_t stream);
+/* the same map as OCP e4m3 bytes of value * inv_scale (clamped to +-448): the A operand of an e4m3 implicit-GEMM 3x3 conv
+ * (gr_gemm_desc.fp8 with conv_C > 0) whose activation scale 1 / inv_scale is a constant folded into that GEMM's w_scale
+ * (BASELINE configs[4] extended to the region encoder's convs; groma/model/roi_align.py:150-193) */
+int gr_fuse_shuffle_fp8(const void* tar, const float* tar_coef, int tarS, const void* top, const float* top_coef, int topS,
+                        const void* down, const float* down_coef, int downS, void* out, int imgs, int C, int shuffle, int pad,
+                        float inv_scale, hipStream_t stream);
 int gr_cast_f32_bf16(const float* a, const float* b, void* out, long n, hipStream_t stream);
 int gr_add_rows_f32(const float* a, const float* b, float* out, long rows, int C, int b_mod, hipStream_t stream);
 int gr_embed_gather(const long* ids, const void* table0, const void* table1, float* out, long n, int C, int V0, int V1,
@@ -261,6 +267,11 @@ int gr_nms(const float* boxes_xyxy, const float* scores, int n, float iou_thresh
 int gr_roi_align_pack(const void* feat_nhwc, const float* rois, void* out, int R, int C, int H, int W, int pooled_h,
                       int pooled_w, float spatial_scale, int sampling_ratio, int aligned, int pad, int out_f32,
                       hipStream_t stream);
+/* the same tiles as OCP e4m3 bytes of value * inv_scale (clamped to +-448): the A operand of the e4m3 per-ROI conv
+ * (groma/model/roi_align.py:312-315) */
+int gr_roi_align_pack_fp8(const void* feat_nhwc, const float* rois, void* out, int R, int C, int H, int W, int pooled_h,
+                          int pooled_w, float spatial_scale, int sampling_ratio, int aligned, int pad, float inv_scale,
+                          hipStream_t stream);
 
 /* The reference op itself, argument for argument: `void roi_align_forward(Tensor input, Tensor rois, Tensor output,
  * Tensor argmax_y, Tensor argmax_x, int aligned_height, int aligned_width, float spatial_scale, int sampling_ratio,

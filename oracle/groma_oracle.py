@@ -70,9 +70,28 @@ def _r(x):
 #   weights:     per-OUTPUT-CHANNEL scale s = max(|w|, 1e-20) / 448, q = e4m3_rne(w / s)      (quantised once at load)
 #   product:     fp32 accumulation of the exact e4m3 products, then * w_scale[n] * a_scale[m], then the fp32 epilogue.
 # A normalisation output is quantised straight from fp32 (the fused norm -> e4m3 kernel); a stored activation (attention
-# context, GELU / SwiGLU output) is a bf16 tensor that is then row-quantised.  lm_head, bridge, patch embedding and the region
-# encoder keep bf16 operands in this mode (as on the device).
+# context, GELU / SwiGLU output) is a bf16 tensor that is then row-quantised.  lm_head (+) extra_lm_head read the final RMSNorm
+# the same way (round 4).  Bridge, patch embedding, the region encoder's 1x1 input convs, round-0 fuse conv and linears keep bf16.
+# The region encoder's 3x3 convs from fuse round 1 on, and the per-ROI conv (round 4; groma_amd/weights.py pack_region):
+#   activations: relu(GroupNorm(.)) maps / their RoIAlign tiles, STATIC scale s = (64 * max|gamma| + max|beta|) / 448 of the
+#                GroupNorm that produced them (conv_act_scale), q = e4m3_rne(clamp(x * (1 / s), -448, 448))
+#   weights:     per-OUTPUT-CHANNEL scale over the channel's (C, 3, 3) taps (the per-ROI conv: over its three levels' taps jointly)
+#   product:     fp32 accumulation of the exact e4m3 products, then * (w_scale[n] * s)  (one fp32 factor, as the device folds it)
 E4M3 = torch.float8_e4m3fn
+CONV_ACT_SIGMAS = 64.0
+
+
+def conv_act_scale(g, b):
+    return max(CONV_ACT_SIGMAS * float(g.abs().max()) + float(b.abs().max()), 1e-20) / 448.0
+
+
+def _conv8(x, w, s_in, b=None, **kw):
+    """e4m3 3x3 conv of the device: x fp32 [bs, C, H, W] (the tensor the quantiser sees), w fp32 [N, C, 3, 3]"""
+    xq = (x * (1.0 / s_in)).clamp(-448.0, 448.0).to(E4M3).to(torch.float32)
+    sw = w.flatten(1).abs().amax(dim=1).clamp_min(1e-20) / 448.0
+    wq = (w / sw[:, None, None, None]).to(E4M3).to(torch.float32)
+    y = F.conv2d(xq, wq, None, **kw) * (sw * s_in)[None, :, None, None]
+    return y if b is None else y + b[None, :, None, None]
 
 
 def quant_rows_e4m3(x):
@@ -478,9 +497,14 @@ def region_fuse(sd, cfg, mlvl_tokens, prefix="region_encoder."):
         # mmcv ConvModule: conv(no bias) -> GN(groups) -> ReLU (R: mmcv/mmcv/cnn/bricks/conv_module.py:196-206)
         # (rounded mode: the conv output is stored as bf16 and the GN statistics are taken from the stored values; the
         #  normalised map is only rounded again where it is consumed -- as the next conv's / RoIAlign's bf16 input)
-        inputs = [F.relu(F.group_norm(_r(_conv16(x, sd[f"{m}fuse_convs.{r}.conv.weight"], None, padding=1)),
-                                      rc["gn_groups"], sd[f"{m}fuse_convs.{r}.gn.weight"],
-                                      sd[f"{m}fuse_convs.{r}.gn.bias"], 1e-5)) for x in fused]
+        wr = sd[f"{m}fuse_convs.{r}.conv.weight"]
+        if _ROUND[0] == "e4m3" and r >= 1 and C % 128 == 0:  # (the device's e4m3 conv gather needs C % 128 == 0: weights.pack_region)
+            s_in = conv_act_scale(sd[f"{m}fuse_convs.{r - 1}.gn.weight"], sd[f"{m}fuse_convs.{r - 1}.gn.bias"])
+            convs = [_conv8(x, wr, s_in, padding=1) for x in fused]
+        else:
+            convs = [_conv16(x, wr, None, padding=1) for x in fused]
+        inputs = [F.relu(F.group_norm(_r(y), rc["gn_groups"], sd[f"{m}fuse_convs.{r}.gn.weight"],
+                                      sd[f"{m}fuse_convs.{r}.gn.bias"], 1e-5)) for y in convs]
     return [_r(x) for x in inputs]
 
 
@@ -500,11 +524,18 @@ def roi_extract(sd, cfg, feats, rois_list, prefix="region_encoder.roi_align."):
     strides = [14 / 8, 14 / 4, 14 / 2]
     P = rc["roi_size"]
     acc = None
-    for lvl, f in enumerate(feats):
-        rf = torch.from_numpy(cref.roi_align_avg(f.float().contiguous().numpy(), rois.float().numpy(), (P, P),
-                                                 1.0 / strides[lvl], 2, True))
-        y = _conv16(rf, sd[f"{prefix}pconvs.{lvl}.weight"], sd[f"{prefix}pconvs.{lvl}.bias"], padding=1)
-        acc = y if acc is None else acc + y
+    rfs = [torch.from_numpy(cref.roi_align_avg(f.float().contiguous().numpy(), rois.float().numpy(), (P, P),
+                                               1.0 / strides[lvl], 2, True)) for lvl, f in enumerate(feats)]
+    nf = rc["num_fuse"]
+    if _ROUND[0] == "e4m3" and nf >= 1 and feats[0].shape[1] % 128 == 0:  # one e4m3 conv over the three levels' taps (as the device)
+        m = prefix.replace("roi_align.", "mlvl_fuse.")
+        s_in = conv_act_scale(sd[f"{m}fuse_convs.{nf - 1}.gn.weight"], sd[f"{m}fuse_convs.{nf - 1}.gn.bias"])
+        acc = _conv8(torch.cat(rfs, 1), torch.cat([sd[f"{prefix}pconvs.{l}.weight"] for l in range(len(rfs))], 1), s_in,
+                     sum(sd[f"{prefix}pconvs.{l}.bias"] for l in range(len(rfs))), padding=1)
+    else:
+        for lvl, rf in enumerate(rfs):
+            y = _conv16(rf, sd[f"{prefix}pconvs.{lvl}.weight"], sd[f"{prefix}pconvs.{lvl}.bias"], padding=1)
+            acc = y if acc is None else acc + y
     x = F.relu(acc).flatten(1, -1)
     x = _lin16(x, sd, prefix + "flatten_linear")
     x = x + pe
@@ -589,6 +620,8 @@ def get_input_embeddings(sd, input_ids):
 
 def lm_logits(sd, hidden):
     """R: groma/model/groma.py:399-402"""
+    if _ROUND[0] == "e4m3":  # a21 in e4m3: `hidden` is the final RMSNorm output, quantised straight from fp32
+        return torch.cat((_lin8(hidden, sd["llm.lm_head.weight"]), _lin8(hidden, sd["extra_lm_head.weight"])), dim=-1)
     return torch.cat((_lin16(hidden, sd, "llm.lm_head", False), _lin16(hidden, sd, "extra_lm_head", False)), dim=-1)
 
 

@@ -38,7 +38,9 @@ def test_fp8_weights_are_e4m3(setup):
     ref = m16.llm.w["layers"][0]["wqkv"][0].float()
     deq = w8.float() * s[:, None]
     assert util.relerr(deq, ref) < 5e-2
-    assert m8.llm.w["head"].dtype == torch.bfloat16  # lm_head stays bf16
+    h8, hs = m8.llm.w["head8"]   # round 4: the head is e4m3 too (a21 is named by configs[4])
+    assert h8.dtype == torch.float8_e4m3fn and hs.shape[0] == h8.shape[0]
+    assert m8.region.w["fp8"] and m8.region.w["fuse"][1]["w8"].dtype == torch.float8_e4m3fn   # and the 3x3 convs from round 1 on
 
 
 def test_fp8_vit_states(setup):
