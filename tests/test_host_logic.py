@@ -447,3 +447,30 @@ def test_bench_pins_host_threads_per_rank():
     finally:
         os.sched_setaffinity(0, before_aff)
         torch.set_num_threads(before_thr)
+
+
+def test_e4m3_conv_scale_and_oracle_conv_agree_with_the_packer():
+    """fp8 mode's region convs: the static activation scale is a formula of the GroupNorm's affine parameters that the product
+    (groma_amd/weights.py) and the oracle (oracle/groma_oracle.py) each state for themselves -- they must be the same number -- and
+    the oracle's e4m3 conv is what it says: fp32 accumulation of exact e4m3 products of clamped, statically scaled activations and
+    per-output-channel scaled weights"""
+    import torch.nn.functional as F
+    from groma_amd import weights
+    g = torch.Generator().manual_seed(3)
+    gam, bet = torch.randn(64, generator=g), torch.randn(64, generator=g) * 0.1
+    s = O.conv_act_scale(gam, bet)
+    assert s == weights.conv_act_scale(gam, bet) and weights.CONV_ACT_SIGMAS == O.CONV_ACT_SIGMAS
+    assert abs(s * 448.0 - (64.0 * float(gam.abs().max()) + float(bet.abs().max()))) < 1e-4
+    x = torch.relu(torch.randn((2, 16, 9, 9), generator=g)) * 3.0
+    x[0, 0, 0, 0] = 1e6                               # beyond the bound: saturates at 448 * s instead of becoming NaN
+    w = torch.randn((8, 16, 3, 3), generator=g) * 0.05
+    y = O._conv8(x, w, s, padding=1)
+    assert torch.isfinite(y).all()
+    xq = (x / s).clamp(-448, 448).to(torch.float8_e4m3fn).float()
+    sw = w.flatten(1).abs().amax(1) / 448.0
+    wq = (w / sw[:, None, None, None]).to(torch.float8_e4m3fn).float()
+    ref = F.conv2d(xq.double(), wq.double(), padding=1).float() * (sw * s)[None, :, None, None]
+    assert util.relerr(y, ref) < 1e-6
+    assert float(xq.max()) == 448.0                   # the clamp, not a NaN code
+    # and the format's own distance on this input stays at the e4m3 level (3 mantissa bits on both operands)
+    assert util.relerr(y, F.conv2d(x.clamp(max=448 * s), w, padding=1)) < 8e-2
