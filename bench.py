@@ -297,7 +297,7 @@ def measure(model, cfg, args, dev, rank, job, P, gen, batch, plan="throughput", 
 
     old = model.gemm_plan
     model.gemm_plan = plan
-    caps = lambda: model.vit.graphs.captures + model.llm.graphs.captures
+    caps = lambda: model.vit.graphs.captures + model.llm.graphs.captures + model.region.graphs.captures
     mark = {}
     try:
         # hipGraph capture is set-up, like building the model: a shape is captured on its third sighting (GraphPool.CAPTURE_AT), so
@@ -325,14 +325,7 @@ def launch_roofline(m, step, n, kind):
     old_graph, old_pool = m.decode_graph, engine.GraphPool.enabled
     m.decode_graph, engine.GraphPool.enabled = False, False
     try:
-        with ops.precision(m.precision):
-            ops.prof_enable(True)
-        for i in range(n):
-            step(1000 + i)
-        torch.cuda.synchronize()
-        with ops.precision(m.precision):
-            ops.prof_enable(False)
-            recs = ops.prof_read_launches()
+        recs, vit_recs = profiled_steps(m, step, n, 1000)
     finally:
         m.decode_graph, engine.GraphPool.enabled = old_graph, old_pool
     if kind == "hbm":
@@ -357,7 +350,39 @@ def launch_roofline(m, step, n, kind):
         out["note"] = ("operand pairs: every contraction issues hi.hi + hi.lo + lo.hi, so `achieved` counts 3x the algorithmic 2MNK "
                        "(the MFMA work actually issued); algorithmic rate = achieved / 3")
         out["algorithmic_tflops"] = ach / 3.0
+    if vit_recs is not None:
+        out["vit_pair_gemms"] = pair_block(vit_recs, n)
     return out
+
+
+def profiled_steps(m, step, n, base):
+    """n eager steps with the HIP-event hook on in the library of every stage of model m -> (records of the library behind the
+    ViT, records of the ViT's own library or None when it is the same one)"""
+    from groma_amd import ops
+    libs = [m.precision] + ([m.vit_precision] if m.vit_precision != m.precision else [])
+    for p in libs:
+        with ops.precision(p):
+            ops.prof_enable(True)
+    for i in range(n):
+        step(base + i)
+    torch.cuda.synchronize()
+    out = []
+    for p in libs:
+        with ops.precision(p):
+            ops.prof_enable(False)
+            out.append(ops.prof_read_launches())
+    return out[0], (out[1] if len(out) > 1 else None)
+
+
+def pair_block(vit_recs, n):
+    """the ViT's GEMMs of a precision="hybrid" model (libgroma_hip_ref.so: gemm_pair_256_kernel / gemm_pair_kernel, 3 MFMA passes on
+    (hi, lo) operand pairs): issued MFMA work against the 2.5 PF peak, and the algorithmic rate (a third of it)"""
+    ms = sum(r[4] for r in vit_recs)
+    fl = sum(2.0 * r[0] * r[1] * r[2] for r in vit_recs)
+    ach = 3.0 * fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+    return {"kernels": "gemm_pair_256_kernel / gemm_pair_kernel (libgroma_hip_ref.so): hi.hi + hi.lo + lo.hi per contraction",
+            "launches_per_step": len(vit_recs) / max(n, 1), "ms_per_step": ms / max(n, 1), "issued_tflops": ach, "frac_issued": ach / 2500.0,
+            "algorithmic_tflops": ach / 3.0}
 
 
 def extras_block(model, cfg, args, dev, P):
@@ -410,29 +435,44 @@ def extras_block(model, cfg, args, dev, P):
         g["decode_step"] = {"error": str(e)}
     g["workload"] = "configs[3] per-GPU share: prefill + greedy decode (hipGraph replay), no EOS"
     ex["generate_4_images_per_call"] = g
-    m8 = GromaModel.from_synthetic(cfg, seed=0, device=dev, fp8=True)
-    m8.init_special_token_id(constants.SyntheticTokenizer())
-    f8 = line(m8, args.batch, False, steps=5, warmup=3, roof="mfma")
-    f8["dtype"] = "fp8 (OCP e4m3 operands for the DINOv2 / LLaMA linears, f32 accumulate; lm_head and region convs bf16)"
-    ex["forward_fp8"] = f8
-    del m8
-    torch.cuda.empty_cache()
-    m16 = GromaModel.from_synthetic(cfg, seed=0, device=dev, precision="fp16")
-    m16.init_special_token_id(constants.SyntheticTokenizer())
-    f16 = line(m16, args.batch, False, steps=5, warmup=3, roof="mfma")
-    f16["dtype"] = "fp16 (IEEE half operands through libgroma_hip_f16.so, f32 accumulate: the reference's inference autocast dtype)"
-    ex["forward_fp16"] = f16
-    del m16
-    torch.cuda.empty_cache()
-    mr = GromaModel.from_synthetic(cfg, seed=0, device=dev, precision="ref")
-    mr.init_special_token_id(constants.SyntheticTokenizer())
-    fr = line(mr, args.batch, False, steps=3, warmup=3, roof="mfma")
-    fr["dtype"] = ("ref: (hi, lo) pairs of halves through libgroma_hip_ref.so, three MFMA passes per contraction, f32 accumulate -- the mode "
-                   "that holds north_star's 1e-3 on the full-depth logits against the fp32 oracle (tests/test_fulldepth_parity_gpu.py)")
-    ex["forward_ref"] = fr
-    del mr
-    torch.cuda.empty_cache()
+    def other(name, dtype_note, steps=5, **kw):
+        """a line measured on another model instance (built, measured, freed)"""
+        m = GromaModel.from_synthetic(cfg, seed=0, device=dev, **kw)
+        m.init_special_token_id(constants.SyntheticTokenizer())
+        r = line(m, args.batch, False, steps=steps, warmup=3, roof="mfma")
+        r["dtype"], r["precision"] = dtype_note, m.mode
+        ex[name] = r
+        del m
+        torch.cuda.empty_cache()
+
+    hyb = model.vit_precision == "ref"
+    if hyb:   # rounds 1-4's headline: the ViT on bf16 operands too (index-valued results then only hold stage by stage)
+        other("forward_bf16_vit", "bf16 operands in every stage incl. the ViT (precision='bf16'): faster, but the proposer's ranking is no longer "
+              "the fp32 reference's end to end (tests/test_e2e_unchained_gpu.py: 51-59 % of the top-300 slots)", precision="bf16")
+    else:
+        other("forward_hybrid", "precision='hybrid': the ViT on operand pairs, the rest bf16", precision="hybrid")
+    other("forward_fp8", "fp8: OCP e4m3 operands (MX-rate MFMA) for the LLaMA linears, lm_head and the region encoder's 3x3 / per-ROI convs, f32 "
+          "accumulate; the ViT on operand pairs (precision='hybrid', fp8=True), so the e4m3 build holds the index contract too", precision="hybrid", fp8=True)
+    other("forward_fp8_e4m3_vit", "fp8 in every stage incl. the ViT linears (round 4's forward_fp8)", fp8=True)
+    other("forward_fp16", "fp16 (IEEE half operands through libgroma_hip_f16.so, f32 accumulate: the reference's inference autocast dtype) behind a "
+          "pair-operand ViT (precision='hybrid-fp16')", precision="hybrid-fp16")
+    other("forward_ref", "ref: (hi, lo) pairs of halves through libgroma_hip_ref.so in EVERY stage, three MFMA passes per contraction, f32 accumulate -- "
+          "the mode that also holds north_star's 1e-3 on the full-depth logits against the fp32 oracle (tests/test_fulldepth_parity_gpu.py)",
+          steps=3, precision="ref")
     return ex
+
+
+def extras_summary(ex):
+    """{line: [images/s, roofline fraction of its dominant kernel or None]} + the decode step: what the driver's stored head / tail
+    of the JSON line must still show (the long extras block is cut out of the middle)"""
+    out = {}
+    for k, v in (ex or {}).items():
+        if isinstance(v, dict) and "value" in v:
+            rf = v.get("roofline") or {}
+            out[k] = [round(v["value"], 2), round(rf["frac"], 3) if "frac" in rf else None]
+            if "decode_step" in v and "ms_per_token" in v["decode_step"]:
+                out["decode_ms_per_token"] = [round(v["decode_step"]["ms_per_token"], 3), round(v["decode_step"]["frac_of_8TBps"], 3)]
+    return out
 
 
 def pin_host_threads(local_rank, world):
@@ -464,6 +504,10 @@ def main():
                     help="GEMM operand type of the DINOv2/LLaMA linears.  bf16 is the headline (BASELINE's precision); fp16 = the "
                          "IEEE-half build of the same kernels (libgroma_hip_f16.so: the reference's own inference autocast dtype, "
                          "same MFMA rate); fp8 = OCP e4m3 operands + f32 accumulate (BASELINE configs[4] extension)")
+    ap.add_argument("--vit-operands", default="pair", choices=["pair", "same"],
+                    help="pair (default, GromaModel precision='hybrid'): the DINOv2 encoder runs on (hi, lo) half pairs with three MFMA "
+                         "passes per contraction (libgroma_hip_ref.so), which makes the proposal / NMS / token ids of the run equal the "
+                         "fp32 reference's; same: the ViT uses --dtype operands like every other stage (the headline of rounds 1-4)")
     ap.add_argument("--mode", default="forward", choices=["forward", "generate"],
                     help="forward = the headline prefill metric (BASELINE configs[2]); generate = configs[3]: greedy decoding "
                          "of --new-tokens tokens per image at --batch images per GPU (use --batch 4), HBM-bound decode steps")
@@ -522,8 +566,12 @@ def main():
     cfg = gconfig.groma_7b(box_score_thres=0.0) if args.config == "7b" else gconfig.groma_tiny(box_score_thres=0.0)
     fp8 = args.dtype == "fp8"
     precision = "fp16" if args.dtype == "fp16" else "bf16"
-    ops._lib.PRECISION[0] = precision  # process default = the headline model's library (the HIP-event hook below is per library)
-    model = GromaModel.from_synthetic(cfg, seed=0, device=dev, fp8=fp8, precision=precision)
+    ops._lib.PRECISION[0] = precision  # process default = the library of everything behind the ViT (the HIP-event hook is per library)
+    pair_vit = args.vit_operands == "pair"
+    # the headline build since round 5 is precision="hybrid": the ViT -- the one 16-bit stage in front of the fp32 proposer -- on (hi, lo)
+    # operand pairs, so that the top-300 / NMS / spliced ids of the benchmarked build equal the fp32 reference's end to end
+    # (tests/test_e2e_unchained_gpu.py); everything behind it on --dtype operands.  --vit-operands same = rounds 1-4's headline.
+    model = GromaModel.from_synthetic(cfg, seed=0, device=dev, fp8=fp8, precision={"bf16": "hybrid", "fp16": "hybrid-fp16"}[precision] if pair_vit else precision)
     model.init_special_token_id(constants.SyntheticTokenizer())
     P = 128
     gen = args.mode == "generate"
@@ -549,14 +597,9 @@ def main():
     # kernels eagerly
     model.decode_graph = False
     engine.GraphPool.enabled = False
-    ops.prof_enable(True)
-    for i in range(args.steps):
-        step(args.warmup + i)
-    torch.cuda.synchronize()
-    ops.prof_enable(False)
+    recs, vit_recs = profiled_steps(model, step, args.steps, args.warmup)
     engine.GraphPool.enabled = not args.no_prefill_graphs
     model.decode_graph = True
-    recs = ops.prof_read_launches()
     if args.gemm_breakdown and rank == 0:
         agg = {}
         for M_, N_, K_, tag, ms in recs:
@@ -580,7 +623,7 @@ def main():
     # `traffic_source` says so
     traffic, traffic_source = None, None
     if rank == 0 and world == 1 and not args.no_traffic and args.config == "7b" and not fp8 and not gen:
-        traffic = measure_traffic(args.batch)
+        traffic = measure_traffic(args.batch, extra=["--vit-operands", args.vit_operands])
         if traffic is not None:
             traffic_source = "measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (separate child runs, gfx950 x2 fetch correction)"
     if traffic is None and args.config == "7b" and not fp8 and not gen:
@@ -618,6 +661,9 @@ def main():
                    "images_per_gpu": job.rows, "images_per_forward_call": min(args.batch, job.rows),
                    "global_batch": job.global_batch, "prompt_tokens": P,
                    "llm_seq_len": fl["L"], "regions_per_image": sum(n_reg) / len(n_reg),
+                   "precision": model.mode,
+                   "vit_operands": ("(hi, lo) pairs of halves, 3 MFMA passes per contraction (libgroma_hip_ref.so): the index-valued results of "
+                                    "this build equal the fp32 reference's, unchained" if model.vit_precision == "ref" else "same as dtype"),
                    "gemm_plan": args.gemm_plan, "prefill_graphs": not args.no_prefill_graphs,
                    "parallelism": f"dp{world} (image batch sharded, full replica per GPU)"},
         "roofline": {"bound": "mfma", "kernel": kname,
@@ -634,6 +680,8 @@ def main():
                      "e2e_algorithmic_tflops_per_gpu": fl["total"] * job.rows * args.steps / elapsed / 1e12,
                      "e2e_frac_of_peak": fl["total"] * job.rows * args.steps / elapsed / 1e12 / peak},
     }
+    if vit_recs is not None:
+        out["roofline"]["vit_pair_gemms"] = pair_block(vit_recs, args.steps)
     if gen:  # configs[3]: the decode steps stream the bf16 weights once per token -> HBM roofline of the GEMV kernel
         gv = [r for r in recs if r[3] & 8]
         gv_ms = sum(r[4] for r in gv)
@@ -647,7 +695,8 @@ def main():
         if rank == 0 and world == 1 and not args.no_traffic and args.config == "7b" and not fp8:
             # FETCH_SIZE / WRITE_SIZE of the fused weight-streaming kernel, per launch, from two rocprofv3 --pmc child runs of this
             # command (the decode steps are graph replays there; the counters see the same kernels)
-            gv_traffic = measure_traffic(args.batch, "gemv_fused_kernel", ["--mode", "generate", "--new-tokens", str(args.new_tokens)])
+            gv_traffic = measure_traffic(args.batch, "gemv_fused_kernel", ["--mode", "generate", "--new-tokens", str(args.new_tokens),
+                                                                             "--vit-operands", args.vit_operands])
         out["roofline"] = {"bound": "hbm", "kernel": "gemv_fused_kernel<MB, XG>(GemvFArgs) -- decode-step weight streaming, one launch per weight matrix",
                            "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0, "traffic": gv_traffic,
                            "traffic_note": "bytes/launch at the L2<->fabric boundary (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, gfx950 correction), averaged over the fused-stream launches; algorithmic = bytes_per_launch" if gv_traffic else None,
@@ -661,12 +710,19 @@ def main():
                 out["extras"] = extras_block(model, cfg, args, dev, P)
             except Exception as e:  # an extra never takes the headline down
                 out["extras"] = {"error": f"{type(e).__name__}: {e}"}
+            summ = extras_summary(out["extras"])
+            # a compact copy at the FRONT (right behind the headline numbers) and again as the LAST key of the line
+            out = dict(list(out.items())[:5] + [("extras_summary", summ)] + list(out.items())[5:])
         if world == 1 and not args.no_cpu_baseline and not gen:
             try:
                 out["cpu_baseline"] = cpu_baseline(args.config, full_reps=args.cpu_baseline_reps)
             except Exception as e:  # never lose the GPU measurement to a host-side failure
                 out["cpu_baseline"] = {"value": None, "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
                                        "sample": f"failed: {type(e).__name__}: {e}"}
+        if "extras_summary" in out:
+            out["summary_tail"] = {"value": round(ips, 2), "precision": model.mode, "roofline_frac": round(achieved / peak, 4),
+                                   "e2e_frac_of_peak": round(out["roofline"].get("e2e_frac_of_peak", 0.0), 4),
+                                   "extras [images/s, roofline frac]": out["extras_summary"]}
         print(json.dumps(out), flush=True)
     if use_dist:
         import torch.distributed as dist

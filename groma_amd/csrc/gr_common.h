@@ -74,6 +74,16 @@ __device__ __forceinline__ uint32_t pack2bf_unit(float a, float b) { return pack
 #define GR_SP 0
 #endif
 #define GR_SPW (1 + GR_SP)  // physical 16-bit elements per logical element
+#if GR_SP
+// The MFMA kernels of this build do 3 passes per contraction on twice the operand bytes: they carry their own names, so that a
+// trace of a precision="hybrid" model (the ViT from this library, everything else from the bf16 one, in ONE process) keeps the
+// two apart -- rocprofv3 --stats aggregates by kernel name, and bench.py's roofline block is per kernel name.
+#define gemm_bf16_256_kernel gemm_pair_256_kernel
+#define gemm_bf16_kernel gemm_pair_kernel
+#define attention_kernel attention_pair_kernel
+#define norm_rows_kernel norm_rows_pair_kernel
+#define qkv_split_kernel qkv_split_pair_kernel
+#endif
 __device__ __host__ __forceinline__ long sp_idx(long i) { return GR_SP ? (((i >> 5) << 6) + (i & 31)) : i; }
 // (a, b) -> packed hi pair (+ packed lo pair in the split build)
 __device__ __forceinline__ void split2(float a, float b, uint32_t& hi, uint32_t& lo) {

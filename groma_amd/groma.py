@@ -60,13 +60,16 @@ def _box_iou(b1, b2):  # torchvision.ops.box_iou on a handful of host-side boxes
     return inter / (a1[:, None] + a2 - inter)
 
 
+# precision="hybrid" / "hybrid-fp16": (operand type behind the ViT, operand type of the ViT)
+HYBRID_MODES = {"hybrid": ("bf16", "ref"), "hybrid-fp16": ("fp16", "ref")}
+
 _entry = engine.model_entry(lambda self, *a, **kw: self.precision)  # every boundary entry point: see engine.normal_mode / ops.precision
 
 
 class GromaModel:
     config_class = GromaConfig
 
-    def __init__(self, config: GromaConfig, source=None, device="cuda", fp8=False, precision="bf16"):
+    def __init__(self, config: GromaConfig, source=None, device="cuda", fp8=False, precision="bf16", vit_precision=None):
         self.config = config
         # 16-bit operand type of the GEMM / attention kernels and of every 16-bit buffer (KV cache, feature maps):
         # "bf16" (libgroma_hip.so: BASELINE's benchmark dtype) or "fp16" (libgroma_hip_f16.so: what the reference's inference
@@ -77,11 +80,23 @@ class GromaModel:
         # into the fp32 MFMA accumulators: 3x the MFMA work, within ~1e-6 of fp32 per contraction, which is what keeps the
         # 24 + 32-layer chain inside north_star's 1e-3 of the reference's fp32 forward (R: groma/eval/eval_rec.py:69 loads fp32
         # weights).  Same kernels, same launch sequence; 16-bit buffers are twice as wide.
-        if precision not in ("bf16", "fp16", "ref"):
-            raise ValueError(f"precision must be 'bf16', 'fp16' or 'ref', got {precision!r}")
+        # "hybrid" (round 5) selects the operand type PER STAGE: the ViT -- the only 16-bit stage in front of the fp32 proposer, 724
+        # of the 11 850 GFLOP of an image -- runs on operand pairs ("ref"), everything behind it (bridge, region encoder, LLaMA) on
+        # bf16 ("hybrid") or fp16 ("hybrid-fp16") operands, or e4m3 with fp8=True.  The proposer then sees ViT states within
+        # ~3e-6 of the reference's fp32 ones, so the INDEX-valued results of the path -- top-300 proposal ids, NMS keep ids, the
+        # shuffled selection, the spliced token ids -- equal the reference's end to end, with no stage chaining
+        # (R: groma/model/groma.py:222-280 in one fp32 pass; tests/test_e2e_unchained_gpu.py), at ~0.9x the bf16 throughput
+        # instead of "ref"'s 0.4x.  The logits keep the 16-bit format's distance.
+        vit_precision = vit_precision or precision
+        if precision in HYBRID_MODES:
+            precision, vit_precision = HYBRID_MODES[precision]
+        if precision not in ("bf16", "fp16", "ref") or vit_precision not in ("bf16", "fp16", "ref"):
+            raise ValueError(f"precision must be 'bf16', 'fp16', 'ref', 'hybrid' or 'hybrid-fp16', got {precision!r} / ViT {vit_precision!r}")
         if precision == "ref" and fp8:
             raise ValueError("fp8=True and precision='ref' are exclusive")
-        self.precision = precision
+        # `precision`: operand type of everything behind the ViT (what serving / the KV cache / the decode arena are built for);
+        # `vit_precision`: the ViT's.  Equal except under "hybrid".
+        self.precision, self.vit_precision = precision, vit_precision
         self.decode_graph = True  # generate(): replay one captured hipGraph per token (False = eager per-kernel launches)
         # output_hidden_states=True: False = hidden_states[0] is the 1-tuple (final normed state,) -- every reference caller only
         # reads hidden_states[-1]['pred_boxes'] and passes the flag for that (R: groma/eval/eval_rec.py:93-101), so the 33
@@ -122,12 +137,27 @@ class GromaModel:
         ops._lib.load()  # fail loudly if the HIP library is missing
         cfg = self.config
         self._ws = engine.Workspace(self.device)
-        self.vit = engine.VitEngine(weights.pack_vit(source, cfg, self.fp8), cfg, self._ws)
+        with ops.precision(self.vit_precision):   # ("hybrid": the ViT's weights are operand pairs, and never e4m3)
+            self.vit = engine.VitEngine(weights.pack_vit(source, cfg, self.fp8 and self.vit_precision != "ref"), cfg, self._ws)
         self.proposer = engine.ProposerEngine(weights.pack_ddetr(source, cfg), cfg, self._ws)
         self.region = engine.RegionEngine(weights.pack_region(source, cfg, self.fp8), cfg, self._ws)
         self.bridge = weights.pack_bridge(source, cfg)
         self.llm = engine.LlamaEngine(weights.pack_llm(source, cfg, self.fp8), cfg, self._ws)
         self._loaded = True
+
+    @property
+    def mode(self):
+        """the name this model's per-stage operand types go by: "bf16" | "fp16" | "ref" | "hybrid" | "hybrid-fp16" (+ "+e4m3")"""
+        name = next((k for k, v in HYBRID_MODES.items() if v == (self.precision, self.vit_precision)), None)
+        if name is None:
+            name = self.precision if self.precision == self.vit_precision else f"{self.precision}+vit:{self.vit_precision}"
+        return name + ("+e4m3" if self.fp8 else "")
+
+    def _vit_forward(self, images):
+        """a1 under the ViT's own operand type.  Its results are fp32 hidden states [bs, T, D] in either build (the residual
+        stream), so nothing is converted at the hand-over: the proposer, the bridge and the region pyramid read them as they are."""
+        with ops.precision(self.vit_precision):
+            return self.vit.forward(images)
 
     def _side_stream(self):
         if getattr(self, "_side", None) is None:
@@ -157,12 +187,23 @@ class GromaModel:
         reference's parameter names (groma/eval/eval_rec.py:69).  Weights are repacked to 16-bit device layouts:
         torch_dtype=torch.float16 (what groma/eval/run_groma.py and the model worker pass) selects the fp16 operand build, an
         EXPLICIT torch_dtype=torch.float32 the reference-precision build ("ref": split operands, ~fp32 results at 3x the MFMA
-        work), anything else (None / "auto" / bfloat16) bf16; `precision="bf16" | "fp16" | "ref"` overrides."""
+        work), anything else (None / "auto" / bfloat16) bf16; `precision="bf16" | "fp16" | "ref" | "hybrid" | "hybrid-fp16"`
+        overrides ("hybrid": the ViT on operand pairs so that box indices / token ids equal the fp32 reference's, the rest 16-bit).
+        The selection is logged (logger "groma_amd"); the implicit float32 -> "ref" one also warns, because it costs 2.5x the
+        bf16 step, twice the weight / KV bytes, and decodes through the general GEMM kernels."""
         if torch_dtype not in (None, "auto", torch.float32, torch.float16, torch.bfloat16):
             raise NotImplementedError(f"torch_dtype={torch_dtype}: the MI355X path computes with bf16 or fp16 operands (fp32 accumulate)")
         # torch_dtype states how the CALLER would have held the weights (fp32 in eval_rec.py:69, fp16 in run_groma.py): norms,
         # biases and the proposer stay fp32, the GEMM operands take the 16-bit type
         precision = kw.get("precision") or ("fp16" if torch_dtype == torch.float16 else "ref" if torch_dtype == torch.float32 else "bf16")
+        import logging
+        logging.getLogger("groma_amd").info("from_pretrained(%s): torch_dtype=%s -> precision=%r", path, torch_dtype, precision)
+        if torch_dtype == torch.float32 and not kw.get("precision"):
+            import warnings
+            warnings.warn("GromaModel.from_pretrained(torch_dtype=torch.float32) selects precision='ref' (operand pairs, three MFMA passes: "
+                          "~fp32 results, 2.5x the bf16 step time, 2x the weight and KV-cache bytes, no streaming decode kernels).  Pass "
+                          "precision='hybrid' for reference-exact box indices / token ids at ~0.9x the bf16 speed, or precision='bf16'.",
+                          stacklevel=2)
         for unsupported in ("load_in_8bit", "load_in_4bit", "quantization_config"):
             if kw.get(unsupported):
                 raise NotImplementedError(f"{unsupported} is not supported by the MI355X path (bf16 / fp32 only)")
@@ -239,7 +280,7 @@ class GromaModel:
         """Steps A-E (groma.py:218-280): ViT -> proposer -> NMS -> shuffle.  Returns (hidden4, selected_boxes list of
         device f32 [N_i,4], aux dict)."""
         images = images.to(device=self.device, dtype=F32).contiguous()
-        hidden4 = self.vit.forward(images)
+        hidden4 = self._vit_forward(images)
         selected, aux = self.propose(hidden4, refer_boxes, ground_boxes, debug)
         return hidden4, selected, aux
 
@@ -449,7 +490,7 @@ class GromaModel:
             if past_key_values is None:
                 images = images.to(device=dev, dtype=F32).contiguous()
                 ids_early = self._ids_to_host_async(input_ids)  # the prompt ids are needed on the host after the NMS sync: fetch them now
-                hidden4 = self.vit.forward(images)
+                hidden4 = self._vit_forward(images)
                 # Two HIP streams: the region-encoder pyramid (5 rounds of MFMA-bound 3x3 convs) and the bridge MLP only
                 # need the ViT states, so they run beside the launch-latency-bound fp32 proposer + NMS + host sync.
                 main = torch.cuda.current_stream()

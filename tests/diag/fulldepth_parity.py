@@ -16,7 +16,10 @@ cores.
 
 precision="ref" (operand pairs, csrc/gr_common.h) is compared UNCHAINED only: one fp32 oracle pass that runs its own ViT end to
 end, which is the reference's computation (R: groma/model/groma.py:222-280,389-402 in one fp32 pass); there is no rounded
-oracle for it -- pure fp32 is its oracle."""
+oracle for it -- pure fp32 is its oracle.
+precision="hybrid" / "hybrid-fp16" (round 5: the ViT on operand pairs, everything behind it bf16 / fp16) is compared UNCHAINED too:
+both oracle passes -- fp32, and operands rounded to the 16-bit type BEHIND the ViT -- consume the oracle's own fp32 ViT states,
+nothing of the device's."""
 import os, sys, time, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
@@ -57,13 +60,15 @@ def run(seed=0, precision="bf16"):
     tk = util.TokenIds()
     images, ids = synth.make_inputs(full, tk, 1, seed=1234)
     t = time.time()
+    hybrid = precision.startswith("hybrid")
+    base = {"hybrid": "bf16", "hybrid-fp16": "fp16"}.get(precision, precision)   # operand type behind the ViT
     model = GromaModel.from_synthetic(full, seed=seed, device=dev, precision=precision)
     model.init_special_token_id(constants.SyntheticTokenizer())
     sd = LazyDeviceStateDict(full, seed, dev)
     # spot check: the lazy dict serves exactly what the device model packed (distinct per layer)
     a, b = sd["llm.model.layers.0.mlp.down_proj.weight"], sd["llm.model.layers.31.mlp.down_proj.weight"]
     from groma_amd import ops
-    with ops.precision(precision):
+    with ops.precision(base):
         assert not torch.equal(a, b) and torch.equal(ops.to_h16(a), model.llm.w["layers"][0]["wd"][0].cpu())
         assert torch.equal(ops.to_h16(b), model.llm.w["layers"][31]["wd"][0].cpu())
     print(f"device model (distinct per-layer weights) packed in {time.time() - t:.1f} s")
@@ -77,18 +82,21 @@ def run(seed=0, precision="bf16"):
         dbg = {}
         model.proposer.forward(aux["hidden4"], debug=dbg)   # the device's own class logits (arena views of this forward)
         dev_cls = dbg["enc_class"].float().cpu()
-        unchained = precision == "ref"
+        unchained = precision == "ref" or hybrid
         ref, ref_v = {}, {}
-        for mode in ((None,) if unchained else (None, precision)):
+        for mode in ((None,) if precision == "ref" else (None, base)):
             t = time.time()
+            with O.rounding(None if hybrid else mode):   # (hybrid: the ViT is NOT a 16-bit stage -- both passes take the fp32 ViT)
+                own = ref_v[None] if (hybrid and None in ref_v) else O.vit_forward(sd, cd, images)
+                ref_v[mode] = own if hybrid else own[-4:]
             with O.rounding(mode):
-                own = O.vit_forward(sd, cd, images)
-                ref_v[mode] = own[-4:]
                 torch.manual_seed(77)
                 ref[mode] = O.groma_forward(sd, cd, util.tok_dict(tk), ids.clone(), images,
                                             hidden_states=tuple(own) if unchained else tuple(dev_h))
-            print(f"oracle ({'fp32' if mode is None else precision + '-rounded'}{', UNCHAINED (its own ViT states)' if unchained else ''}): "
+            print(f"oracle ({'fp32' if mode is None else base + '-rounded'}{', UNCHAINED (its own ViT states)' if unchained else ''}): "
                   f"24-layer ViT + proposer + region encoder + 32-layer LLaMA in {time.time() - t:.1f} s")
+        if hybrid:
+            ref_v = {m: v[-4:] for m, v in ref_v.items()}
         # what the index-valued results do WITHOUT stage chaining: the fp32 oracle's proposer on the oracle's own ViT states
         torch.manual_seed(77)
         per = ref[None] if unchained else O.perceive(sd, cd, images, hidden_states=tuple(ref_v[None]))
@@ -104,7 +112,8 @@ def run(seed=0, precision="bf16"):
     print(f"UNCHAINED (oracle runs its own fp32 ViT): top-300 ids equal at {un['topk_pos_equal']:.3f} of slots, set overlap {un['topk_set_overlap']:.3f}; "
           f"NMS ids equal: {un['nms_equal']} (set overlap {un['nms_set_overlap']:.3f}); oracle min adjacent gap of the top-301 logits "
           f"{un['min_gap']:.2e}, device class-logit max abs error {un['cls_err']:.2e}")
-    r32, r16 = ref[None], ref[None if unchained else precision]
+    r32, r16 = ref[None], ref[None if precision == "ref" else base]
+    precision_name, precision = precision, base   # (the prints below name the operand type of the rounded oracle)
     eq = dict(topk_equal=torch.equal(aux["topk_idx"].cpu().long(), r32["det"]["topk_idx"]),
               nms_equal=torch.equal(aux["nms_keep"][0], r32["nms_inds"][0]),
               ids_equal=torch.equal(aux["input_ids"], r32["input_ids"]) and torch.equal(r16["input_ids"], r32["input_ids"]))
@@ -114,7 +123,7 @@ def run(seed=0, precision="bf16"):
 
     def three(name, d, f):
         a, b, c = rel(d, f(r32)), rel(d, f(r16)), rel(f(r16), f(r32))
-        if unchained:
+        if precision_name == "ref":
             print(f"{name:42s} device<->fp32 oracle (unchained) {a:.3e}")
         else:
             print(f"{name:42s} device<->fp32 {a:.3e} | device<->{precision}-rounded {b:.3e} | {precision}-rounded<->fp32 {c:.3e} | ratio {a / c:.2f}")

@@ -68,3 +68,20 @@ def test_full_depth_reference_precision_unchained(dev):
     for name in ("image_tokens", "region_tokens", "k0", "k31", "logits", "region_logits"):
         assert r[name][0] <= 1e-3, (name, r[name])    # the north-star tolerance, every stage, 24 + 32 layers deep
     assert r["argmax_agree"] >= 0.999
+
+
+def test_full_depth_hybrid_precision_unchained(dev):
+    """precision="hybrid" -- the build bench.py's headline runs (round 5): only the ViT on operand pairs, bridge / region encoder /
+    LLaMA on bf16 operands -- against oracle passes that run their OWN fp32 ViT (no stage chaining): the index-valued results of the
+    whole path equal the reference's at the real depth (configs[1] "box-index bit-exact vs ref", R: groma/model/groma.py:222-280),
+    the ViT states are within 1e-4 of fp32, and everything behind the ViT keeps the bf16 format's own distance (R: :389-402)."""
+    r = _diag().run(precision="hybrid")
+    un = r["unchained"]
+    assert r["topk_equal"] and r["nms_equal"] and r["ids_equal"] and r["L"] == 582
+    assert un["topk_pos_equal"] == 1.0 and un["nms_equal"]
+    for d32, _, _ in r["vit"]:
+        assert d32 < 1e-4
+    _format_gates(r, 1.5)
+    d32, d16, fmt = r["logits"]
+    assert d32 <= 1.1 * fmt
+    assert r["argmax_agree_clear"] == 1.0

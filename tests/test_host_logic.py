@@ -244,6 +244,20 @@ def test_precision_context_selects_library_and_dtype():
     with pytest.raises(ValueError):
         GromaModel(config.groma_tiny(), precision="half")
     assert GromaModel(config.groma_tiny(), precision="fp16").precision == "fp16"
+    # round 5: per-stage operand types.  "hybrid" = the ViT (the one 16-bit stage in front of the fp32 proposer) on operand pairs,
+    # everything behind it on bf16 / fp16 / e4m3; `precision` stays the type serving / the KV cache are built for
+    m = GromaModel(config.groma_tiny(), precision="hybrid")
+    assert (m.precision, m.vit_precision, m.mode) == ("bf16", "ref", "hybrid")
+    m = GromaModel(config.groma_tiny(), precision="hybrid-fp16")
+    assert (m.precision, m.vit_precision, m.mode) == ("fp16", "ref", "hybrid-fp16")
+    m = GromaModel(config.groma_tiny(), precision="hybrid", fp8=True)      # e4m3 behind a pair-operand ViT is a legal combination
+    assert (m.precision, m.vit_precision, m.mode, m.fp8) == ("bf16", "ref", "hybrid+e4m3", True)
+    assert GromaModel(config.groma_tiny(), precision="ref").mode == "ref" and GromaModel(config.groma_tiny()).mode == "bf16"
+    assert GromaModel(config.groma_tiny(), precision="bf16", vit_precision="fp16").mode == "bf16+vit:fp16"
+    with pytest.raises(ValueError):
+        GromaModel(config.groma_tiny(), precision="ref", fp8=True)
+    with pytest.raises(ValueError):
+        GromaModel(config.groma_tiny(), precision="bf16", vit_precision="fp8")
 
 
 def test_graph_pool_policy(monkeypatch):
