@@ -63,6 +63,35 @@ extern "C" int gr_diag_att_clk(unsigned long long* out) { return (int)hipMemcpyF
 // 64-key V^T tile row is 128 physical elements (chunk 8*tt + g = hi of keys 32*tt + 8*g.., + 4 = lo), and both contractions
 // issue hi.hi + hi.lo + lo.hi.  P is split in registers.  Tiles are twice as large: one workgroup per CU.
 
+// De-phasing the two workgroups that share a CU (round 5).  A wave-iteration is ~1.0 k clk of MFMA followed by ~1.2 k clk of
+// soft-max VALU, and the two waves a SIMD holds (one from each resident workgroup) start together and then STAY in phase: while
+// both are in their MFMA segment they share the matrix pipe, while both are in the soft-max they share the VALU, so the pair
+// costs the SUM of the two segments (tests/diag/attn_clk.py) although the pipes are independent.  Two compile-time knobs break
+// the symmetry by the wave's hardware slot on its SIMD (HW_ID[3:0]; the two co-resident waves differ in it):
+//   ATT_PRIO_SLOT = p : odd slots run at s_setprio p -- the favoured wave gets through a contended segment first and the pair
+//                       settles half an iteration apart (MFMA of one under the soft-max of the other);
+//   ATT_SKEW = n      : the workgroup whose wave 0 sits in an odd slot sleeps n x 1024 clk before its first tile.
+#ifndef ATT_PRIO_SLOT
+#define ATT_PRIO_SLOT 0
+#endif
+#ifndef ATT_SKEW
+#define ATT_SKEW 0
+#endif
+// ATT_PRIO_PHASE = 1: s_setprio 1 around the two MFMA loops of an iteration (S^T = K.Q^T and O^T += V^T.P^T), 0 in the soft-max.
+// VALU issue between the waves of a SIMD is arbitrated by priority, then age (MI355X_MICROARCH.md "Two waves per SIMD", item 2): a
+// wave in its MFMA segment that loses issue slots to a co-resident wave's soft-max VALU also loses matrix-pipe time, while a
+// soft-max that yields to MFMA issues still gets the 3 of 4 issue slots an MFMA stream leaves free.
+#ifndef ATT_PRIO_PHASE
+#define ATT_PRIO_PHASE 0
+#endif
+#if ATT_PRIO_PHASE
+#define ATT_MFMA_BEGIN __builtin_amdgcn_s_setprio(1);
+#define ATT_MFMA_END __builtin_amdgcn_s_setprio(0);
+#else
+#define ATT_MFMA_BEGIN
+#define ATT_MFMA_END
+#endif
+
 template <int HD>
 __global__ __launch_bounds__(256, GR_SP ? 1 : 2) void attention_kernel(AttnArgs p) {
   constexpr int KV = 64;
@@ -85,6 +114,12 @@ __global__ __launch_bounds__(256, GR_SP ? 1 : 2) void attention_kernel(AttnArgs 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int fr = lane & 15, fg = lane >> 4;
+#if ATT_PRIO_SLOT || ATT_SKEW
+  const unsigned hw_slot = __builtin_amdgcn_s_getreg((3 << 11) | 4);  // HW_REG_HW_ID bits [3:0]: wave slot on this SIMD
+#endif
+#if ATT_PRIO_SLOT
+  if (hw_slot & 1) __builtin_amdgcn_s_setprio(ATT_PRIO_SLOT);
+#endif
   // Block order: (batch, head) fastest, query block slowest and -- when causal -- the block with the most visible keys
   // first, so the long blocks start in the first wave of workgroups and the short ones fill the tail of the launch
   // (A/B on one box, tests/diag/attn_bench.py: L = 582 causal 14 x 32 heads 97.5 -> 96 us, 4 x 32 heads 34.1 -> 26.5 us;
@@ -104,6 +139,50 @@ __global__ __launch_bounds__(256, GR_SP ? 1 : 2) void attention_kernel(AttnArgs 
   int kvmax = Skv;
   if (p.kv_len) kvmax = min(kvmax, p.kv_len[b]);
 
+  // loop bounds: block-level (staging + barriers) and wave-level (compute)
+  const int blk_last = min(q0 + 64 * QT - 1, p.Lq - 1);
+  const int wav_last = min(q0 + wave * (16 * QT) + 16 * QT - 1, p.Lq - 1);
+  const int blk_limit = p.causal ? min(kvmax, q_pos0 + blk_last + 1) : kvmax;
+  const int wav_limit = p.causal ? min(kvmax, q_pos0 + wav_last + 1) : kvmax;
+  const int ntiles = (blk_limit + KV - 1) / KV;
+  const bool wave_has_rows = q0 + wave * (16 * QT) < p.Lq;
+  const int wav_first = min(q0 + wave * (16 * QT), p.Lq - 1);
+  const int wav_min_limit = p.causal ? min(kvmax, q_pos0 + wav_first + 1) : kvmax;  // min over the wave's rows
+
+  // stage K tile (lds chunk position pos holds logical chunk pos ^ (row&7)) and Vt tile of kv tile t into buffer t&1
+  auto stage = [&](int t) {
+    const int kv0 = t * KV;
+    char* ksm = smem + (t & 1) * STAGE;
+    char* vsm = ksm + KTILE;
+    constexpr int NCH = KV * KCH;
+#pragma unroll
+    for (int i = 0; i < NCH / 256; ++i) {
+      const int q = i * 256 + tid;
+      const int row = q / KCH, pos = q % KCH;
+      const int c = pos ^ kswz(row);
+      int kr = kv0 + row;
+      if (kr > Skv - 1) kr = Skv - 1;
+      __builtin_amdgcn_global_load_lds((gptr_t)(Kp + (long)kr * (HD * SPW) + c * 8), (lptr_t)(ksm + i * 4096 + wave * 1024), 16, 0, 0);
+    }
+    constexpr int NVC = HD * VCH;
+#pragma unroll
+    for (int i = 0; i < NVC / 256; ++i) {
+      const int q = i * 256 + tid;
+      const int row = q / VCH, pos = q % VCH;
+      const int c = pos ^ (row & 7);
+      __builtin_amdgcn_global_load_lds((gptr_t)(Vp + ((long)row * p.kv_stride + kv0) * SPW + c * 8),
+                                       (lptr_t)(vsm + i * 4096 + wave * 1024), 16, 0, 0);
+    }
+  };
+
+  // ATT_STAGE_FIRST: tile 0's LDS-DMA is requested BEFORE the query fragments (and their RoPE tables) are fetched, so the two
+  // latencies of a workgroup's prologue overlap instead of adding up (a causal block at L = 582 runs only 2-10 tiles).
+#ifndef ATT_STAGE_FIRST
+#define ATT_STAGE_FIRST 0
+#endif
+#if ATT_STAGE_FIRST
+  if (ntiles > 0) stage(0);
+#endif
   // this lane's query rows (B-operand columns), one per q-tile -- clamp the tail
   int qi[QT], limit[QT];
   bool q_valid[QT];
@@ -168,16 +247,6 @@ __global__ __launch_bounds__(256, GR_SP ? 1 : 2) void attention_kernel(AttnArgs 
     }
     limit[u] = p.causal ? min(kvmax, q_pos0 + qi[u] + 1) : kvmax;  // keys [0, limit) visible
   }
-  // loop bounds: block-level (staging + barriers) and wave-level (compute)
-  const int blk_last = min(q0 + 64 * QT - 1, p.Lq - 1);
-  const int wav_last = min(q0 + wave * (16 * QT) + 16 * QT - 1, p.Lq - 1);
-  const int blk_limit = p.causal ? min(kvmax, q_pos0 + blk_last + 1) : kvmax;
-  const int wav_limit = p.causal ? min(kvmax, q_pos0 + wav_last + 1) : kvmax;
-  const int ntiles = (blk_limit + KV - 1) / KV;
-  const bool wave_has_rows = q0 + wave * (16 * QT) < p.Lq;
-  const int wav_first = min(q0 + wave * (16 * QT), p.Lq - 1);
-  const int wav_min_limit = p.causal ? min(kvmax, q_pos0 + wav_first + 1) : kvmax;  // min over the wave's rows
-
   f32x4 o[QT][HD / 16];
   float m_run[QT], l_run[QT];
 #pragma unroll
@@ -188,36 +257,21 @@ __global__ __launch_bounds__(256, GR_SP ? 1 : 2) void attention_kernel(AttnArgs 
     for (int n = 0; n < HD / 16; ++n) o[u][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
   }
 
-  // stage K tile (lds chunk position pos holds logical chunk pos ^ (row&7)) and Vt tile of kv tile t into buffer t&1
-  auto stage = [&](int t) {
-    const int kv0 = t * KV;
-    char* ksm = smem + (t & 1) * STAGE;
-    char* vsm = ksm + KTILE;
-    constexpr int NCH = KV * KCH;
-#pragma unroll
-    for (int i = 0; i < NCH / 256; ++i) {
-      const int q = i * 256 + tid;
-      const int row = q / KCH, pos = q % KCH;
-      const int c = pos ^ kswz(row);
-      int kr = kv0 + row;
-      if (kr > Skv - 1) kr = Skv - 1;
-      __builtin_amdgcn_global_load_lds((gptr_t)(Kp + (long)kr * (HD * SPW) + c * 8), (lptr_t)(ksm + i * 4096 + wave * 1024), 16, 0, 0);
-    }
-    constexpr int NVC = HD * VCH;
-#pragma unroll
-    for (int i = 0; i < NVC / 256; ++i) {
-      const int q = i * 256 + tid;
-      const int row = q / VCH, pos = q % VCH;
-      const int c = pos ^ (row & 7);
-      __builtin_amdgcn_global_load_lds((gptr_t)(Vp + ((long)row * p.kv_stride + kv0) * SPW + c * 8),
-                                       (lptr_t)(vsm + i * 4096 + wave * 1024), 16, 0, 0);
-    }
-  };
-
 #ifdef G256_CLK
   unsigned long long am[20] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #endif
+#if !ATT_STAGE_FIRST
   if (ntiles > 0) stage(0);
+#endif
+#if ATT_SKEW
+  {
+    __shared__ int skew;
+    if (tid == 0) skew = (int)(hw_slot & 1);
+    __syncthreads();
+    if (skew)
+      for (int i = 0; i < ATT_SKEW; ++i) __builtin_amdgcn_s_sleep(16);
+  }
+#endif
   for (int t = 0; t < ntiles; ++t) {
     const int kv0 = t * KV;
     ATT_MARK(0)
@@ -254,6 +308,7 @@ __global__ __launch_bounds__(256, GR_SP ? 1 : 2) void attention_kernel(AttnArgs 
       }
     };
     load_k(0, kfr[0]);
+    ATT_MFMA_BEGIN
 #pragma unroll
     for (int g = 0; g < NKG; ++g) {
       if (g + 1 < NKG) load_k(g + 1, kfr[(g + 1) & 1]);
@@ -272,6 +327,7 @@ __global__ __launch_bounds__(256, GR_SP ? 1 : 2) void attention_kernel(AttnArgs 
       }
       __builtin_amdgcn_sched_barrier(0);
     }
+    ATT_MFMA_END
     ATT_MARK(2)
     // ---- online softmax; lane holds keys kv0 + (j>>1)*32 + fg*8 + (j&1)*4 + r of query fr (per q-tile).
     // The running max is kept in RAW score units and the softmax scale is folded into one fma per element
@@ -356,6 +412,7 @@ __global__ __launch_bounds__(256, GR_SP ? 1 : 2) void attention_kernel(AttnArgs 
       }
     };
     load_v(0, vfr[0]);
+    ATT_MFMA_BEGIN
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
       if (g + 1 < NG) load_v(g + 1, vfr[(g + 1) & 1]);
@@ -374,6 +431,7 @@ __global__ __launch_bounds__(256, GR_SP ? 1 : 2) void attention_kernel(AttnArgs 
       }
       __builtin_amdgcn_sched_barrier(0);
     }
+    ATT_MFMA_END
     ATT_MARK(4)
   }
 #ifdef G256_CLK

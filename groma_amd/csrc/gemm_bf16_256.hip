@@ -233,9 +233,10 @@ __global__ __launch_bounds__(NT) void G256_KERNEL(GemmArgs p) {
     cv_kx = tap - cv_ky * 3;
     cv_base = (long)seg * p.conv_seg_stride;
   }
-  auto advance = [&]() {  // (aoff1, aoff2) <- (aoff2, offset of the following K-tile)
+  auto advance = [&](auto mode_c) {  // (aoff1, aoff2) <- (aoff2, offset of the following K-tile); mode 0: test conv_C, 1: plain rows, 2: conv gather
+    constexpr int AMODE = decltype(mode_c)::value;
     aoff1 = aoff2;
-    if (p.conv_C > 0) {
+    if (AMODE == 2 || (AMODE == 0 && p.conv_C > 0)) {
       cv_c += KT;
       if (cv_c == p.conv_C) {
         cv_c = 0;
@@ -250,8 +251,8 @@ __global__ __launch_bounds__(NT) void G256_KERNEL(GemmArgs p) {
     }
   };
 
-  auto issue_at = [&](int h, int tile, long koff) {  // one half-tile of K-tile `tile` into stage tile&1
-    if (tile >= nt) return;
+  auto issue_at = [&](int h, int tile, long koff, bool in_range = false) {  // one half-tile of K-tile `tile` into stage tile&1
+    if (!in_range && tile >= nt) return;  // (in_range: the caller knows tile < nt -- the steady-state K loop, no branch)
 #ifdef G256_ABL_NODMA  // timing ablation (tests/diag): only the prologue's two K-tiles are ever staged; results are garbage
     if (tile >= 2) return;
 #endif
@@ -337,9 +338,19 @@ __global__ __launch_bounds__(NT) void G256_KERNEL(GemmArgs p) {
   __builtin_amdgcn_sched_barrier(0);                                                                      \
   __builtin_amdgcn_s_barrier();                                                                           \
   __builtin_amdgcn_sched_barrier(0);
-  for (int t = 0; t < nt; ++t) {
+  // Round 5: the K loop is PEELED into a steady-state loop (t + 2 < nt: every wait is the counted one, every staged tile exists)
+  // and a two-iteration tail, so the steady state carries no scalar branch but its back-edge.  As one loop the `steady` /
+  // `tile < nt` tests compiled to ~8 s_cbranch per K-tile inside the LOAD segments (seen in the ISA: wait-count variants and the
+  // guarded LDS-DMA issues as separate basic blocks) -- taken branches on the segment that has to stay shorter than the partner's
+  // 512-clk MFMA segment.  Same instructions in the same order per accumulator: bitwise identical.  -DG256_PEEL=0 = the old form.
+#ifndef G256_PEEL
+#define G256_PEEL 1
+#endif
+  auto ktile = [&](int t, auto steady_c, auto amode_c) {
+    constexpr bool STEADY_C = decltype(steady_c)::value;
     const char* st = smem + (t & 1) * STAGE_BYTES;
-    const bool steady = t + 2 < nt;
+    const bool steady = G256_PEEL ? STEADY_C : (t + 2 < nt);
+    const bool rng = G256_PEEL ? STEADY_C : false;
     // ===== X
 #ifdef G256_ABL_NOREAD  // timing ablation: fragments are read for K-tile 0 only
     if (t == 0)
@@ -358,7 +369,7 @@ __global__ __launch_bounds__(NT) void G256_KERNEL(GemmArgs p) {
     }
     __builtin_amdgcn_sched_barrier(0);
     WAIT_VM(6);
-    issue_at(HT_A1, t + 1, aoff1);
+    issue_at(HT_A1, t + 1, aoff1, rng);
     DRAIN_READS
     PHASE32(0, 0)
     // ===== Y
@@ -374,12 +385,20 @@ __global__ __launch_bounds__(NT) void G256_KERNEL(GemmArgs p) {
     }
     __builtin_amdgcn_sched_barrier(0);
     WAIT_VM(2);
-    issue_at(HT_A0, t + 2, aoff2);
-    issue_at(HT_B0, t + 2, (long)(ks_begin + t + 2) * KT);
-    issue_at(HT_B1, t + 2, (long)(ks_begin + t + 2) * KT);
-    advance();
+    issue_at(HT_A0, t + 2, aoff2, rng);
+    issue_at(HT_B0, t + 2, (long)(ks_begin + t + 2) * KT, rng);
+    issue_at(HT_B1, t + 2, (long)(ks_begin + t + 2) * KT, rng);
+    advance(amode_c);
     DRAIN_READS
     PHASE32(1, MTX)
+  };
+  {
+    int t = 0;
+#if G256_PEEL
+    if (p.conv_C > 0) for (; t + 2 < nt; ++t) ktile(t, std::true_type{}, std::integral_constant<int, 2>{});
+    else for (; t + 2 < nt; ++t) ktile(t, std::true_type{}, std::integral_constant<int, 1>{});
+#endif
+    for (; t < nt; ++t) ktile(t, std::false_type{}, std::integral_constant<int, 0>{});
   }
   PH_FLUSH
   if (wm == 0) __builtin_amdgcn_s_barrier();  // re-align the groups (same barrier count for every wave)

@@ -241,7 +241,7 @@ class VitEngine:
         # every buffer the launches address, taken up front: the zero-padding bookkeeping of k / vt runs on every call
         # (replayed or not) and the addresses key the graph
         ops._chk(images, F32, "images")
-        graph = not fp8 and TRACE is None and GraphPool.enabled
+        graph = TRACE is None and GraphPool.enabled
         if graph:  # the caller's tensor moves from call to call: stage it
             img = ws.get("vit_img", images.shape, F32)
             img.copy_(images)
@@ -262,6 +262,9 @@ class VitEngine:
         # the shared eager arena of ops (which must not be born or regrown inside a capture)
         n_sk = ops.plan_ws_elems(M, [(3 * D, D), (D, D), (I, D), (D, I)])
         skw = ws.get("vit_splitk", (n_sk,), F32) if n_sk else None
+        # e4m3 operands: the quantised rows and their scales live in arenas too (round 5: the e4m3 launch sequence is captured like
+        # the 16-bit one; rounds 3-4 allocated them per launch and ran eagerly)
+        q8 = {K_: (ws.get(f"vit_q8_{K_}", (M, K_), ops.FP8), ws.get(f"vit_s8_{K_}", (M,), F32)) for K_ in ((D, I) if fp8 else ())}
 
         def out_buf(layer_out_index):  # hidden_states index (0 = embeddings ... nl = last layer)
             j = layer_out_index - (nl + 1 - self.keep)
@@ -270,7 +273,7 @@ class VitEngine:
         def lin(x_f32, ln_g, ln_b, wt, tag=None, **kw):
             """LayerNorm -> GEMM (bf16 operands, or e4m3 operands with dynamic per-row activation scales)"""
             if fp8:
-                x8, sx = ops.norm_fp8(x_f32, ln_g, ln_b, self.eps, False)
+                x8, sx = ops.norm_fp8(x_f32, ln_g, ln_b, self.eps, False, out=q8[x_f32.shape[-1]])
                 _trace_q8(tag, x8, sx)
                 return ops.gemm(x8, wt[0], a_scale=sx, w_scale=wt[1], **kw)
             x = ops.layernorm(x_f32, ln_g, ln_b, self.eps, out_bf16=True, out=x_b)
@@ -280,7 +283,7 @@ class VitEngine:
 
         def lin_bf16(x_bf16, wt, tag=None, **kw):
             if fp8:
-                x8, sx = ops.quant_rows_fp8(x_bf16)
+                x8, sx = ops.quant_rows_fp8(x_bf16, out=q8[x_bf16.shape[-1]])
                 _trace_q8(tag, x8, sx)
                 return ops.gemm(x8, wt[0], a_scale=sx, w_scale=wt[1], **kw)
             return ops.gemm(x_bf16, wt[0], split_ws=skw, **kw)
@@ -313,8 +316,9 @@ class VitEngine:
                 h = hn
 
         if graph:
-            bufs = [img, a, mid, k, vt, x_b, qkv_b, ctx_b, y_b] + kept + scratch + ([] if q is None else [q]) + ([] if skw is None else [skw])
-            self.graphs.run(("vit", bs, ops._PLAN[0]) + tuple(t.data_ptr() for t in bufs), launch)
+            bufs = [img, a, mid, k, vt, x_b, qkv_b, ctx_b, y_b] + kept + scratch + ([] if q is None else [q]) + ([] if skw is None else [skw]) \
+                + [t for pair in q8.values() for t in pair]
+            self.graphs.run(("vit", bs, ops._PLAN[0], fp8) + tuple(t.data_ptr() for t in bufs), launch)
         else:
             launch()
         first = nl + 1 - self.keep
@@ -607,7 +611,8 @@ class LlamaEngine:
         skw = buf("llm_splitk", (n_sk,), F32) if n_sk else None  # caller-owned split-K workspace: see VitEngine.forward
         # a prefill whose shape and memory repeat is replayed from a captured hipGraph (GraphPool): everything the launches
         # bake in goes into the key; the ragged-row lengths are staged into a buffer of our own
-        graph = not dec and not fp8 and TRACE is None and GraphPool.enabled and states is None
+        graph = not dec and TRACE is None and GraphPool.enabled and states is None
+        q8 = {K_: (buf(f"llm_q8_{K_}", (M, K_), ops.FP8), buf(f"llm_s8_{K_}", (M,), F32)) for K_ in ((T, self.I) if fp8 else ())}
         if graph and kv_len is not None:
             kvl = ws.get("llm_kvlen", (bs,), I32)
             kvl.copy_(kv_len)
@@ -616,7 +621,7 @@ class LlamaEngine:
         def lin(x_f32, gain, wt, tag=None, **kw):
             """RMSNorm -> GEMM (bf16 operands, or e4m3 operands with dynamic per-row activation scales)"""
             if fp8:
-                x8, sx = ops.norm_fp8(x_f32, gain, None, self.eps, True)
+                x8, sx = ops.norm_fp8(x_f32, gain, None, self.eps, True, out=q8[x_f32.shape[-1]])
                 _trace_q8(tag, x8, sx)
                 return ops.gemm(x8, wt[0], a_scale=sx, w_scale=wt[1], **kw)
             x = ops.rmsnorm(x_f32, gain, self.eps, out=x_b)
@@ -626,7 +631,7 @@ class LlamaEngine:
 
         def lin_bf16(x_bf16, wt, tag=None, **kw):
             if fp8:
-                x8, sx = ops.quant_rows_fp8(x_bf16)
+                x8, sx = ops.quant_rows_fp8(x_bf16, out=q8[x_bf16.shape[-1]])
                 _trace_q8(tag, x8, sx)
                 return ops.gemm(x8, wt[0], a_scale=sx, w_scale=wt[1], **kw)
             return ops.gemm(x_bf16, wt[0], split_ws=skw, **kw)
@@ -661,8 +666,9 @@ class LlamaEngine:
                     _trace("llm0.h_out", h)
 
         if graph:
-            bufs = [h, x_b, qkv_b, ctx_b, y_b] + ([] if q is None else [q]) + ([] if kv_len is None else [kv_len]) + ([] if skw is None else [skw])
-            self.graphs.run(("llm", bs, L, past, kv_len is None, ops._PLAN[0]) + tuple(t.data_ptr() for t in bufs)
+            bufs = [h, x_b, qkv_b, ctx_b, y_b] + ([] if q is None else [q]) + ([] if kv_len is None else [kv_len]) + ([] if skw is None else [skw]) \
+                + [t for pair in q8.values() for t in pair]
+            self.graphs.run(("llm", bs, L, past, kv_len is None, ops._PLAN[0], fp8) + tuple(t.data_ptr() for t in bufs)
                             + cache_addresses(cache), launch)
         else:
             launch()

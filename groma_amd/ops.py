@@ -738,24 +738,35 @@ def prof_read_launches(cap=65536):
     return [(int(mnk[i, 0]), int(mnk[i, 1]), int(mnk[i, 2]), int(mnk[i, 3]), float(ms[i])) for i in range(k)]
 
 
-def quant_rows_fp8(x):
-    """x bf16|f32 [rows, K] -> (q e4m3 [rows, K], scale f32 [rows]) with x ~= q * scale[:, None]"""
+def quant_rows_fp8(x, out=None):
+    """x bf16|f32 [rows, K] -> (q e4m3 [rows, K], scale f32 [rows]) with x ~= q * scale[:, None].
+    out = (q, s): caller-owned buffers (launch sequences replayed from a hipGraph bake their addresses)"""
     lib = _lib.load()
     K = x.shape[-1]
     rows = x.numel() // K
-    q = torch.empty((rows, K), dtype=FP8, device=x.device)
-    s = torch.empty((rows,), dtype=F32, device=x.device)
+    if out is not None:
+        q, s = _chk(out[0], FP8, "q"), _chk(out[1], F32, "s")
+        if q.numel() != rows * K or s.numel() != rows:
+            raise ValueError("quant_rows_fp8: out buffers do not match the input")
+    else:
+        q = torch.empty((rows, K), dtype=FP8, device=x.device)
+        s = torch.empty((rows,), dtype=F32, device=x.device)
     _lib.check(lib.gr_quant_rows_fp8(_p(x), int(x.dtype == F32), _p(q), _p(s), rows, K, K, _stream()), "gr_quant_rows_fp8")
     return q, s
 
 
-def norm_fp8(x, gamma, beta, eps, rms):
-    """RMSNorm / LayerNorm of f32 rows, emitted as e4m3 + per-row scale"""
+def norm_fp8(x, gamma, beta, eps, rms, out=None):
+    """RMSNorm / LayerNorm of f32 rows, emitted as e4m3 + per-row scale; out = (q, s): caller-owned buffers"""
     lib = _lib.load()
     _chk(x, F32, "x")
     C = x.shape[-1]
     rows = x.numel() // C
-    q = torch.empty((rows, C), dtype=FP8, device=x.device)
-    s = torch.empty((rows,), dtype=F32, device=x.device)
+    if out is not None:
+        q, s = _chk(out[0], FP8, "q"), _chk(out[1], F32, "s")
+        if q.numel() != rows * C or s.numel() != rows:
+            raise ValueError("norm_fp8: out buffers do not match the input")
+    else:
+        q = torch.empty((rows, C), dtype=FP8, device=x.device)
+        s = torch.empty((rows,), dtype=F32, device=x.device)
     _lib.check(lib.gr_norm_fp8(_p(x), _p(gamma), _p(beta), _p(q), _p(s), rows, C, eps, int(rms), _stream()), "gr_norm_fp8")
     return q, s

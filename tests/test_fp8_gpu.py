@@ -111,3 +111,30 @@ def test_fp8_generate_graph_equals_eager(setup):
     torch.manual_seed(11)
     g16 = m16.generate(ids.clone(), images=images, max_new_tokens=6).cpu()
     print("fp8 tokens", new.tolist(), "bf16 tokens", g16[:, ids.shape[1]:].tolist())
+
+
+def test_fp8_prefill_graphs_equal_eager(setup):
+    """Round 5: the e4m3 launch sequences (ViT layers, LLaMA prefill layers) are captured and replayed like the 16-bit ones -- their
+    quantised rows and scales live in workspace arenas whose addresses key the graph (rounds 3-4 ran the e4m3 model eagerly).
+    Replays must be bitwise the eager results, for new pixels and for another batch shape through the same arenas in between."""
+    cfg, sd, tk, m16, m8, images, ids = setup
+    from groma_amd import engine, synth
+    images_b, _ = synth.make_inputs(cfg, tk, bs=2, seed=78)
+
+    def run(img, n=2):
+        torch.manual_seed(5)
+        return m8.forward(input_ids=ids[:n].clone(), images=img[:n].cuda(), return_dict=True).logits.clone()
+
+    engine.GraphPool.enabled = False
+    try:
+        ea, eb, e1 = run(images), run(images_b), run(images, n=1)
+    finally:
+        engine.GraphPool.enabled = True
+    m8.vit.graphs.clear(), m8.llm.graphs.clear()
+    v0, l0 = m8.vit.graphs.replays, m8.llm.graphs.replays
+    for _ in range(4):                               # eager, eager, capture + replay, replay
+        assert torch.equal(run(images), ea)
+    assert torch.equal(run(images_b), eb)
+    assert torch.equal(run(images, n=1), e1)
+    assert torch.equal(run(images), ea)
+    assert m8.vit.graphs.replays > v0 and m8.llm.graphs.replays > l0
