@@ -244,11 +244,45 @@ def run_dry_exchange(args, rank, world):
         return pack_rows(heads, boxes)
 
     last = {}
+    # --host-glue: every rank also runs, per step, the REAL host code a forward executes between the NMS result and the LLaMA
+    # launches (GromaModel._host_select: CPU-RNG shuffles + gather lists; _host_splice_plan: placeholder splice, scatter rows) for its
+    # share of the batch -- no model weights, no device -- so `host_glue_us_per_step` is that code's cost under N-way contention
+    # for the host cores (multi-GPU readiness needs a host-side number while no 8-GPU box is available)
+    glue_us = []
+    if args.host_glue:
+        import time as _time
+        from groma_amd import config as gconfig, constants
+        from groma_amd.groma import GromaModel
+        gm = GromaModel(gconfig.groma_7b(box_score_thres=0.0))
+        gm.init_special_token_id(constants.SyntheticTokenizer())
+        from groma_amd import synth
+        _, prompt_ids = synth.make_inputs(gconfig.groma_tiny(), gm, max(job.rows, 1), seed=7, prompt_len=128)
+        keep_h = torch.stack([torch.randperm(300)[:100] for _ in range(max(job.rows, 1))])
+
+        def host_glue():
+            t0 = _time.perf_counter()
+            sel_idx, flat_sel, img_of = GromaModel._host_select(keep_h, [100] * keep_h.shape[0], 300)
+            plan = gm._host_splice_plan(prompt_ids.clone(), 256, [int(x.numel()) for x in sel_idx])
+            glue_us.append((_time.perf_counter() - t0) * 1e6)
+            return plan
 
     def step(i):
+        if args.host_glue and job.rows:
+            host_glue()
         last["i"], last["out"] = i, job.exchange(rows_of(job.lo, job.hi, i)) if job.rows else job.exchange(torch.zeros((0, head + ROW_BOXES + 1)))
         return last["out"]
     elapsed = job.timed(step, args.warmup, args.steps)
+    glue = None
+    if args.host_glue:   # median over this rank's timed steps, then max / min over ranks
+        mine = sorted(glue_us[-args.steps:])[len(glue_us[-args.steps:]) // 2] if glue_us else 0.0
+        t = torch.tensor([mine], dtype=torch.float64)
+        hi, lo = t.clone(), t.clone()
+        if world > 1:
+            import torch.distributed as dist
+            dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+            dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        glue = {"host_glue_us_per_step_rank_max": float(hi), "host_glue_us_per_step_rank_min": float(lo), "images_per_rank": job.rows,
+                "host_threads_per_rank": torch.get_num_threads(), "host_cores": os.cpu_count()}
     ok = torch.equal(last["out"], rows_of(0, job.global_batch, last["i"]))
     if rank == 0:
         print(json.dumps({"metric": "dry exchange (no model)", "value": job.global_batch * args.steps / elapsed, "unit": "rows/s",
@@ -257,7 +291,8 @@ def run_dry_exchange(args, rank, world):
                           "mode": args.mode, "row_width": head + ROW_BOXES + 1,
                           "ms_per_step_rank_max": job.last_elapsed_max / max(args.steps, 1) * 1e3,
                           "ms_per_step_rank_min": job.last_elapsed_min / max(args.steps, 1) * 1e3,
-                          "exchange_ok": bool(ok), "exchanged_regions": int(last["out"][:, -1].sum().item())}), flush=True)
+                          "exchange_ok": bool(ok), "exchanged_regions": int(last["out"][:, -1].sum().item()),
+                          **({"host_glue": glue} if glue else {})}), flush=True)
     if world > 1:
         import torch.distributed as dist
         dist.barrier()
@@ -532,6 +567,9 @@ def main():
     ap.add_argument("--cpu-baseline-reps", type=int, default=3,
                     help="timed full-depth oracle forwards after the reduced-depth warm-up; the median is reported (BASELINE.md 3)")
     ap.add_argument("--gemm-breakdown", default=None, help="write a per-shape GEMM table (from the HIP-event hook) here")
+    ap.add_argument("--host-glue", action="store_true",
+                    help="with --dry-exchange: every rank also runs the forward's real host-side glue (CPU-RNG shuffles, placeholder "
+                         "splice, scatter-row lists) per step and the JSON reports its microseconds per step under N-way host contention")
     ap.add_argument("--dry-exchange", action="store_true",
                     help="launcher / process-group / exchange / timing path only, with synthetic rows on CPU (gloo); no model")
     args = ap.parse_args()
@@ -546,6 +584,7 @@ def main():
     if args.gpus != world:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch one process per GPU (or let `python bench.py --gpus N` do it)")
     if args.dry_exchange:
+        pin_host_threads(local_rank, world)
         raise SystemExit(run_dry_exchange(args, rank, world))
     if torch.cuda.device_count() <= local_rank:
         raise SystemExit(f"rank {rank}: LOCAL_RANK {local_rank} but {torch.cuda.device_count()} GPU(s) visible")

@@ -103,6 +103,11 @@ __global__ __launch_bounds__(256, GR_SP ? 1 : 2) void attention_kernel(AttnArgs 
   constexpr int VROW = KV * 2 * SPW;  // bytes per V^T tile row (128; split build 256)
   constexpr int VCH = VROW / 16;
   constexpr int VTILE = HD * VROW;    // Vt tile [HD][64] bf16
+#ifdef ATT_R04_PAIR  // A/B only (tests/diag): round 4's pair-build soft-max split and V^T swizzle
+  constexpr int VSWZ = 7;
+#else
+  constexpr int VSWZ = VCH - 1;       // V^T chunk swizzle mask: all chunk positions of a row (8, or 16 in the pair build)
+#endif
   constexpr int STAGE = KTILE + VTILE;
   // Key order inside a 64-key tile: MFMA row i of score sub-tile j holds key (j>>1)*32 + (i>>2)*8 + (j&1)*4 + (i&3),
   // so that after S^T = K.Q^T a lane (k-group fg) owns keys 32*tt + fg*8 + {0..7} of query fr: exactly the 8
@@ -169,7 +174,7 @@ __global__ __launch_bounds__(256, GR_SP ? 1 : 2) void attention_kernel(AttnArgs 
     for (int i = 0; i < NVC / 256; ++i) {
       const int q = i * 256 + tid;
       const int row = q / VCH, pos = q % VCH;
-      const int c = pos ^ (row & 7);
+      const int c = pos ^ (row & VSWZ);
       __builtin_amdgcn_global_load_lds((gptr_t)(Vp + ((long)row * p.kv_stride + kv0) * SPW + c * 8),
                                        (lptr_t)(vsm + i * 4096 + wave * 1024), 16, 0, 0);
     }
@@ -378,10 +383,15 @@ __global__ __launch_bounds__(256, GR_SP ? 1 : 2) void attention_kernel(AttnArgs 
 #pragma unroll
         for (int tt = 0; tt < 2; ++tt) {
 #if GR_SP
-          split2(s[u][2 * tt][0], s[u][2 * tt][1], pb[u][tt].w[0], pbl[u][tt].w[0]);
-          split2(s[u][2 * tt][2], s[u][2 * tt][3], pb[u][tt].w[1], pbl[u][tt].w[1]);
-          split2(s[u][2 * tt + 1][0], s[u][2 * tt + 1][1], pb[u][tt].w[2], pbl[u][tt].w[2]);
-          split2(s[u][2 * tt + 1][2], s[u][2 * tt + 1][3], pb[u][tt].w[3], pbl[u][tt].w[3]);
+#ifdef ATT_R04_PAIR
+#define ATT_SPLIT_P split2
+#else
+#define ATT_SPLIT_P split2_unit   // (P in [0, 1]: no saturation)
+#endif
+          ATT_SPLIT_P(s[u][2 * tt][0], s[u][2 * tt][1], pb[u][tt].w[0], pbl[u][tt].w[0]);
+          ATT_SPLIT_P(s[u][2 * tt][2], s[u][2 * tt][3], pb[u][tt].w[1], pbl[u][tt].w[1]);
+          ATT_SPLIT_P(s[u][2 * tt + 1][0], s[u][2 * tt + 1][1], pb[u][tt].w[2], pbl[u][tt].w[2]);
+          ATT_SPLIT_P(s[u][2 * tt + 1][2], s[u][2 * tt + 1][3], pb[u][tt].w[3], pbl[u][tt].w[3]);
 #else
           pb[u][tt].w[0] = pack2bf_unit(s[u][2 * tt][0], s[u][2 * tt][1]);
           pb[u][tt].w[1] = pack2bf_unit(s[u][2 * tt][2], s[u][2 * tt][3]);
@@ -405,9 +415,11 @@ __global__ __launch_bounds__(256, GR_SP ? 1 : 2) void attention_kernel(AttnArgs 
         const int step = g * GV + e, tt = step / (HD / 16), n = step % (HD / 16);
         const int row = n * 16 + fr;      // d index
         const int c = tt * 4 * SPW + fg;  // keys 32*tt + fg*8 .. +7 = one 16-B chunk of the Vt row
-        dst[e] = *(const bf16x8*)(vsm + row * VROW + ((c ^ (row & 7)) << 4));
+        // chunk swizzle over ALL chunk positions of a V^T row: 8 in the 16-bit builds, 16 in the pair build (256-B rows start on
+        // bank 0 there, and `row & 7` left the 16 rows a ds_read_b128 lane group touches 2-way conflicted -- round 5)
+        dst[e] = *(const bf16x8*)(vsm + row * VROW + ((c ^ (row & VSWZ)) << 4));
 #if GR_SP
-        dst[GV + e] = *(const bf16x8*)(vsm + row * VROW + (((c + 4) ^ (row & 7)) << 4));
+        dst[GV + e] = *(const bf16x8*)(vsm + row * VROW + (((c + 4) ^ (row & VSWZ)) << 4));
 #endif
       }
     };

@@ -343,8 +343,12 @@ __global__ __launch_bounds__(NT) void G256_KERNEL(GemmArgs p) {
   // `tile < nt` tests compiled to ~8 s_cbranch per K-tile inside the LOAD segments (seen in the ISA: wait-count variants and the
   // guarded LDS-DMA issues as separate basic blocks) -- taken branches on the segment that has to stay shorter than the partner's
   // 512-clk MFMA segment.  Same instructions in the same order per accumulator: bitwise identical.  -DG256_PEEL=0 = the old form.
+  // Measured on one box, builds alternating in one process (tests/diag/gemm_variants.py, profiles/r05_gemm_peel_ab.txt): bf16
+  // build -1.8 % over the step's GEMM launches (gate-up 1021 -> 1007 us, down 532 -> 523, lm_head 1563 -> 1531, 3x3 conv at 128^2
+  // 2956 -> 2803, QKV unchanged); the operand-pair build, whose MFMA segments are 48 long and already cover its load segments,
+  // is 1.9 % SLOWER peeled (fc1 317 -> 325 us, fc2 280 -> 288) and keeps the single loop.
 #ifndef G256_PEEL
-#define G256_PEEL 1
+#define G256_PEEL (GR_SP ? 0 : 1)
 #endif
   auto ktile = [&](int t, auto steady_c, auto amode_c) {
     constexpr bool STEADY_C = decltype(steady_c)::value;

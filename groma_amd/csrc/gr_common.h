@@ -94,6 +94,18 @@ __device__ __forceinline__ void split2(float a, float b, uint32_t& hi, uint32_t&
   lo = 0;
 #endif
 }
+// the same for values known to lie in [0, 1] (soft-max probabilities): neither half can leave the half range, so no saturation --
+// the general form costs 4 v_med3 + 4 scalar conversions + a pack per pair, and P is split for EVERY score of the pair attention
+// (round 5: that split was 2/3 of the kernel's VALU work, which is what bounds it)
+__device__ __forceinline__ void split2_unit(float a, float b, uint32_t& hi, uint32_t& lo) {
+  hi = pack2bf_unit(a, b);
+#if GR_SP
+  const h16x2_hw h = __builtin_bit_cast(h16x2_hw, hi);
+  lo = pack2bf_unit(a - (float)h[0], b - (float)h[1]);
+#else
+  lo = 0;
+#endif
+}
 __device__ __forceinline__ float ld1f(const bf16_t* base, long i) {
   const long p = sp_idx(i);
   float v = bf2f(base[p]);

@@ -153,6 +153,23 @@ class GraphPool:
     enabled = True
 
     CAPTURE_AT = 3
+    _first_sight = ops._lib.ThreadSlot(False)   # per thread: capture a key the FIRST time it is seen (GraphPool.first_sight())
+
+    @classmethod
+    def first_sight(cls):
+        """with GraphPool.first_sight(): ...  -- every pool captures a new key on its first sighting inside the block instead of
+        its third.  For warm-up passes whose shapes are known to recur (serving.ContinuousBatcher.warm_admission): the capture
+        passes then happen before live traffic, not inside the first three live requests of a shape."""
+        import contextlib
+
+        @contextlib.contextmanager
+        def ctx():
+            prev, cls._first_sight[0] = cls._first_sight[0], True
+            try:
+                yield
+            finally:
+                cls._first_sight[0] = prev
+        return ctx()
 
     def __init__(self, cap=16, byte_budget=2 << 30):
         # cap: graphs kept (LRU); byte_budget: device memory the graphs' private pools may pin in total (what a capture reserved is
@@ -172,7 +189,7 @@ class GraphPool:
             self.replays += 1
             return
         n = self._seen.pop(key, 0) + 1
-        if n < GraphPool.CAPTURE_AT:
+        if n < GraphPool.CAPTURE_AT and not GraphPool._first_sight[0]:
             self._seen[key] = n
             if len(self._seen) > 256:
                 self._seen.popitem(last=False)
@@ -196,13 +213,22 @@ class GraphPool:
         g = torch.cuda.CUDAGraph()
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(cur)
+        err = None
         with torch.cuda.stream(side):
             g.capture_begin(capture_error_mode="thread_local")
             try:
                 launch()
-            finally:
-                g.capture_end()
-        cur.wait_stream(side)
+            except BaseException as e:   # a launch that raises (GR_EINVAL, a workspace requested inside the capture) invalidates the capture
+                err = e
+            try:
+                g.capture_end()          # always end it: a dangling capture would poison every later launch on this stream
+            except Exception:
+                if err is None:
+                    raise
+        cur.wait_stream(side)            # (the streams are re-joined whatever happened)
+        if err is not None:
+            self._seen.pop(key, None)    # nothing is kept; the key starts counting again
+            raise err                    # the ORIGINAL error, not the secondary one from ending a broken capture
         self._graphs[key] = g
         self._bytes[key] = max(0, torch.cuda.memory_reserved(dev) - before)
         self.captures += 1
@@ -436,17 +462,38 @@ class RegionEngine:
             pads += [ws.get(f"reg_pad8{l}", (bs, S[l] + 2, S[l] + 2, D), ops.FP8, zero=True) for l in range(3)]
         bufs = list(hidden3) + feats + pads + [ws.get(f"reg_in{l}", h16(bs * S[l] * S[l], D), H16()) for l in range(3)] + \
             [ws.get(f"reg_conv{l}_{r}", h16(bs * S[l] * S[l], D), H16()) for l in range(3) for r in range(min(2, rc.num_fuse))]
+        # every temporary of the launch sequence lives in an arena too (round 5): the packed inputs of the 1x1 convs
+        # (0.65 GB at 14 images), the GroupNorm partial sums / coefficients and the split-K workspace of the plan-split GEMMs --
+        # none of them is born inside a capture any more, so a captured batch shape pins nothing in a private graph pool
+        bufs += self._fuse_temps(bs, S)
         self.graphs.run(("fuse", bs, ops._PLAN[0]) + tuple(t.data_ptr() for t in bufs), lambda: self._fuse_launch(hidden3))
         return feats, S
+
+    def _fuse_temps(self, bs, S):
+        """the arena views _fuse_launch works in besides its maps (the same views on every call with the same shapes)"""
+        ws, rc, D, Cpad = self.ws, self.rc, self.D, self.w["Cpad"]
+        t = {}
+        for l in range(3):
+            HW = S[l] * S[l]
+            t[f"up{l}"] = ws.get(f"reg_up{l}", h16(bs * HW, Cpad), H16())
+            for r in range(min(2, rc.num_fuse)):   # the coefficients of round r are read while round r + 1 writes its own
+                t[f"sums{l}_{r}"] = ws.get(f"reg_gns{l}_{r}", (bs, ops.gn_stats_blocks(HW), D, 2), F32)
+                t[f"coef{l}_{r}"] = ws.get(f"reg_gnc{l}_{r}", (bs, 2, D), F32)
+        n_sk = max(ops.plan_ws_elems(bs * S[l] * S[l], [(D, Cpad)]) for l in range(3))
+        if n_sk:
+            t["splitk"] = ws.get("reg_splitk", (n_sk,), F32)
+        self._ft = t
+        return list(t.values())
 
     def _fuse_launch(self, hidden3):
         w, ws, rc, D, G = self.w, self.ws, self.rc, self.D, self.G
         bs = hidden3[0].shape[0]
         S = [G * 4, G * 2, G]
         maps, sums = [], [None, None, None]
+        ft = self._ft   # (set by fuse() for exactly these shapes)
         for l in range(3):
-            a = _trace(f"reg.up{l}", ops.upsample_coord_pack(hidden3[l], G, S[l], w["Cpad"]))
-            maps.append(_trace(f"reg.in{l}", ops.gemm(a, w["in_w"][l], bias=w["in_b"][l],
+            a = _trace(f"reg.up{l}", ops.upsample_coord_pack(hidden3[l], G, S[l], w["Cpad"], out=ft[f"up{l}"]))
+            maps.append(_trace(f"reg.in{l}", ops.gemm(a, w["in_w"][l], bias=w["in_b"][l], split_ws=ft.get("splitk"),
                                                       out=ws.get(f"reg_in{l}", h16(bs * S[l] * S[l], D), H16()))))
         for r in range(rc.num_fuse):
             new_maps, new_coef = [], []
@@ -470,7 +517,8 @@ class RegionEngine:
                     _trace(f"reg.pad{l}", pad), _trace(f"reg.conv{l}", out)
                 new_maps.append(out)
                 # GN of THIS round's conv (fuse_convs[r].gn), applied where the map is consumed next
-                new_coef.append(ops.gn_coef(out, bs, S[l] * S[l], D, rc.gn_groups, w["fuse"][r]["g"], w["fuse"][r]["b"], 1e-5))
+                new_coef.append(ops.gn_coef(out, bs, S[l] * S[l], D, rc.gn_groups, w["fuse"][r]["g"], w["fuse"][r]["b"], 1e-5,
+                                            sums=ft[f"sums{l}_{r & 1}"], coef=ft[f"coef{l}_{r & 1}"]))
             maps, sums = new_maps, new_coef
         feats = []
         for l in range(3):

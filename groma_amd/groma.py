@@ -63,6 +63,13 @@ def _box_iou(b1, b2):  # torchvision.ops.box_iou on a handful of host-side boxes
 # precision="hybrid" / "hybrid-fp16": (operand type behind the ViT, operand type of the ViT)
 HYBRID_MODES = {"hybrid": ("bf16", "ref"), "hybrid-fp16": ("fp16", "ref")}
 
+def _img_of(counts):
+    """[0] * counts[0] + [1] * counts[1] + ... as an int64 tensor.  Not torch.repeat_interleave: with a many-thread intra-op pool it
+    opens a parallel region for a few hundred elements -- measured 5.2 ms against 23 us single-threaded (8 threads on 8 busy cores),
+    inside the one window of a forward in which the GPU waits for the host"""
+    return torch.cat([torch.full((int(c),), i, dtype=I64) for i, c in enumerate(counts)]) if len(counts) else torch.empty((0,), dtype=I64)
+
+
 _entry = engine.model_entry(lambda self, *a, **kw: self.precision)  # every boundary entry point: see engine.normal_mode / ops.precision
 
 
@@ -344,7 +351,9 @@ class GromaModel:
             if spec["rng"] is not None:
                 torch.set_rng_state(spec["rng"])   # mis-speculated: nothing was consumed as far as the ordinary path can tell
         sel_idx = []
-        for i, nk in enumerate(n_keep_l):   # (a handful of host ops per image: this loop sits between the sync and the next launch)
+        if seeds is None and all(int(nk) > 0 for nk in n_keep_l):
+            sel_idx = self._host_select(keep_h, n_keep_l, nmax)[0]   # (the same draws in the same order as the loop below)
+        for i, nk in enumerate(n_keep_l if not sel_idx else ()):   # (a handful of host ops per image: this loop sits between the sync and the next launch)
             if nk > 0:  # groma.py:273-276 -- torch.randperm on the CPU global RNG (T4)
                 if seeds is not None and seeds[i] is not None:
                     # serving: each request owns its shuffle seed.  A local generator yields exactly what the global RNG
@@ -361,7 +370,7 @@ class GromaModel:
         R = sum(n_sel)
         stage = self._pinned("sel", 2 * R)
         counts = torch.tensor(n_sel)
-        img_of = torch.repeat_interleave(torch.arange(bs), counts)
+        img_of = _img_of(n_sel)
         torch.add(torch.cat(sel_idx), img_of, alpha=nmax, out=stage[:R])
         stage[R:2 * R] = img_of
         sel_dev = stage[:2 * R].to(dev, non_blocking=True)
@@ -384,7 +393,7 @@ class GromaModel:
                              if (seeds is not None and seeds[i] is not None) else torch.randperm(n) for i in range(bs)])   # image order (T4)
         R = bs * n
         stage = self._pinned("spec", 2 * R)
-        img_of = torch.arange(bs).repeat_interleave(n)
+        img_of = torch.arange(bs)[:, None].expand(bs, n).reshape(-1)   # (not repeat_interleave: see _img_of)
         torch.add(perms.reshape(-1), img_of, alpha=n, out=stage[:R])      # position of the j-th selected entry inside keep [bs, n]
         stage[R:2 * R] = img_of
         sd = stage[:2 * R].to(dev, non_blocking=True)
@@ -458,21 +467,53 @@ class GromaModel:
 
     def _splice(self, input_ids_h, n_img_tok, n_reg):
         """groma.py:317-357 on the host (index bookkeeping only)."""
+        # (round 5: the placeholder runs are slices of two cached tensors and the positions come from plain-Python scans of the row --
+        #  per image the reference's tensor-by-tensor form cost ~130 us of dispatch here, 1.8 ms per 14-image batch inside the window in
+        #  which the GPU waits for the host; same ids, tests/test_host_logic.py::test_splice_matches_oracle...)
+        ph = self.__dict__.get("_splice_ph")
+        if ph is None or ph[0] != (n_img_tok, self.img_token_id, self.reg_token_id, tuple(self.box_idx_token_ids)):
+            pairs = torch.tensor([[b, self.reg_token_id] for b in self.box_idx_token_ids], dtype=I64).reshape(-1)
+            ph = self._splice_ph = ((n_img_tok, self.img_token_id, self.reg_token_id, tuple(self.box_idx_token_ids)),
+                                    torch.full((n_img_tok,), self.img_token_id, dtype=I64), pairs)
+        img_ph, pairs = ph[1], ph[2]
+        rows = input_ids_h.tolist()
         new_ids = []
-        for i in range(input_ids_h.shape[0]):
+        for i, row in enumerate(rows):
             ids = input_ids_h[i]
-            assert self.img_token_id in ids and self.reg_token_id in ids
-            img_pos = (ids == self.img_token_id).nonzero(as_tuple=True)[0]
-            reg_pos = (ids == self.reg_token_id).nonzero(as_tuple=True)[0]
-            pad_pos = (ids == self.pad_token_id).nonzero(as_tuple=True)[0]
-            pad_pos = pad_pos[0] if len(pad_pos) > 0 else len(ids)
+            assert self.img_token_id in row and self.reg_token_id in row
+            img_pos, reg_pos = row.index(self.img_token_id), row.index(self.reg_token_id)
+            if row.count(self.img_token_id) != 1 or row.count(self.reg_token_id) != 1:
+                # the reference evaluates `assert img_pos < reg_pos` on position TENSORS: more than one <image> / <region> fails there with
+                raise RuntimeError("Boolean value of Tensor with more than one value is ambiguous")   # (same class, same text)
+            pad_pos = row.index(self.pad_token_id) if self.pad_token_id in row else len(row)
             assert img_pos < reg_pos
-            img_ph = torch.full((n_img_tok,), self.img_token_id)
-            reg_ph = torch.tensor([[self.box_idx_token_ids[j], self.reg_token_id] for j in range(n_reg[i])],
-                                  dtype=I64).reshape(-1)
-            new_ids.append(torch.cat((ids[:img_pos], img_ph, ids[img_pos + 1: reg_pos], reg_ph, ids[reg_pos + 1: pad_pos])))
-        out = torch.nn.utils.rnn.pad_sequence(new_ids, batch_first=True, padding_value=self.pad_token_id)
+            if n_reg[i] > len(self.box_idx_token_ids):
+                raise IndexError("more regions than <r_k> tokens")
+            new_ids.append(torch.cat((ids[:img_pos], img_ph, ids[img_pos + 1: reg_pos], pairs[: 2 * n_reg[i]], ids[reg_pos + 1: pad_pos])))
+        if len({int(x.numel()) for x in new_ids}) == 1:
+            out = torch.stack(new_ids)
+        else:
+            out = torch.nn.utils.rnn.pad_sequence(new_ids, batch_first=True, padding_value=self.pad_token_id)
         return out, out.ne(self.pad_token_id)
+
+    def _host_splice_plan(self, ids_h, n_img_tok, n_reg):
+        """The host side of groma.py:317-369 for one batch: spliced ids + mask, and the rows of the flattened sequence that receive
+        image / region features.  Pure host code (no device value enters or leaves): this and _host_select() are everything a
+        forward does on the CPU between the NMS result and the LLaMA launches -- what `bench.py --dry-exchange --host-glue` times
+        under N-way host contention."""
+        new_ids_h, mask_h = self._splice(ids_h, n_img_tok, n_reg)
+        flat = new_ids_h.reshape(-1)
+        img_rows_h = (flat == self.img_token_id).nonzero(as_tuple=True)[0]
+        reg_rows_h = (flat == self.reg_token_id).nonzero(as_tuple=True)[0]
+        return new_ids_h, mask_h, flat, img_rows_h, reg_rows_h
+
+    @staticmethod
+    def _host_select(keep_h, n_keep_l, nmax):
+        """The CPU-RNG shuffle of the kept proposals (groma.py:273-276, T4) and the flat gather list the device selection uses, as
+        propose() builds them on a mis-speculated / ragged batch (the general path; host tensors in, host tensors out)"""
+        sel_idx = [keep_h[i].index_select(0, torch.randperm(int(nk))) for i, nk in enumerate(n_keep_l)]
+        img_of = _img_of([int(x.numel()) for x in sel_idx])
+        return sel_idx, torch.cat(sel_idx) + img_of * nmax, img_of
 
     # ------------------------------------------------------------------ forward
     @_entry
@@ -544,13 +585,10 @@ class GromaModel:
                 n_reg = [b.shape[0] for b in selected_boxes]
                 n_img_tok = (self.vit.G // 2) ** 2  # image tokens: groma.py:224-237, :361 (computed on the side stream)
                 # splice placeholders, embed, inject (groma.py:317-369)
-                new_ids_h, mask_h = self._splice(ids_h, n_img_tok, n_reg)
+                new_ids_h, mask_h, flat, img_rows_h, reg_rows_h = self._host_splice_plan(ids_h, n_img_tok, n_reg)
                 if labels is not None:
                     labels = self._splice_labels(ids_h, labels.cpu(), n_img_tok, n_reg)
                 L = new_ids_h.shape[1]
-                flat = new_ids_h.reshape(-1)
-                img_rows_h = (flat == self.img_token_id).nonzero(as_tuple=True)[0]
-                reg_rows_h = (flat == self.reg_token_id).nonzero(as_tuple=True)[0]
                 assert img_rows_h.numel() == image_features.shape[0] and reg_rows_h.numel() == region_features.shape[0]
                 # spliced ids + the two scatter-row lists in ONE pinned, asynchronous H2D copy
                 n0, n1, n2 = flat.numel(), img_rows_h.numel(), reg_rows_h.numel()

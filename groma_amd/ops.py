@@ -27,15 +27,46 @@ def SP():
     return 2 if _lib.PRECISION[0] == "ref" else 1
 
 
-def split_pack(t):
+# Largest magnitude the half-based operand storages hold: IEEE half 65504; a (hi, lo) pair hi = 65504 saturated + lo up to 65504.
+H16_MAX = 65504.0
+PAIR_MAX = 2 * 65504.0
+
+
+class OperandOverflow(ValueError):
+    """a tensor packed for a half-based build (precision "fp16" / "ref" / the pair ViT of "hybrid") holds values the storage cannot
+    represent: raised at LOAD time for weights (weights.bf), so a checkpoint with out-of-range parameters is reported instead of
+    silently saturated.  Activations are converted on the device, where the conversions saturate at +-65504 (gr_common.h sat_h16) --
+    where the reference's own fp16 autocast (R: groma/eval/run_groma.py:82) would produce inf."""
+
+
+def _check_range(t, limit, what, on_overflow):
+    if on_overflow == "saturate" or t.numel() == 0:
+        return
+    m = float(t.abs().max())   # (load-time only: one host sync per packed tensor)
+    if m > limit or m != m:
+        msg = f"{what or 'tensor'}: max |x| = {m:.6g} exceeds the {limit:.6g} the half-based operand storage holds"
+        if on_overflow == "raise":
+            raise OperandOverflow(msg)
+        import warnings
+        warnings.warn(msg + " -- saturated")
+
+
+def split_pack(t, on_overflow="saturate", what=None):
     """f32 [..., K] (K % 32 == 0) -> the split-operand storage of libgroma_hip_ref.so: half [..., 2K] with
     hi = f16(x), lo = f16(x - hi) interleaved in blocks of 32 (load-time / test plumbing; the kernels write this layout
-    themselves on the forward path)"""
-    t = t.float().clamp(-65504.0, 65504.0)
+    themselves on the forward path).
+    Range and precision of a pair (tests/test_operand_range.py): |x - (hi + lo)| <= max(2^-22 |x|, 2^-25) for |x| <= 65504 -- 22
+    mantissa bits while lo is a normal half (|x| >= 2^-3), an ABSOLUTE 2^-25 below that (lo is then a subnormal half: quantum
+    2^-24), so an operand of magnitude 0.02 keeps ~19 bits and anything below 3e-8 is flushed; 65504 < |x| <= 131008 is still
+    exact to 2^-11 relative (hi saturated, lo takes the rest), beyond that the pair saturates.
+    on_overflow: "saturate" (what the device-side conversions do) | "warn" | "raise" (OperandOverflow) for |x| > 131008."""
+    t = t.float()
+    _check_range(t, PAIR_MAX, what, on_overflow)
+    t = t.clamp(-PAIR_MAX, PAIR_MAX)
     K = t.shape[-1]
     if K % 32:
         raise ValueError(f"split operand rows must be multiples of 32 elements, got {K}")
-    hi = t.to(torch.float16)
+    hi = t.clamp(-H16_MAX, H16_MAX).to(torch.float16)
     lo = (t - hi.float()).to(torch.float16)
     return torch.stack((hi.reshape(*t.shape[:-1], K // 32, 32), lo.reshape(*t.shape[:-1], K // 32, 32)), dim=-2) \
         .reshape(*t.shape[:-1], 2 * K).contiguous()
@@ -48,12 +79,15 @@ def unsplit(t):
     return (v[..., 0, :] + v[..., 1, :]).reshape(*t.shape[:-1], K2 // 2)
 
 
-def to_h16(t):
-    """f32 values -> the active operand storage (bf16 / fp16 cast, or the split pair layout)"""
+def to_h16(t, on_overflow="saturate", what=None):
+    """f32 values -> the active operand storage (bf16 / fp16 cast, or the split pair layout).
+    on_overflow ("saturate" | "warn" | "raise"): what to do with values beyond the storage's range (weights.bf passes "raise")"""
     if SP() == 2:
-        return split_pack(t)
+        return split_pack(t, on_overflow, what)
     if H16() == torch.float16:
-        t = t.float().clamp(-65504.0, 65504.0)  # the device-side conversions saturate too (gr_common.h sat_h16): never inf
+        t = t.float()
+        _check_range(t, H16_MAX, what, on_overflow)
+        t = t.clamp(-H16_MAX, H16_MAX)  # the device-side conversions saturate too (gr_common.h sat_h16): never inf
     return t.to(H16()).contiguous()
 
 
@@ -467,21 +501,31 @@ def s2d_pack(h, G):
     return out
 
 
-def upsample_coord_pack(h, G, Ho, Cpad):
+def upsample_coord_pack(h, G, Ho, Cpad, out=None):
     lib = _lib.load()
     B, T, C = h.shape
-    out = torch.empty((B * Ho * Ho, Cpad * SP()), dtype=H16(), device=h.device)
+    if out is None:
+        out = torch.empty((B * Ho * Ho, Cpad * SP()), dtype=H16(), device=h.device)
+    _chk(out, H16(), "out")
     _lib.check(lib.gr_upsample_coord_pack(_p(h), _p(out), B, G, Ho, C, Cpad, _stream()), "gr_upsample_coord_pack")
     return out
 
 
-def gn_coef(x, imgs, HW, C, groups, gamma, beta, eps):
+def gn_stats_blocks(HW):
+    return int(_lib.load().gr_gn_stats_blocks(HW))
+
+
+def gn_coef(x, imgs, HW, C, groups, gamma, beta, eps, sums=None, coef=None):
     """GroupNorm statistics of a conv output x bf16 [imgs*HW, C] -> per-(image, channel) affine y = x*a + b,
-    f32 [imgs, 2, C] (consumed by fuse_shuffle)."""
+    f32 [imgs, 2, C] (consumed by fuse_shuffle).  sums / coef: caller-owned buffers ([imgs, gn_stats_blocks(HW), C, 2] / [imgs, 2, C])"""
     lib = _lib.load()
-    sums = torch.empty((imgs, lib.gr_gn_stats_blocks(HW), C, 2), dtype=F32, device=x.device)
+    if sums is None:
+        sums = torch.empty((imgs, lib.gr_gn_stats_blocks(HW), C, 2), dtype=F32, device=x.device)
+    _chk(sums, F32, "sums")
     _lib.check(lib.gr_gn_stats(_p(x), _p(sums), imgs, HW, C, _stream()), "gr_gn_stats")
-    coef = torch.empty((imgs, 2, C), dtype=F32, device=x.device)
+    if coef is None:
+        coef = torch.empty((imgs, 2, C), dtype=F32, device=x.device)
+    _chk(coef, F32, "coef")
     _lib.check(lib.gr_gn_finalize(_p(sums), _p(gamma), _p(beta), _p(coef), imgs, HW, C, groups, eps, _stream()),
                "gr_gn_finalize")
     return coef

@@ -134,6 +134,25 @@ class ContinuousBatcher:
         self.graph = None
         self.steps = 0
 
+    # ------------------------------------------------------------------ admission-time warm-up
+    @engine.model_entry(lambda self, *a, **kw: self.model.precision)
+    def warm_admission(self, input_ids, image, rows=1):
+        """One throw-away admission prefill of `rows` copies of an example request BEFORE live traffic: the hipGraphs of the ViT,
+        the region pyramid and the LLaMA prefill for that batch shape are captured on this pass (engine.GraphPool.first_sight)
+        instead of inside the first three live admissions of the shape, and the workspace arenas reach their working size.
+        Nothing of the example survives: the staging cache is overwritten by the next admission, no slot is taken."""
+        if self.slots.n_free != self.rows:
+            raise RuntimeError("warm_admission() must run before the first admission")
+        if self.use_graph and self.graph is None:
+            self._capture()
+        k = max(1, min(int(rows), self.rows))
+        ids = input_ids.reshape(1, -1).to(I64).cpu().repeat(k, 1)
+        imgs = torch.stack([image] * k)
+        with engine.GraphPool.first_sight():
+            for _ in range(2):   # first pass: arenas grow to their size (new addresses = new keys); second: capture on stable addresses
+                self.model.forward(input_ids=ids.clone(), images=imgs, use_cache=True, return_dict=True,
+                                   _cache=_RowView(self.staging, k), _seeds=[0] * k)
+
     # ------------------------------------------------------------------ request intake
     def submit(self, input_ids, image, max_new_tokens=256, refer_boxes=None, ground_boxes=None, eos_token_id="config",
                stop_token_id=None, seed=None, temperature=0.0):

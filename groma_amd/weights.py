@@ -54,9 +54,10 @@ class Source:
 
 
 def bf(t):
-    """f32 [.., K] -> the active operand storage: bf16 / fp16 (saturating, like the device-side conversions), or the
-    (hi, lo) pair layout of precision "ref" (twice as wide; ops.split_pack)"""
-    return ops.to_h16(t)
+    """f32 [.., K] -> the active operand storage: bf16 / fp16, or the (hi, lo) pair layout of precision "ref" (twice as wide;
+    ops.split_pack).  A WEIGHT beyond the range of a half-based storage (|w| > 65504 in the fp16 build, > 131008 as a pair) raises
+    ops.OperandOverflow at load time instead of being saturated silently (tests/test_operand_range.py)"""
+    return ops.to_h16(t, on_overflow="raise", what="weight")
 
 
 FP8 = torch.float8_e4m3fn

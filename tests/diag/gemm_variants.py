@@ -9,6 +9,7 @@ from groma_amd import _lib, ops
 
 args = sys.argv[1:]
 ref = "--ref" in args
+fp8 = "--fp8" in args   # e4m3 operands (gemm_fp8_256_kernel) on the LLaMA shapes, bf16-library variants
 libs = [a.split("=", 1) for a in args if "=" in a]
 prec = "ref" if ref else "bf16"
 opened = {n: _lib._open(os.path.abspath(p), 2 if ref else 0) for n, p in libs}
@@ -23,7 +24,7 @@ LLM = [("llama gate-up +SwiGLU", 8148, 22016, 4096, 32, dict(act=3)),
        ("llama o-proj +resid f32", 8148, 4096, 4096, 32, dict(resid=1)),
        ("lm_head f32", 8148, 32128, 4096, 1, dict(f32=1))]
 CONV = [("fuse conv 3x3 @128^2", 14, 128, 1024, 5), ("fuse conv 3x3 @64^2", 14, 64, 1024, 5)]
-SHAPES = VIT if ref else LLM + VIT
+SHAPES = VIT if ref else (LLM if fp8 else LLM + VIT)
 
 
 def use(lib):
@@ -39,6 +40,11 @@ with ops.precision(prec):
         a = ops.to_h16(torch.randn((M, K), device=dev) * 0.5)
         w = ops.to_h16(torch.randn((N, K), device=dev) * 0.05)
         kws = dict(tile=0)
+        if fp8:
+            from groma_amd import weights
+            a, sa = ops.quant_rows_fp8(a)
+            w, sw = weights.q8(w.float())
+            kws.update(a_scale=sa, w_scale=sw)
         if kw.get("bias"): kws["bias"] = torch.randn((N,), device=dev)
         if kw.get("scale"): kws["scale"] = torch.randn((N,), device=dev)
         if kw.get("act"): kws["act"] = kw["act"]
@@ -65,10 +71,10 @@ with ops.precision(prec):
         for n in opened:
             us = statistics.median(ts[n])
             tot[n] += us * calls
-            line += f"  [{n}] {us:8.1f} us {(3 if ref else 1) * 2.0 * M * N * K / us / 1e6:5.0f} TF/s{'' if torch.equal(outs[n], outs[base]) else ' !!DIFFERS'}"
+            line += f"  [{n}] {us:8.1f} us {(3 if ref else 1) * 2.0 * M * N * K / us / 1e6:5.0f} TF/s{'' if torch.equal(outs[n].view(torch.uint8), outs[base].view(torch.uint8)) else ' !!DIFFERS'}"
         print(line, flush=True)
         del a, w, h0, outs
-    if not ref:   # the region encoder's implicit-GEMM 3x3 convs
+    if not ref and not fp8:   # the region encoder's implicit-GEMM 3x3 convs
         for name, imgs, S, C, calls in CONV:
             pad = ops.to_h16(torch.randn((imgs, S + 2, S + 2, C), device=dev) * 0.5)
             w = ops.to_h16(torch.randn((C, 9 * C), device=dev) * 0.02)

@@ -265,6 +265,7 @@ def test_graph_pool_policy(monkeypatch):
     the third, replay afterwards; the pool keeps `cap` graphs and an evicted key starts counting again; disabled / traced runs
     launch eagerly and leave the pool alone."""
     import contextlib
+    import pytest
     from groma_amd import engine
 
     log = []
@@ -360,6 +361,22 @@ def test_graph_pool_policy(monkeypatch):
     # warm(): capture at admission time, not on the third live request
     small.warm("w", mk("w"))
     assert "w" in small._graphs and small.captures == 4
+    # first_sight(): a warm-up pass captures a new key at once (serving.ContinuousBatcher.warm_admission)
+    fs = engine.GraphPool(cap=4)
+    with engine.GraphPool.first_sight():
+        fs.run("k", mk("k"))
+    assert "k" in fs._graphs and fs.captures == 1 and not engine.GraphPool._first_sight[0]
+    fs.run("k2", mk("k2"))
+    assert "k2" not in fs._graphs                                         # outside the block: third sighting again
+    # a launch that raises inside the capture: the capture is ended, the ORIGINAL error surfaces, nothing is kept
+    def boom():
+        raise RuntimeError("GR_EINVAL inside the capture")
+    n_cap = small.captures
+    with pytest.raises(RuntimeError, match="GR_EINVAL inside the capture"):
+        small.warm("bad", boom)
+    assert "bad" not in small._graphs and small.captures == n_cap
+    small.warm("good", mk("good"))
+    assert "good" in small._graphs
     # a key is everything baked into the launches: cache_addresses() changes when a cache grows
     class C:
         pass

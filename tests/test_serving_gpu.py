@@ -157,3 +157,31 @@ def test_sampled_rows_are_independent_of_batch_composition(setup):
     b.run_until_done()
     assert b.result(rid).tokens == _solo_generate(model, ids, image, 9, seed)
     assert alone != b.live.get(rid, None)
+
+
+def test_warm_admission_captures_before_live_traffic(setup):
+    """ContinuousBatcher.warm_admission (round 5, ADVICE r04: GraphPool.warm had no caller): a throw-away admission prefill under
+    engine.GraphPool.first_sight() captures the ViT / pyramid / prefill graphs of the shape up front; the first LIVE request of that
+    shape is then a replay, and its tokens are exactly those of a batcher that was never warmed."""
+    from groma_amd.serving import ContinuousBatcher
+    cfg, model, reqs = setup
+    ids, image, n, seed = reqs[0]
+    cold = ContinuousBatcher(model, max_rows=2, max_len=1024)
+    rid = cold.submit(ids, image, max_new_tokens=n, seed=seed)
+    want = cold.run_until_done()[rid].tokens
+    for pool in (model.vit.graphs, model.llm.graphs, model.region.graphs):
+        pool.clear()
+    b = ContinuousBatcher(model, max_rows=2, max_len=1024)
+    b.warm_admission(ids, image, rows=1)
+    caps = (model.vit.graphs.captures, model.region.graphs.captures)
+    reps = model.vit.graphs.replays
+    rid = b.submit(ids, image, max_new_tokens=n, seed=seed)
+    got = b.run_until_done()[rid].tokens
+    assert got == want
+    assert model.vit.graphs.replays > reps                                             # the live request replayed the warmed graph
+    assert (model.vit.graphs.captures, model.region.graphs.captures) == caps           # and captured nothing itself
+    with pytest.raises(RuntimeError):
+        b2 = ContinuousBatcher(model, max_rows=2, max_len=1024)
+        b2.submit(ids, image, max_new_tokens=6, seed=seed)
+        b2.step()
+        b2.warm_admission(ids, image)                                                   # too late: a slot is taken
