@@ -366,9 +366,9 @@ def launch_roofline(m, step, n, kind):
     if kind == "hbm":
         gv = [r for r in recs if r[3] & 8]
         ms = sum(r[4] for r in gv)
-        nbytes = sum(2.0 * r[1] * r[2] for r in gv)
+        nbytes = sum((1.0 if r[3] & 16 else 2.0) * r[1] * r[2] for r in gv)   # (tag 16: e4m3 weights, one byte per element)
         ach = nbytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
-        return {"bound": "hbm", "kernel": "gemv_fused_kernel<MB, XG>(GemvFArgs) -- decode-step weight streaming, one launch per weight matrix", "achieved": ach, "peak": 8000.0,
+        return {"bound": "hbm", "kernel": "gemv_fused_kernel<MB, XG, W8>(GemvFArgs) -- decode-step weight streaming, one launch per weight matrix", "achieved": ach, "peak": 8000.0,
                 "unit": "GB/s", "frac": ach / 8000.0, "traffic": None, "launches_per_step": len(gv) / n,
                 "avg_launch_us": ms * 1e3 / max(len(gv), 1), "bytes_per_launch": nbytes / max(len(gv), 1)}
     fp8 = bool(m.fp8)

@@ -48,6 +48,7 @@ class GemvDesc(ctypes.Structure):
         ("epi", c_int), ("C", c_void_p), ("ldc", c_long), ("resid", c_void_p), ("ldr", c_long),
         ("q", c_void_p), ("kc", c_void_p), ("vt", c_void_p), ("cosT", c_void_p), ("sinT", c_void_p),
         ("H", c_int), ("HD", c_int), ("pos0", c_int), ("kv_stride", c_int), ("pos_dev", c_void_p), ("pos_stride", c_int),
+        ("w8", c_int), ("w_scale", c_void_p),
     ]
 
 
@@ -138,7 +139,7 @@ def _open(path, operand):
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
         fn.argtypes = argtypes
         fn.restype = c_long if name == "gr_nms_workspace_bytes" else c_int
-    if lib.gr_abi_version() != 8:
+    if lib.gr_abi_version() != 9:
         raise RuntimeError(f"{os.path.basename(path)} ABI version mismatch")
     if lib.gr_operand_type() != operand:
         raise RuntimeError(f"{os.path.basename(path)} was built for another 16-bit operand type")

@@ -19,6 +19,7 @@ H16 = ops.H16  # dtype of the active 16-bit operand type (bf16 / fp16: ops.preci
 
 
 Q_IN_PLACE = True  # prefill attention reads q (and applies RoPE) straight from the fused QKV projection
+FUSED_DECODE = True  # a decode step of <= 8 rows runs on the fused weight streams (False: the general kernels -- tests compare the two)
 
 
 def _ru(x, m):
@@ -640,7 +641,10 @@ class LlamaEngine:
         past = 0 if dyn else cache.seq_len
         if not dyn and past + L > cache.smax:
             cache.grow(_ru(past + L + 64, 64))
-        if L == 1 and M <= 8 and not w["fp8"] and T <= 8192 and cache.smax <= 8192 and ops.SP() == 1 and states is None:
+        # (e4m3 weights, round 5: the fused streams read the e4m3 bytes -- half the HBM traffic per token; their operand staging
+        #  holds M x K 16-bit values in LDS, which fits up to 4 rows at the down-projection's K = 11 008)
+        fits8 = not w["fp8"] or _ru(bs, 4) * max(T, self.I) * 2 <= 128 * 1024
+        if FUSED_DECODE and L == 1 and M <= 8 and fits8 and T <= 8192 and cache.smax <= 8192 and ops.SP() == 1 and states is None:
             return self._decode_forward(h, bs, cache, kv_len, pos_dev, pos_stride, past)
         # A decode step that does not fit the weight-streaming path (more than 8 rows, e4m3 operands, > 8192 keys) runs the
         # general kernels below.  Its scratch may be baked into GreedyDecoder's captured hipGraph, so -- like _decode_forward --
@@ -764,11 +768,12 @@ class LlamaEngine:
         q = ws.get("dec_q", h16(bs, H, 1, hd), H16(), exact=True)
         ctx = ws.get("dec_ctx", h16(bs, T), H16(), exact=True)
         y = ws.get("dec_y", h16(bs, self.I), H16(), exact=True)
+        ws8 = (lambda wt: dict(w_scale=wt[1])) if w["fp8"] else (lambda wt: {})   # e4m3 weights carry their per-row scale
         for i, Lw in enumerate(w["layers"]):
             t0 = TRACE is not None and i == 0
             if t0:
                 _trace("dec0.h_in", h)
-            ops.gemv_fused(Lw["wqkv"][0], M=bs, norm=(h, Lw["n1"], self.eps),
+            ops.gemv_fused(Lw["wqkv"][0], M=bs, norm=(h, Lw["n1"], self.eps), **ws8(Lw["wqkv"]),
                            qkv=dict(q=q, k=cache.k[i], vt=cache.vt[i], cos=w["cos"], sin=w["sin"], H=H, hd=hd, pos0=past,
                                     pos_dev=pos_dev, pos_stride=pos_stride))
             att = ops.decode_attention(q, cache.k[i], cache.vt[i], ctx, Smax=cache.smax if dyn else past + 1, q_pos0=past,
@@ -779,21 +784,24 @@ class LlamaEngine:
                 if not isinstance(att, tuple):
                     _trace("dec0.ctx", ctx)
             if isinstance(att, tuple):  # key slices on separate blocks: the o-proj merges them while building its operand
-                ops.gemv_fused(Lw["wo"][0], M=bs, a_parts=att, resid=h)
+                ops.gemv_fused(Lw["wo"][0], M=bs, a_parts=att, resid=h, **ws8(Lw["wo"]))
             else:
-                ops.gemv_fused(Lw["wo"][0], M=bs, x=ctx, resid=h)
+                ops.gemv_fused(Lw["wo"][0], M=bs, x=ctx, resid=h, **ws8(Lw["wo"]))
             if t0:
                 _trace("dec0.h_attn", h)
-            ops.gemv_fused(Lw["wgu"][0], M=bs, norm=(h, Lw["n2"], self.eps), swiglu_out=y)
+            ops.gemv_fused(Lw["wgu"][0], M=bs, norm=(h, Lw["n2"], self.eps), swiglu_out=y, **ws8(Lw["wgu"]))
             if t0:
                 _trace("dec0.act", y)
-            ops.gemv_fused(Lw["wd"][0], M=bs, x=y, resid=h)
+            ops.gemv_fused(Lw["wd"][0], M=bs, x=y, resid=h, **ws8(Lw["wd"]))
         if not dyn:
             cache.seq_len = past + 1
         if TRACE is not None and len(w["layers"]) == 1:
             _trace("dec.h_out", h)
         logits = self.decode_logits(bs)
-        ops.gemv_fused(w["head"], M=bs, norm=(h, w["norm"], self.eps), out=logits)
+        if w["fp8"] and "head8" in w:
+            ops.gemv_fused(w["head8"][0], M=bs, norm=(h, w["norm"], self.eps), out=logits, w_scale=w["head8"][1])
+        else:
+            ops.gemv_fused(w["head"], M=bs, norm=(h, w["norm"], self.eps), out=logits)
         return logits.view(bs, 1, self.Vpad)[:, :, : self.V], None
 
 

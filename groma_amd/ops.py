@@ -308,17 +308,24 @@ def gemv_partials(a, w, M=None, a_parts=None):
     return ws, splits
 
 
-def gemv_fused(w, *, M, x=None, norm=None, a_parts=None, out=None, resid=None, swiglu_out=None, qkv=None):
+def gemv_fused(w, *, M, x=None, norm=None, a_parts=None, out=None, resid=None, swiglu_out=None, qkv=None, w_scale=None):
     """One decode-step weight stream y[M <= 8, N] = x . w[N,K]^T with its producer and consumer fused (csrc/gemv_fused.hip).
     Operand (exactly one): x = 16-bit [M,K]; norm = (h f32 [M,K], gamma, eps) -> RMSNorm in the prologue; a_parts = the
     un-merged output of decode_attention(nsplit > 1).
     Result (exactly one): out f32 [M,N]; resid f32 [M,N] (+= y in place); swiglu_out 16-bit [M, N/2] (interleaved gate / up rows);
     qkv = dict(q, k, vt, cos, sin, H, hd, pos0, pos_dev, pos_stride): RoPE + q / K-cache row / V^T-cache column."""
     lib = _lib.load()
-    _chk(w, H16(), "w")
+    if w.dtype == FP8:   # e4m3 weight stream (w_scale = the per-row scale): half the bytes per token, operand quantised in the prologue
+        if w_scale is None:
+            raise ValueError("an e4m3 weight stream needs w_scale")
+        _chk(w, FP8, "w")
+    else:
+        _chk(w, H16(), "w")
     N, K = w.shape
     d = _lib.GemvDesc()
     d.W, d.ldw, d.M, d.N, d.K = w.data_ptr(), w.stride(0), M, N, K
+    if w.dtype == FP8:
+        d.w8, d.w_scale = 1, _chk(w_scale, F32, "w_scale").data_ptr()
     if norm is not None:
         h, gamma, eps = norm
         _chk(h, F32, "h"); _chk(gamma, F32, "gamma")

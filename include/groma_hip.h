@@ -42,7 +42,7 @@ extern "C" {
 typedef struct ihipStream_t* hipStream_t;
 #endif
 
-#define GROMA_HIP_ABI_VERSION 8
+#define GROMA_HIP_ABI_VERSION 9
 int gr_abi_version(void);
 #define GR_OPERAND_BF16 0
 #define GR_OPERAND_F16 1
@@ -118,6 +118,11 @@ typedef struct gr_gemv_desc {
   const float* a_parts; int a_nsplit, a_hd;
   int epi; void* C; long ldc; float* resid; long ldr;
   void* q; void* kc; void* vt; const float* cosT; const float* sinT; int H, HD, pos0, kv_stride; const int* pos_dev; int pos_stride;
+  /* ABI 9 -- OCP e4m3 weights (BASELINE configs[4] at L = 1): w8 != 0: W is [N, K] e4m3 BYTES (ldw in elements) with the per-row
+   * scale w_scale [N]; the operand is quantised by the prologue exactly as the e4m3 prefill path forms it (per row, s = max|x| / 448,
+   * q = e4m3_rne(x * (1 / s)): x_mode 1 from the fp32 normalisation output, x_mode 0 / 2 from the 16-bit-rounded activation) and
+   * y = acc * w_scale[n] * s[m] before the epilogue.  M * K * 2 <= 128 KB (the staged operand); x_mode 1 needs K <= 4096. */
+  int w8; const float* w_scale;
 } gr_gemv_desc;
 int gr_gemv_fused(const gr_gemv_desc* d, hipStream_t stream);
 

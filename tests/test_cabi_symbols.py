@@ -23,9 +23,9 @@ def test_header_symbols_are_exported_and_typed():
         for n in names:
             assert hasattr(lib, n), f"{n} declared in include/groma_hip.h but not exported by {path}"
     assert set(names) == set(_lib.SIGNATURES), "ctypes signature table out of sync with the header"
-    assert _lib.load().gr_abi_version() == 8 and _lib.load().gr_operand_type() == 0
-    assert _lib.load("fp16").gr_abi_version() == 8 and _lib.load("fp16").gr_operand_type() == 1
-    assert _lib.load("ref").gr_abi_version() == 8 and _lib.load("ref").gr_operand_type() == 2
+    assert _lib.load().gr_abi_version() == 9 and _lib.load().gr_operand_type() == 0
+    assert _lib.load("fp16").gr_abi_version() == 9 and _lib.load("fp16").gr_operand_type() == 1
+    assert _lib.load("ref").gr_abi_version() == 9 and _lib.load("ref").gr_operand_type() == 2
 
 
 def test_split_build_rejects_what_it_has_no_form_of():

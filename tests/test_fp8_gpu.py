@@ -138,3 +138,77 @@ def test_fp8_prefill_graphs_equal_eager(setup):
     assert torch.equal(run(images, n=1), e1)
     assert torch.equal(run(images), ea)
     assert m8.vit.graphs.replays > v0 and m8.llm.graphs.replays > l0
+
+
+def test_fp8_weight_stream_equals_the_e4m3_gemm(dev):
+    """gr_gemv_fused with e4m3 weights (round 5: the decode step of an fp8 model streams HALF the bytes) against the e4m3 GEMM path the
+    prefill uses on the same rows: the operand quantisers are the same arithmetic (fp8.hip) and both accumulate exact e4m3 products
+    in fp32, so the two agree to summation order -- for each prologue (fused RMSNorm from fp32, a stored 16-bit activation, merged
+    attention slices is covered by the model-level test below) and each epilogue."""
+    from groma_amd import ops, weights
+    g = torch.Generator(device="cuda").manual_seed(0)
+    M, K, N, eps = 4, 4096, 1024, 1e-6
+    w = torch.randn((N, K), generator=g, device="cuda") * 0.02
+    w8, ws = weights.q8(w)
+    h = torch.randn((M, K), generator=g, device="cuda")
+    h[1] *= 40.0                                   # rows of very different magnitude: the per-row scales matter
+    gamma = torch.rand((K,), generator=g, device="cuda") + 0.5
+    # fused RMSNorm prologue -> f32 logits-style output
+    out = torch.empty((M, N), device="cuda")
+    ops.gemv_fused(w8, M=M, norm=(h, gamma, eps), out=out, w_scale=ws)
+    x8, sx = ops.norm_fp8(h, gamma, None, eps, True)
+    ref = ops.gemm(x8, w8, a_scale=sx, w_scale=ws, out_f32=True)
+    assert util.relerr(out, ref) < 2e-6, util.relerr(out, ref)
+    # stored bf16 activation -> in-place residual update, K = 11008 (the down projection's operand staging: 88 KB of LDS)
+    K2 = 11008
+    w2 = torch.randn((N, K2), generator=g, device="cuda") * 0.02
+    w28, ws2 = weights.q8(w2)
+    y = (torch.randn((M, K2), generator=g, device="cuda") * 3).bfloat16()
+    res = torch.randn((M, N), generator=g, device="cuda")
+    r1 = res.clone()
+    ops.gemv_fused(w28, M=M, x=y, resid=r1, w_scale=ws2)
+    y8, sy = ops.quant_rows_fp8(y)
+    ref2 = res + ops.gemm(y8, w28, a_scale=sy, w_scale=ws2, out_f32=True)
+    assert util.relerr(r1, ref2) < 2e-6, util.relerr(r1, ref2)
+    # SwiGLU over interleaved (gate, up) rows -> 16-bit output
+    so = torch.empty((M, N // 2), device="cuda", dtype=torch.bfloat16)
+    ops.gemv_fused(w8, M=M, norm=(h, gamma, eps), swiglu_out=so, w_scale=ws)
+    ref3 = ops.gemm(x8, w8, a_scale=sx, w_scale=ws, act=3)
+    assert util.relerr(so, ref3) < 5e-3 and (so.float() - ref3.float()).abs().max() <= 2.0 ** -7 * ref3.float().abs().max()
+    # 3 rows (padding row in the 4-row block) and an operand too large for the staging buffer
+    out3 = torch.empty((3, N), device="cuda")
+    ops.gemv_fused(w8, M=3, norm=(h[:3].contiguous(), gamma, eps), out=out3, w_scale=ws)
+    assert util.relerr(out3, ref[:3]) < 2e-6
+    with pytest.raises(RuntimeError):
+        ops.gemv_fused(w28, M=8, x=y.repeat(2, 1).contiguous(), resid=torch.zeros((8, N), device="cuda"), w_scale=ws2)   # 8 x 11008 x 2 B > 128 KB
+
+
+def test_fp8_decode_step_on_the_weight_streams_equals_the_general_kernels(setup, monkeypatch):
+    """one decode step of the e4m3 model: the fused e4m3 weight streams (5 launches per layer) against the general e4m3 GEMM / attention
+    kernels the step ran on in rounds 1-4 -- same cache, same token, logits equal to summation order"""
+    cfg, sd, tk, m16, m8, images, ids = setup
+    from groma_amd import engine
+    torch.manual_seed(3)
+    out = m8.forward(input_ids=ids.clone(), images=images, use_cache=True, return_dict=True)
+    cache = out.past_key_values
+    L = cache.seq_len
+    tok = out.logits[:, -1].argmax(-1)
+    snap = [(k.clone(), v.clone()) for k, v in zip(cache.k, cache.vt)]
+
+    def step(fused):
+        for (k0, v0), k, v in zip(snap, cache.k, cache.vt):
+            k.copy_(k0), v.copy_(v0)
+        cache.seq_len = L
+        monkeypatch.setattr(engine, "FUSED_DECODE", fused)
+        try:
+            return m8.forward(input_ids=tok[:, None], past_key_values=cache, use_cache=True, return_dict=True).logits.clone()
+        finally:
+            monkeypatch.undo()
+
+    a = step(True)
+    k_fused = [k.clone() for k in cache.k]
+    b = step(False)
+    e = util.relerr(a, b)
+    print("fp8 decode step: fused e4m3 streams vs general e4m3 kernels, logits rel err", e, "| K cache row", util.relerr(k_fused[0][:, :, L], cache.k[0][:, :, L]))
+    assert e < 1e-4
+    assert util.relerr(k_fused[0][:, :, L], cache.k[0][:, :, L]) < 1e-2     # the new K row, rounded to bf16 on both paths
