@@ -724,7 +724,7 @@ def main():
     if gen:  # configs[3]: the decode steps stream the bf16 weights once per token -> HBM roofline of the GEMV kernel
         gv = [r for r in recs if r[3] & 8]
         gv_ms = sum(r[4] for r in gv)
-        gv_bytes = sum(2.0 * r[1] * r[2] for r in gv)  # algorithmic bytes per launch: the N x K bf16 weight, read once
+        gv_bytes = sum((1.0 if r[3] & 16 else 2.0) * r[1] * r[2] for r in gv)  # algorithmic bytes per launch: the N x K weight (16-bit, or e4m3 bytes: tag 16), read once
         out["metric"] = "images/sec greedy generate (448px, 300 proposals, 128-token prompt, %d new tokens)" % args.new_tokens
         out["config"]["workload"] = ("configs[3]: generate() = full Groma-7B prefill + %d greedy decode steps (hipGraph replay), "
                                      "random-init weights, no EOS" % args.new_tokens)
@@ -736,7 +736,7 @@ def main():
             # command (the decode steps are graph replays there; the counters see the same kernels)
             gv_traffic = measure_traffic(args.batch, "gemv_fused_kernel", ["--mode", "generate", "--new-tokens", str(args.new_tokens),
                                                                              "--vit-operands", args.vit_operands])
-        out["roofline"] = {"bound": "hbm", "kernel": "gemv_fused_kernel<MB, XG>(GemvFArgs) -- decode-step weight streaming, one launch per weight matrix",
+        out["roofline"] = {"bound": "hbm", "kernel": "gemv_fused_kernel<MB, XG, W8>(GemvFArgs) -- decode-step weight streaming, one launch per weight matrix",
                            "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0, "traffic": gv_traffic,
                            "traffic_note": "bytes/launch at the L2<->fabric boundary (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, gfx950 correction), averaged over the fused-stream launches; algorithmic = bytes_per_launch" if gv_traffic else None,
                            "launches_per_step": len(gv) / max(args.steps, 1),

@@ -31,46 +31,7 @@
 #define GF_WG_PER_CU 2  // persistent workgroups per CU
 #endif
 
-struct GemvFArgs {
-  const bf16_t* W;
-  long ldw;
-  int M, N, K;
-  int x_mode;  // 0: A bf16 [M,K] ; 1: RMSNorm(h) * gamma ; 2: merged attention slices (a_parts)
-  const bf16_t* A;
-  long lda;
-  const float* h;
-  long ldh;
-  const float* gamma;
-  float eps;
-  const float* a_parts;
-  int a_nsplit, a_hd;
-  int epi;  // 0: f32 out ; 1: resid += ; 2: SwiGLU -> bf16 [M, N/2] ; 3: QKV RoPE + cache write
-  void* C;
-  long ldc;
-  float* resid;
-  long ldr;
-  bf16_t* q;
-  bf16_t* kc;
-  bf16_t* vt;
-  const float* cosT;
-  const float* sinT;
-  int H, HD, pos0, kv_stride;
-  const int* pos_dev;
-  int pos_stride;
-  const float* w_scale;  // W8: per-output-row scale of the e4m3 weight [N]
-};
-
-typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
-// two OCP e4m3 bytes (the low or the high half of a dword) -> a packed pair of the library's 16-bit type: ONE v_cvt_scalef32_pk_*_fp8
-// (scale 1.0; every e4m3 value is exact in bf16 and in half)
-template <bool HI>
-__device__ __forceinline__ uint32_t fp8x2_to_h16x2(uint32_t v) {
-#ifdef GR_F16
-  return __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(v, 1.0f, HI));
-#else
-  return __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(v, 1.0f, HI));
-#endif
-}
+#include "gemv_args.h"
 
 // XG: the operand comes from global memory (x_mode 0) -- else it is staged in LDS by the prologue (compile-time, so neither
 // instantiation carries the other's registers: both stay well under 256 VGPRs = two or three workgroups per CU).
@@ -80,24 +41,14 @@ __device__ __forceinline__ uint32_t fp8x2_to_h16x2(uint32_t v) {
 // paid once per workgroup, not once per group (first version: 2.8 TB/s on the QKV / gate-up / head shapes, because every
 // 8-row group redid it), and the first two slices of the NEXT group are requested before the butterfly / LDS exchange /
 // epilogue of the current one, so the weight stream does not drain between groups.
-// W8 (round 5, BASELINE configs[4] x configs[3]): the weights are OCP e4m3 bytes with a per-row scale, HALF the bytes per token.  The
-// operand is quantised exactly as the e4m3 prefill forms it (fp8.hip: per-row s = max|x| / 448, q = e4m3_rne(x * (1 / s)); a
-// normalisation output straight from fp32, a stored activation from its 16-bit value) by the prologue, which keeps the e4m3 VALUES
-// as 16-bit numbers in LDS (exact); a lane's 8 weight bytes become four packed 16-bit pairs with 4 conversions per row and
-// slice, and the products go through the same v_dot2c / butterfly / epilogue -- times w_scale[n] * s[m] first, in the prefill
-// GEMM's order.  x is always staged (XG = false).
-template <int MB, bool XG, bool W8>
+template <int MB, bool XG>
 __global__ __launch_bounds__(256, (XG && MB == 8) ? 1 : 2) void gemv_fused_kernel(GemvFArgs p) {
-  static_assert(!(W8 && XG), "the e4m3 stream stages its operand");
-  constexpr int WB = W8 ? 1 : 2;   // bytes per weight element
   constexpr int ROWS = GF_ROWS;  // rows of W per group
   constexpr int NV = ROWS * MB;  // dot products per row group (32 at <= 4 batch rows, 64 at 8): lanes 0..NV-1 own one each after the butterfly
   extern __shared__ __attribute__((aligned(16))) char smem[];
   bf16_t* xs = (bf16_t*)smem;                         // x_mode 1 / 2: [MB][K]
   __shared__ float red[4][NV];
   __shared__ float stat[4][4];
-  __shared__ float xsc[8];        // W8: per-batch-row activation scale
-  __shared__ unsigned amax_u[8];  // W8, x_mode 0 / 2: running max |x| of a row (bit pattern of a non-negative float)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int ngroups = (p.N + ROWS - 1) / ROWS;
@@ -109,7 +60,7 @@ __global__ __launch_bounds__(256, (XG && MB == 8) ? 1 : 2) void gemv_fused_kerne
   // checked by the entry point, so no row is ever clamped).
   int r_lo, r_hi;                // first row of the lower / upper half of the current group's rows
   const char *base_lo, *base_hi; // their addresses (SGPR pairs)
-  const unsigned ldwB = (unsigned)p.ldw * (unsigned)WB;
+  const unsigned ldwB = (unsigned)p.ldw * 2u;
   auto set_group = [&](int g) {
     r_lo = g * ROWS;
     r_hi = g * ROWS + ROWS / 2;
@@ -119,14 +70,13 @@ __global__ __launch_bounds__(256, (XG && MB == 8) ? 1 : 2) void gemv_fused_kerne
       r_lo = hh * p.HD + j * (ROWS / 2);
       r_hi = r_lo + p.HD / 2;
     }
-    base_lo = (const char*)p.W + (long)r_lo * p.ldw * WB;
-    base_hi = (const char*)p.W + (long)r_hi * p.ldw * WB;
+    base_lo = (const char*)(p.W + (long)r_lo * p.ldw);
+    base_hi = (const char*)(p.W + (long)r_hi * p.ldw);
   };
   const int ns = (p.K + GF_KS - 1) / GF_KS;          // K slices; wave w takes w, w + 4, ...
   const int cnt = wave < ns ? (ns - wave + 3) / 4 : 0;
 
-  using wvec = std::conditional_t<W8, u32x2, bf16x8>;   // a lane's 8 weights of one row and slice
-  wvec wA[ROWS], wB[ROWS];
+  bf16x8 wA[ROWS], wB[ROWS];
   bf16x8 xn[XG ? MB : 1];  // XG: raw x of the NEXT slice to be consumed (one buffer: requested at the start of the previous consume)
   const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
   auto load_x = [&](int i) {
@@ -140,15 +90,15 @@ __global__ __launch_bounds__(256, (XG && MB == 8) ? 1 : 2) void gemv_fused_kerne
       }
     }
   };
-  auto load = [&](int i, wvec* w) {  // slice i of this wave: every load issued before anything is consumed
+  auto load = [&](int i, bf16x8* w) {  // slice i of this wave: every load issued before anything is consumed
     const int k0 = (wave + 4 * i) * GF_KS + lane * 8;
     // K % 64 == 0: a lane's 8 values are all in or all out.  Lanes beyond K (last slice of K = 11008) re-read the row's last
     // 16 B instead of branching around the load -- their x is zero, so the product is 0 whatever the (finite) weight is.
-    const unsigned voff = (unsigned)min(k0, p.K - 8) * (unsigned)WB;
+    const unsigned voff = (unsigned)min(k0, p.K - 8) * 2u;
     // read exactly once per step by exactly one wave: non-temporal (do not displace the KV cache / x in L2 / MALL)
 #pragma unroll
     for (int r = 0; r < ROWS; ++r)
-      w[r] = __builtin_nontemporal_load((const wvec*)((r < ROWS / 2 ? base_lo : base_hi) + (voff + (unsigned)(r % (ROWS / 2)) * ldwB)));
+      w[r] = __builtin_nontemporal_load((const bf16x8*)((r < ROWS / 2 ? base_lo : base_hi) + (voff + (unsigned)(r % (ROWS / 2)) * ldwB)));
   };
   auto start_group = [&](int g) {  // request the first two slices of group g (and the first x slice)
     set_group(g);
@@ -158,54 +108,8 @@ __global__ __launch_bounds__(256, (XG && MB == 8) ? 1 : 2) void gemv_fused_kerne
   int grp = blockIdx.x;
   start_group(grp);
 
-  // W8 helpers.  q16(a, b, c, d, inv): four values * inv -> e4m3 (RNE, v_cvt_pk_fp8_f32) -> the same values as 16-bit numbers.
-  auto q16 = [](float a, float b, float c, float d, float inv, uint32_t& lo, uint32_t& hi) {
-    const uint32_t q = pack4_fp8(a * inv, b * inv, c * inv, d * inv);
-    lo = fp8x2_to_h16x2<false>(q);
-    hi = fp8x2_to_h16x2<true>(q);
-  };
-  // rows staged in xs as 16-bit VALUES with their max |x| in amax_u[] -> quantised in place, scales to xsc[] (x_mode 0 / 2)
-  auto quantise_staged = [&]() {
-    __syncthreads();
-    const int c8 = p.K >> 3;
-    for (int idx = tid; idx < MB * c8; idx += 256) {
-      const int m = idx / c8, k0 = (idx - m * c8) << 3;
-      const float sc = fmaxf(__builtin_bit_cast(float, amax_u[m]), 1e-20f) / 448.0f;
-      const float inv = 1.0f / sc;
-      union { bf16x8 v; uint32_t u[4]; } x;
-      x.v = *(const bf16x8*)(xs + (long)m * p.K + k0);
-      float f[8];
-#pragma unroll
-      for (int e = 0; e < 8; ++e) f[e] = bf2f((bf16_t)x.v[e]);
-      q16(f[0], f[1], f[2], f[3], inv, x.u[0], x.u[1]);
-      q16(f[4], f[5], f[6], f[7], inv, x.u[2], x.u[3]);
-      *(bf16x8*)(xs + (long)m * p.K + k0) = x.v;
-    }
-    if (tid < MB) xsc[tid] = fmaxf(__builtin_bit_cast(float, amax_u[tid]), 1e-20f) / 448.0f;
-    __syncthreads();
-  };
-  if (W8) {
-    if (tid < 8) amax_u[tid] = 0u;
-    __syncthreads();
-  }
-
-  // ---- prologue (x_mode 1 / 2; W8: x_mode 0 too), once per workgroup, in the shadow of the first weight loads
-  if (W8 && p.x_mode == 0) {  // stored 16-bit activation rows (attention context, SwiGLU output): stage, then row-quantise
-    const int c8 = p.K >> 3;
-    for (int m = 0; m < MB; ++m) {
-      float am = 0.f;
-      for (int c = tid; c < c8; c += 256) {
-        bf16x8 v = zero8;
-        if (m < p.M) v = *(const bf16x8*)(p.A + (long)m * p.lda + (c << 3));
-        *(bf16x8*)(xs + (long)m * p.K + (c << 3)) = v;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) am = fmaxf(am, fabsf(bf2f((bf16_t)v[e])));
-      }
-      am = wave_max(am);
-      if (lane == 0) atomicMax(&amax_u[m], __builtin_bit_cast(unsigned, am));
-    }
-    quantise_staged();
-  } else if (!XG && p.x_mode == 1) {  // x = f16(gamma * (h * rsqrt(mean(h^2) + eps)))  (HF LlamaRMSNorm), 4 batch rows at a time
+  // ---- prologue (x_mode 1 / 2), once per workgroup, in the shadow of the first weight loads
+  if (!XG && p.x_mode == 1) {  // x = f16(gamma * (h * rsqrt(mean(h^2) + eps)))  (HF LlamaRMSNorm), 4 batch rows at a time
     constexpr int KJ = 4;      // float4 per thread and row held in registers (K <= 4096); wider rows take the two-pass form below
     if (p.K <= KJ * 1024) {
       // straight-line: every load of a 4-row chunk (16 x h, 4 x gamma per thread) is issued before the first use -- ONE exposed
@@ -244,40 +148,6 @@ __global__ __launch_bounds__(256, (XG && MB == 8) ? 1 : 2) void gemv_fused_kerne
           for (int mi = 0; mi < 4; ++mi) stat[wave][mi] = ss[mi];
         }
         __syncthreads();
-        if constexpr (W8) {  // the normalised row is quantised straight from fp32 (what norm_fp8_rows_kernel does for the prefill)
-          float am[4];
-#pragma unroll
-          for (int mi = 0; mi < 4; ++mi) {
-            const int m = m0 + mi;
-            const float rstd = m < p.M ? rsqrtf((stat[0][mi] + stat[1][mi] + stat[2][mi] + stat[3][mi]) / (float)p.K + p.eps) : 0.f;
-            am[mi] = 0.f;
-#pragma unroll
-            for (int j = 0; j < KJ; ++j) {
-              hv[mi][j] = g[j] * (hv[mi][j] * rstd);
-              if (cin[j]) am[mi] = fmaxf(fmaxf(am[mi], fmaxf(fabsf(hv[mi][j][0]), fabsf(hv[mi][j][1]))), fmaxf(fabsf(hv[mi][j][2]), fabsf(hv[mi][j][3])));
-            }
-            am[mi] = wave_max(am[mi]);
-          }
-          __syncthreads();  // (every thread has read stat[] of the sums)
-          if (lane == 0) {
-#pragma unroll
-            for (int mi = 0; mi < 4; ++mi) stat[wave][mi] = am[mi];
-          }
-          __syncthreads();
-#pragma unroll
-          for (int mi = 0; mi < 4; ++mi) {
-            const int m = m0 + mi;
-            const float sc = fmaxf(fmaxf(fmaxf(stat[0][mi], stat[1][mi]), fmaxf(stat[2][mi], stat[3][mi])), 1e-20f) / 448.0f;
-            const float inv = 1.0f / sc;
-            if (tid == 0) xsc[m] = sc;
-#pragma unroll
-            for (int j = 0; j < KJ; ++j) {
-              uint2 pk;
-              q16(hv[mi][j][0], hv[mi][j][1], hv[mi][j][2], hv[mi][j][3], inv, pk.x, pk.y);
-              if (cin[j]) *(uint2*)(xs + (long)m * p.K + cc[j]) = pk;
-            }
-          }
-        } else {
 #pragma unroll
         for (int mi = 0; mi < 4; ++mi) {
           const int m = m0 + mi;
@@ -290,7 +160,6 @@ __global__ __launch_bounds__(256, (XG && MB == 8) ? 1 : 2) void gemv_fused_kerne
             pk.y = pack2bf(o[2], o[3]);
             if (cin[j]) *(uint2*)(xs + (long)m * p.K + cc[j]) = pk;
           }
-        }
         }
       }
     } else {
@@ -341,19 +210,12 @@ __global__ __launch_bounds__(256, (XG && MB == 8) ? 1 : 2) void gemv_fused_kerne
         for (int e = 0; e < 4; ++e) pk.u[e] = pack2bf(o[2 * e] / l, o[2 * e + 1] / l);
       }
       *(bf16x8*)(xs + (long)m * p.K + k0) = pk.v;
-      if constexpr (W8) {  // (the row maximum of the ROUNDED context, as quant_rows_fp8 sees the stored tensor)
-        float am = 0.f;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) am = fmaxf(am, fabsf(bf2f((bf16_t)pk.v[e])));
-        atomicMax(&amax_u[m], __builtin_bit_cast(unsigned, am));
-      }
     }
-    if constexpr (W8) quantise_staged();
-    else __syncthreads();
+    __syncthreads();
   }
 
   float acc[ROWS][MB];
-  auto consume = [&](int i, const wvec* w) {
+  auto consume = [&](int i, const bf16x8* w) {
     // raw 16-bit pairs straight into v_dot2c_f32_(bf16|f16): 4 instructions per (row, batch row) and slice, no conversions
     union X8 { bf16x8 v; uint32_t u[4]; };
     X8 xv[MB];
@@ -367,14 +229,7 @@ __global__ __launch_bounds__(256, (XG && MB == 8) ? 1 : 2) void gemv_fused_kerne
 #pragma unroll
     for (int r = 0; r < ROWS; ++r) {
       X8 wv;
-      if constexpr (W8) {
-        wv.u[0] = fp8x2_to_h16x2<false>(w[r][0]);
-        wv.u[1] = fp8x2_to_h16x2<true>(w[r][0]);
-        wv.u[2] = fp8x2_to_h16x2<false>(w[r][1]);
-        wv.u[3] = fp8x2_to_h16x2<true>(w[r][1]);
-      } else {
-        wv.v = w[r];
-      }
+      wv.v = w[r];
 #pragma unroll
       for (int m = 0; m < MB; ++m) {
         float a = acc[r][m];
@@ -440,11 +295,10 @@ __global__ __launch_bounds__(256, (XG && MB == 8) ? 1 : 2) void gemv_fused_kerne
     __syncthreads();
     if (wave == 0) {
       const int lv = lane & (NV - 1);
-      float val = ((red[0][lv] + red[1][lv]) + red[2][lv]) + red[3][lv];  // waves in a fixed order
+      const float val = ((red[0][lv] + red[1][lv]) + red[2][lv]) + red[3][lv];  // waves in a fixed order
       // ---- epilogue (wave 0; all 64 lanes stay active for the shuffles, lanes >= NV mirror the others and do not write)
       const int rr = lv / MB, m = lv % MB;
       const int n = rr < ROWS / 2 ? e_lo + rr : e_hi + (rr - ROWS / 2);
-      if constexpr (W8) val = val * p.w_scale[n] * xsc[m];  // dequantise: acc * w_scale[n] * a_scale[m], the e4m3 GEMM epilogue's order
       const bool ok = lane < NV && m < p.M;
       if (p.epi == 0) {
         if (ok) ((float*)p.C)[(long)m * p.ldc + n] = val;
@@ -510,8 +364,8 @@ extern "C" int gr_gemv_fused(const gr_gemv_desc* d, hipStream_t stream) {
       return GR_EINVAL;
   }
   const bool w8 = d->w8 != 0;
-  if (w8 && (!d->w_scale || d->K % 8 != 0 || (d->x_mode == 1 && d->K > 4096))) return GR_EINVAL;  // (the wide-row norm prologue has no e4m3 form)
-  const size_t lds = (d->x_mode == 0 && !w8) ? 0 : (size_t)MB * d->K * sizeof(bf16_t);  // the e4m3 stream stages every operand
+  if (w8 && (!d->w_scale || d->K % 128 != 0 || d->N % 16 != 0 || (d->x_mode == 1 && d->K > 4096))) return GR_EINVAL;
+  const size_t lds = (d->x_mode == 0 || w8) ? 0 : (size_t)MB * d->K * sizeof(bf16_t);
   if (lds > 128 * 1024) return GR_EINVAL;
   GemvFArgs p;
   p.W = (const bf16_t*)d->W; p.ldw = d->ldw; p.M = d->M; p.N = d->N; p.K = d->K;
@@ -523,10 +377,8 @@ extern "C" int gr_gemv_fused(const gr_gemv_desc* d, hipStream_t stream) {
   p.w_scale = d->w_scale;
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)gemv_fused_kernel<4, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) != hipSuccess ||
-        hipFuncSetAttribute((const void*)gemv_fused_kernel<8, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) != hipSuccess ||
-        hipFuncSetAttribute((const void*)gemv_fused_kernel<4, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) != hipSuccess ||
-        hipFuncSetAttribute((const void*)gemv_fused_kernel<8, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) != hipSuccess)
+    if (hipFuncSetAttribute((const void*)gemv_fused_kernel<4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) != hipSuccess ||
+        hipFuncSetAttribute((const void*)gemv_fused_kernel<8, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) != hipSuccess)
       return GR_EINVAL;
     attr_set = true;
   }
@@ -539,16 +391,22 @@ extern "C" int gr_gemv_fused(const gr_gemv_desc* d, hipStream_t stream) {
   }
   const int groups = gr_cdiv(d->N, ROWS);
   const dim3 grid(groups < GF_WG_PER_CU * n_cu ? groups : GF_WG_PER_CU * n_cu);  // persistent over row groups
-  const int prof = gr_prof_begin(stream, d->M, d->N, d->K, 8 | 32 | (w8 ? 16 : 0));
-  if (w8) {
-    if (MB == 4) hipLaunchKernelGGL((gemv_fused_kernel<4, false, true>), grid, dim3(256), lds, stream, p);
-    else hipLaunchKernelGGL((gemv_fused_kernel<8, false, true>), grid, dim3(256), lds, stream, p);
-  } else if (d->x_mode == 0) {
-    if (MB == 4) hipLaunchKernelGGL((gemv_fused_kernel<4, true, false>), grid, dim3(256), 0, stream, p);
-    else hipLaunchKernelGGL((gemv_fused_kernel<8, true, false>), grid, dim3(256), 0, stream, p);
+  if (w8) {  // e4m3 weights: the MFMA stream (gemv_fp8.hip)
+    if (d->epi == 3 && d->HD % 32 != 0) return GR_EINVAL;
+    const int prof8 = gr_prof_begin(stream, d->M, d->N, d->K, 8 | 16 | 32);
+    const int rc = gr_launch_gemv_fp8(p, MB, n_cu, stream);
+    gr_prof_end(stream, prof8);
+    if (rc != GR_OK) return rc;
+    GR_CHECK_LAUNCH();
+    return GR_OK;
+  }
+  const int prof = gr_prof_begin(stream, d->M, d->N, d->K, 8 | 32);
+  if (d->x_mode == 0) {
+    if (MB == 4) hipLaunchKernelGGL((gemv_fused_kernel<4, true>), grid, dim3(256), 0, stream, p);
+    else hipLaunchKernelGGL((gemv_fused_kernel<8, true>), grid, dim3(256), 0, stream, p);
   } else {
-    if (MB == 4) hipLaunchKernelGGL((gemv_fused_kernel<4, false, false>), grid, dim3(256), lds, stream, p);
-    else hipLaunchKernelGGL((gemv_fused_kernel<8, false, false>), grid, dim3(256), lds, stream, p);
+    if (MB == 4) hipLaunchKernelGGL((gemv_fused_kernel<4, false>), grid, dim3(256), lds, stream, p);
+    else hipLaunchKernelGGL((gemv_fused_kernel<8, false>), grid, dim3(256), lds, stream, p);
   }
   gr_prof_end(stream, prof);
   GR_CHECK_LAUNCH();

@@ -641,9 +641,9 @@ class LlamaEngine:
         past = 0 if dyn else cache.seq_len
         if not dyn and past + L > cache.smax:
             cache.grow(_ru(past + L + 64, 64))
-        # (e4m3 weights, round 5: the fused streams read the e4m3 bytes -- half the HBM traffic per token; their operand staging
-        #  holds M x K 16-bit values in LDS, which fits up to 4 rows at the down-projection's K = 11 008)
-        fits8 = not w["fp8"] or _ru(bs, 4) * max(T, self.I) * 2 <= 128 * 1024
+        # (e4m3 weights, round 5: the streams read the e4m3 bytes on the matrix unit -- csrc/gemv_fp8.hip, half the HBM traffic per
+        #  token; the quantised operand is staged as M x K bytes in LDS, plus the merged context as 16-bit values in the o-proj)
+        fits8 = not w["fp8"] or (_ru(bs, 4) * (max(T, self.I) + 16) <= 128 * 1024 and _ru(bs, 4) * (3 * T + 16) <= 128 * 1024 and T <= 4096)
         if FUSED_DECODE and L == 1 and M <= 8 and fits8 and T <= 8192 and cache.smax <= 8192 and ops.SP() == 1 and states is None:
             return self._decode_forward(h, bs, cache, kv_len, pos_dev, pos_stride, past)
         # A decode step that does not fit the weight-streaming path (more than 8 rows, e4m3 operands, > 8192 keys) runs the
