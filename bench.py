@@ -457,26 +457,35 @@ def extras_block(model, cfg, args, dev, P):
         g = line(model, 4, True, steps=3, warmup=3, roof="hbm")
     finally:
         model.generation_config.eos_token_id = eos
-    g["new_tokens"] = args.new_tokens
-    try:  # per decode step: (generate - prefill) / new tokens against the 13.2 GB of weights every token streams once
-        pre = ex["forward_4_images_per_call"]["ms_per_step"]
-        tok_ms = (g["ms_per_step"] - pre) / max(args.new_tokens - 1, 1)
-        wbytes = sum(t.numel() * t.element_size() for L in model.llm.w["layers"] for t in (L["wqkv"][0], L["wo"][0], L["wgu"][0], L["wd"][0]))
-        wbytes += model.llm.w["head"].numel() * model.llm.w["head"].element_size()
-        g["decode_step"] = {"ms_per_token": tok_ms, "weight_bytes_per_token": wbytes, "hbm_GBps_end_to_end": wbytes / (tok_ms * 1e-3) / 1e9,
-                            "frac_of_8TBps": wbytes / (tok_ms * 1e-3) / 8e12,
-                            "note": "(generate ms - 4-image prefill ms) / (new_tokens - 1): everything a token costs, not only the GEMV launches"}
-    except Exception as e:
-        g["decode_step"] = {"error": str(e)}
-    g["workload"] = "configs[3] per-GPU share: prefill + greedy decode (hipGraph replay), no EOS"
-    ex["generate_4_images_per_call"] = g
-    def other(name, dtype_note, steps=5, **kw):
-        """a line measured on another model instance (built, measured, freed)"""
+    def decode_step(m, g, pre_ms):
+        """per decode step: (generate - prefill) / new tokens against the weight bytes every token streams once (13.2 GB 16-bit, 6.6 GB e4m3)"""
+        g["new_tokens"] = args.new_tokens
+        try:
+            tok_ms = (g["ms_per_step"] - pre_ms) / max(args.new_tokens - 1, 1)
+            head = m.llm.w["head8"][0] if (m.fp8 and "head8" in m.llm.w) else m.llm.w["head"]
+            wbytes = sum(t.numel() * t.element_size() for L in m.llm.w["layers"] for t in (L["wqkv"][0], L["wo"][0], L["wgu"][0], L["wd"][0]))
+            wbytes += head.numel() * head.element_size()
+            g["decode_step"] = {"ms_per_token": tok_ms, "weight_bytes_per_token": wbytes, "hbm_GBps_end_to_end": wbytes / (tok_ms * 1e-3) / 1e9,
+                                "frac_of_8TBps": wbytes / (tok_ms * 1e-3) / 8e12,
+                                "note": "(generate ms - 4-image prefill ms) / (new_tokens - 1): everything a token costs, not only the weight-stream launches"}
+        except Exception as e:
+            g["decode_step"] = {"error": str(e)}
+        g["workload"] = "configs[3] per-GPU share: prefill + greedy decode (hipGraph replay), no EOS"
+        return g
+    ex["generate_4_images_per_call"] = decode_step(model, g, ex["forward_4_images_per_call"]["ms_per_step"])
+    def other(name, dtype_note, steps=5, gen_name=None, **kw):
+        """a line measured on another model instance (built, measured, freed); gen_name: also its greedy generate at 4 images per call"""
         m = GromaModel.from_synthetic(cfg, seed=0, device=dev, **kw)
         m.init_special_token_id(constants.SyntheticTokenizer())
         r = line(m, args.batch, False, steps=steps, warmup=3, roof="mfma")
         r["dtype"], r["precision"] = dtype_note, m.mode
         ex[name] = r
+        if gen_name:
+            m.generation_config.eos_token_id = None
+            pre = line(m, 4, False, steps=5, warmup=3)
+            gg = decode_step(m, line(m, 4, True, steps=3, warmup=3, roof="hbm"), pre["ms_per_step"])
+            gg["dtype"], gg["precision"], gg["prefill_ms_4_images"] = dtype_note, m.mode, pre["ms_per_step"]
+            ex[gen_name] = gg
         del m
         torch.cuda.empty_cache()
 
@@ -487,7 +496,8 @@ def extras_block(model, cfg, args, dev, P):
     else:
         other("forward_hybrid", "precision='hybrid': the ViT on operand pairs, the rest bf16", precision="hybrid")
     other("forward_fp8", "fp8: OCP e4m3 operands (MX-rate MFMA) for the LLaMA linears, lm_head and the region encoder's 3x3 / per-ROI convs, f32 "
-          "accumulate; the ViT on operand pairs (precision='hybrid', fp8=True), so the e4m3 build holds the index contract too", precision="hybrid", fp8=True)
+          "accumulate; the ViT on operand pairs (precision='hybrid', fp8=True), so the e4m3 build holds the index contract too; its decode step streams "
+          "the e4m3 bytes on the matrix unit (csrc/gemv_fp8.hip)", gen_name="generate_fp8_4_images_per_call", precision="hybrid", fp8=True)
     other("forward_fp8_e4m3_vit", "fp8 in every stage incl. the ViT linears (round 4's forward_fp8)", fp8=True)
     other("forward_fp16", "fp16 (IEEE half operands through libgroma_hip_f16.so, f32 accumulate: the reference's inference autocast dtype) behind a "
           "pair-operand ViT (precision='hybrid-fp16')", precision="hybrid-fp16")
@@ -506,7 +516,7 @@ def extras_summary(ex):
             rf = v.get("roofline") or {}
             out[k] = [round(v["value"], 2), round(rf["frac"], 3) if "frac" in rf else None]
             if "decode_step" in v and "ms_per_token" in v["decode_step"]:
-                out["decode_ms_per_token"] = [round(v["decode_step"]["ms_per_token"], 3), round(v["decode_step"]["frac_of_8TBps"], 3)]
+                out[("decode_fp8" if "fp8" in k else "decode") + "_ms_per_token"] = [round(v["decode_step"]["ms_per_token"], 3), round(v["decode_step"]["frac_of_8TBps"], 3)]
     return out
 
 
