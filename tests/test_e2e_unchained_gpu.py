@@ -130,3 +130,37 @@ def test_16bit_operands_unchained_survival_is_measured(dev, name, precision):
         r = _compare(name, precision, row)
         assert r["topk_set"] >= 0.8 and r["nms_set"] >= 0.5
         assert r["vit"] < (2e-2 if precision == "bf16" else 3e-3)
+
+
+def test_hybrid_generate_tokens_and_boxes_unchained(dev):
+    """generate() of the benchmarked build against HF-greedy over the oracle running its OWN ViT (R: groma/eval/eval_rec.py:93-104 over
+    groma/model/groma.py:176-200,376-402): the selected boxes the caller reads back (`hidden_states[0][-1]['pred_boxes']`) are the
+    oracle's boxes in the oracle's order, and every greedy token equals the oracle's -- a mismatch is only accepted at a step whose
+    oracle top-2 margin is inside the bf16 band (tests/util.assert_greedy_tokens_match).  The <r_k> rows of extra_lm_head are boosted
+    as in tests/test_parity_gpu.py::gen_setup so that the margins are far outside that band."""
+    from tests.golden.select_e2e_seeds import e2e_cfg
+    from groma_amd import constants, synth
+    from groma_amd.groma import GromaModel
+    cfg = e2e_cfg("tiny")
+    sd = dict(synth.make_state_dict(cfg, 0))
+    w = sd["extra_lm_head.weight"].clone()
+    w[w.shape[0] - 100:] *= 40.0
+    sd["extra_lm_head.weight"] = w
+    model = GromaModel.from_state_dict(cfg, sd, "cuda", precision="hybrid")
+    model.init_special_token_id(constants.SyntheticTokenizer())
+    model.generation_config.eos_token_id = None
+    tk = util.TokenIds()
+    total = 0
+    for row in _rows("tiny"):
+        images, ids = synth.make_inputs(cfg, tk, 1, seed=row["seed"])
+        torch.manual_seed(row["seed"])
+        out = model.generate(ids.clone(), images=images, max_new_tokens=5, return_dict_in_generate=True, output_hidden_states=True)
+        torch.manual_seed(row["seed"])
+        with torch.no_grad():
+            ref = O.greedy_generate(sd, cfg.to_dict(), util.tok_dict(tk), ids.clone(), images, 5, eos_token_id=-1)   # hidden_states=None: its own ViT
+        boxes = out.hidden_states[0][-1]["pred_boxes"][0].float().cpu()
+        assert boxes.shape == ref["pred_boxes"][0].shape and torch.allclose(boxes, ref["pred_boxes"][0], atol=1e-5)
+        P = ids.shape[1]
+        total += util.assert_greedy_tokens_match(out.sequences[:, P:].cpu(), ref["sequences"][:, P:], ref["margins"], 0.05,
+                                                 f"hybrid generate, seed {row['seed']}")
+    assert total >= 10
