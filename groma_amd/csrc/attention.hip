@@ -51,13 +51,13 @@ extern "C" int gr_diag_att_clk(unsigned long long* out) { return (int)hipMemcpyF
 #endif
 
 // (soft-max row statistics are reduced across the four 16-lane rows with rows_max / rows_sum, gr_common.h)
-#ifndef ATT_G
-#if GR_SP
-#define ATT_G (HD == 128 ? 4 : 2)  // (each fragment is a hi / lo pair in the split build)
-#else
-#define ATT_G (HD == 128 ? 8 : 2)  // K / V^T fragments per prefetch group (A/B: hd 128 -5 % with 8, hd 64 neutral)
+#ifndef ATT_G64
+#define ATT_G64 2   // K / V^T fragments per prefetch group at head dim 64
 #endif
+#ifndef ATT_G128
+#define ATT_G128 (GR_SP ? 4 : 8)  // ... at head dim 128 (A/B: -5 % with 8; each fragment is a hi / lo pair in the split build)
 #endif
+#define ATT_G (HD == 128 ? ATT_G128 : ATT_G64)
 // Split-operand build (gr_common.h): q, K, V^T and the context are (hi, lo) pairs in 32-element blocks, so a K row is 2*hd
 // physical elements whose 16-B chunk 8*kk + g holds the hi halves of d = 32*kk + 8*g.. and chunk 8*kk + 4 + g their lo halves, a
 // 64-key V^T tile row is 128 physical elements (chunk 8*tt + g = hi of keys 32*tt + 8*g.., + 4 = lo), and both contractions
@@ -90,6 +90,31 @@ extern "C" int gr_diag_att_clk(unsigned long long* out) { return (int)hipMemcpyF
 #else
 #define ATT_MFMA_BEGIN
 #define ATT_MFMA_END
+#endif
+
+// (score sub-tile j, k-step kk) of fragment e of prefetch group g.  Round 5: inside a group the k-step is the SLOW index when the
+// group spans several sub-tiles (hd 128: 8 fragments = 2 sub-tiles x 4 k-steps), so that consecutive MFMAs go to different
+// accumulators (s[u][j]: 2 q-tiles x 2 sub-tiles = 4 independent chains) instead of four dependent MFMAs per accumulator in a row.
+// Measured flat (profiles/r05_attn_variants.txt: 91.3 vs 91.6 us at 14 x 32 heads, 113.7 vs 112.2 us on the ViT shape, pair build 291.4
+// vs 291.6): the dependent-MFMA spacing is not what the kernel waits for.  OFF by default (= round 4's accumulation order, bitwise).
+#ifndef ATT_S_ORDER
+#define ATT_S_ORDER 0
+#endif
+template <int GK, int NKK>
+__device__ __forceinline__ constexpr int att_step_j(int g, int e) {
+  constexpr int NJ = GK / NKK;  // whole sub-tiles per group (0: a group is part of one sub-tile)
+  return (ATT_S_ORDER && NJ > 1) ? g * NJ + e % NJ : (g * GK + e) / NKK;
+}
+template <int GK, int NKK>
+__device__ __forceinline__ constexpr int att_step_kk(int g, int e) {
+  constexpr int NJ = GK / NKK;
+  return (ATT_S_ORDER && NJ > 1) ? e / NJ : (g * GK + e) % NKK;
+}
+// ATT_SUM4: the soft-max row sum / row max of a lane's 16 scores as 4 independent partial chains (one per sub-tile) combined at the
+// end, instead of one serial chain of 16 dependent adds / 8 dependent max3 (dependent VALU issues at ~0.6 of the independent rate)
+// Measured neutral-to-slower (30.2 vs 29.0 us at 4 images, 115.0 vs 112.2 us on the ViT shape): OFF.
+#ifndef ATT_SUM4
+#define ATT_SUM4 0
 #endif
 
 template <int HD>
@@ -304,7 +329,7 @@ __global__ __launch_bounds__(256, GR_SP ? 1 : 2) void attention_kernel(AttnArgs 
     auto load_k = [&](int g, bf16x8* dst) {
 #pragma unroll
       for (int e = 0; e < GK; ++e) {
-        const int step = g * GK + e, j = step / (HD / 32), kk = step % (HD / 32);
+        const int j = att_step_j<GK, HD / 32>(g, e), kk = att_step_kk<GK, HD / 32>(g, e);
         const int row = (j >> 1) * 32 + (fr >> 2) * 8 + (j & 1) * 4 + (fr & 3);
         dst[e] = *(const bf16x8*)(ksm + row * KROW + (((kk * 4 * SPW + fg) ^ kswz(row)) << 4));
 #if GR_SP
@@ -318,9 +343,21 @@ __global__ __launch_bounds__(256, GR_SP ? 1 : 2) void attention_kernel(AttnArgs 
     for (int g = 0; g < NKG; ++g) {
       if (g + 1 < NKG) load_k(g + 1, kfr[(g + 1) & 1]);
       __builtin_amdgcn_sched_barrier(0);
+#if GR_SP && ATT_S_ORDER
+      // pair build: the three passes are the SLOW index, so an accumulator is revisited every GK * QT MFMAs, not every QT
+#pragma unroll
+      for (int pp = 0; pp < 3; ++pp)
+#pragma unroll
+        for (int e = 0; e < GK; ++e) {
+          const int j = att_step_j<GK, HD / 32>(g, e), kk = att_step_kk<GK, HD / 32>(g, e);
+#pragma unroll
+          for (int u = 0; u < QT; ++u)
+            s[u][j] = GR_MFMA_16x16x32(kfr[g & 1][pp == 2 ? GK + e : e], pp == 1 ? qfl[u][kk] : qf[u][kk], s[u][j]);
+        }
+#else
 #pragma unroll
       for (int e = 0; e < GK; ++e) {
-        const int step = g * GK + e, j = step / (HD / 32), kk = step % (HD / 32);
+        const int j = att_step_j<GK, HD / 32>(g, e), kk = att_step_kk<GK, HD / 32>(g, e);
 #pragma unroll
         for (int u = 0; u < QT; ++u) s[u][j] = GR_MFMA_16x16x32(kfr[g & 1][e], qf[u][kk], s[u][j]);
 #if GR_SP
@@ -330,6 +367,7 @@ __global__ __launch_bounds__(256, GR_SP ? 1 : 2) void attention_kernel(AttnArgs 
         for (int u = 0; u < QT; ++u) s[u][j] = GR_MFMA_16x16x32(kfr[g & 1][GK + e], qf[u][kk], s[u][j]);
 #endif
       }
+#endif
       __builtin_amdgcn_sched_barrier(0);
     }
     ATT_MFMA_END
@@ -347,7 +385,7 @@ __global__ __launch_bounds__(256, GR_SP ? 1 : 2) void attention_kernel(AttnArgs 
       constexpr bool MASKED = decltype(masked_tag)::value;
 #pragma unroll
       for (int u = 0; u < QT; ++u) {
-        float mx = -1e30f;
+        float mxp[4] = {-1e30f, -1e30f, -1e30f, -1e30f};
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -356,13 +394,14 @@ __global__ __launch_bounds__(256, GR_SP ? 1 : 2) void attention_kernel(AttnArgs 
               const int key = kv0 + (j >> 1) * 32 + fg * 8 + (j & 1) * 4 + r;
               if (key >= limit[u]) s[u][j][r] = -1e30f;
             }
-            mx = fmaxf(mx, s[u][j][r]);
+            mxp[ATT_SUM4 ? j : 0] = fmaxf(mxp[ATT_SUM4 ? j : 0], s[u][j][r]);
           }
+        float mx = fmaxf(fmaxf(mxp[0], mxp[1]), fmaxf(mxp[2], mxp[3]));
         mx = rows_max(mx);
         const float m_new = fmaxf(m_run[u], mx);
         const float alpha = __builtin_amdgcn_exp2f((m_run[u] - m_new) * cs);
         const float mc = -m_new * cs;
-        float rs = 0.f;
+        float rsp[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -372,8 +411,9 @@ __global__ __launch_bounds__(256, GR_SP ? 1 : 2) void attention_kernel(AttnArgs 
             float e = __builtin_amdgcn_exp2f(__builtin_fmaf(s[u][j][r], cs, mc));
             if (MASKED) e = s[u][j][r] <= -1e30f ? 0.f : e;
             s[u][j][r] = e;
-            rs += e;
+            rsp[ATT_SUM4 ? j : 0] += e;
           }
+        float rs = (rsp[0] + rsp[1]) + (rsp[2] + rsp[3]);
         rs = rows_sum(rs);
         l_run[u] = l_run[u] * alpha + rs;
         m_run[u] = m_new;
@@ -429,6 +469,17 @@ __global__ __launch_bounds__(256, GR_SP ? 1 : 2) void attention_kernel(AttnArgs 
     for (int g = 0; g < NG; ++g) {
       if (g + 1 < NG) load_v(g + 1, vfr[(g + 1) & 1]);
       __builtin_amdgcn_sched_barrier(0);
+#if GR_SP && ATT_S_ORDER
+#pragma unroll
+      for (int pp = 0; pp < 3; ++pp)   // (passes slow, fragments fast: an accumulator is revisited every GV * QT MFMAs)
+#pragma unroll
+        for (int e = 0; e < GV; ++e) {
+          const int step = g * GV + e, tt = step / (HD / 16), n = step % (HD / 16);
+#pragma unroll
+          for (int u = 0; u < QT; ++u)
+            o[u][n] = GR_MFMA_16x16x32(vfr[g & 1][pp == 2 ? GV + e : e], pp == 1 ? pbl[u][tt].v : pb[u][tt].v, o[u][n]);
+        }
+#else
 #pragma unroll
       for (int e = 0; e < GV; ++e) {
         const int step = g * GV + e, tt = step / (HD / 16), n = step % (HD / 16);
@@ -441,6 +492,7 @@ __global__ __launch_bounds__(256, GR_SP ? 1 : 2) void attention_kernel(AttnArgs 
         for (int u = 0; u < QT; ++u) o[u][n] = GR_MFMA_16x16x32(vfr[g & 1][GV + e], pb[u][tt].v, o[u][n]);
 #endif
       }
+#endif
       __builtin_amdgcn_sched_barrier(0);
     }
     ATT_MFMA_END
