@@ -272,6 +272,9 @@ def test_fp8_chained_logits_and_vit_states_at_width(f8):
     # sums differ in the last bits re-quantise a few values one e4m3 step apart, and every later stage amplifies that)
     assert e_impl < 0.6 * e_b16d
     assert abs(e_b16d - o_fmt) < 0.5 * o_fmt       # and the device's format error is the oracle's format error
+    # the stated tolerance relative to what is MEASURED -- the device may exceed the e4m3 FORMAT's own distance
+    # from bf16 (the oracle's, 9.27e-2 on this stack) by at most 5 %; the flat 1e-1 above is 1.08x the measured value
+    assert e_b16d <= 1.05 * o_fmt
     vs = [rel(a, b) for a, b in zip(d["hidden4"], ref["e4m3"][1])]
     vb = [rel(a, b) for a, b in zip(d["hidden4"], h16)]
     print(f"[fp8 chained] ViT states (0..3 layers deep): vs e4m3-rounded oracle {[f'{x:.2e}' for x in vs]} | vs bf16 device {[f'{x:.2e}' for x in vb]}")

@@ -33,10 +33,22 @@ def _format_gates(r, slack):
         assert d16 <= d32 * 1.05, (name, r[name])
 
 
+# ABSOLUTE bounds (relative L2 against the fp32 oracle) at the real depth, next to the format-relative gates: what a caller of the
+# bf16-behind-the-ViT builds can rely on whatever the format's own distance happens to be.  Measured: image
+# tokens 3.4e-3, region tokens 5.2e-3, K cache layer 0 / 31 4.7e-3 / 2.6e-2, logits 2.6e-2, <r_k> logits 3.4e-2.
+BF16_ABS = dict(image_tokens=5e-3, region_tokens=7e-3, k0=6e-3, k31=3.2e-2, logits=3.2e-2, region_logits=4.5e-2)
+
+
+def _absolute_gates(r, bounds):
+    for name, bound in bounds.items():
+        assert r[name][0] <= bound, (name, r[name], bound)
+
+
 def test_full_depth_distinct_weights_vs_both_oracles(dev):
     r = _diag().run()
     assert r["topk_equal"] and r["nms_equal"] and r["ids_equal"] and r["L"] == 582
     _format_gates(r, 1.5)
+    _absolute_gates(r, BF16_ABS)
     for d32, d16, fmt in r["vit"][1:]:
         assert d32 <= 1.5 * fmt and d32 < 1e-2
     d32, d16, fmt = r["logits"]
@@ -82,6 +94,7 @@ def test_full_depth_hybrid_precision_unchained(dev):
     for d32, _, _ in r["vit"]:
         assert d32 < 1e-4
     _format_gates(r, 1.5)
+    _absolute_gates(r, BF16_ABS)      # the benchmarked build: absolute bounds, unchained
     d32, d16, fmt = r["logits"]
     assert d32 <= 1.1 * fmt
     assert r["argmax_agree_clear"] == 1.0
