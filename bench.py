@@ -474,7 +474,15 @@ def extras_block(model, cfg, args, dev, P):
         return g
     ex["generate_4_images_per_call"] = decode_step(model, g, ex["forward_4_images_per_call"]["ms_per_step"])
     def other(name, dtype_note, steps=5, gen_name=None, **kw):
-        """a line measured on another model instance (built, measured, freed); gen_name: also its greedy generate at 4 images per call"""
+        """a line measured on another model instance (built, measured, freed); gen_name: also its greedy generate at 4 images per call.
+        A failure costs this line only (the error is reported in its place), never the lines already measured."""
+        try:
+            _other(name, dtype_note, steps, gen_name, **kw)
+        except Exception as e:
+            ex[name] = {"error": f"{type(e).__name__}: {e}"}
+            torch.cuda.empty_cache()
+
+    def _other(name, dtype_note, steps, gen_name, **kw):
         m = GromaModel.from_synthetic(cfg, seed=0, device=dev, **kw)
         m.init_special_token_id(constants.SyntheticTokenizer())
         r = line(m, args.batch, False, steps=steps, warmup=3, roof="mfma")

@@ -5,6 +5,44 @@
 #include "gr_common.h"
 #include "../../include/groma_hip.h"
 
+// Single-pass form for 16-bit rows of K <= 12 288 (round 5): the row lives in registers -- every load of the row is issued before the
+// first use, the maximum is taken, and the SAME registers are quantised -- instead of a second read (the generic kernel below walks
+// the row twice, chunk by chunk).  Same arithmetic, same bytes out.
+template <int NCH>  // 512-element chunks per row held per wave (K <= 512 * NCH)
+__global__ __launch_bounds__(256) void quant_rows_fp8_reg_kernel(const bf16_t* __restrict__ x, uint8_t* __restrict__ q,
+                                                                 float* __restrict__ scale, int rows, int K, long ldx) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const bf16_t* xr = x + (long)row * ldx;
+  bf16x8 v[NCH];
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int k = i * 512 + lane * 8;
+    v[i] = k < K ? *(const bf16x8*)(xr + k) : (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+  }
+  float amax = 0.f;
+#pragma unroll
+  for (int i = 0; i < NCH; ++i)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) amax = fmaxf(amax, fabsf(bf2f((bf16_t)v[i][e])));
+  amax = wave_max(amax);
+  const float s = fmaxf(amax, 1e-20f) / 448.0f;
+  const float inv = 1.0f / s;
+  if (lane == 0) scale[row] = s;
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int k = i * 512 + lane * 8;
+    float f[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) f[e] = bf2f((bf16_t)v[i][e]);
+    uint2 o;
+    o.x = pack4_fp8(f[0] * inv, f[1] * inv, f[2] * inv, f[3] * inv);
+    o.y = pack4_fp8(f[4] * inv, f[5] * inv, f[6] * inv, f[7] * inv);
+    if (k < K) *(uint2*)(q + (long)row * K + k) = o;
+  }
+}
+
 template <bool F32>
 __global__ __launch_bounds__(256) void quant_rows_fp8_kernel(const void* __restrict__ x, uint8_t* __restrict__ q,
                                                              float* __restrict__ scale, int rows, int K, long ldx) {
@@ -52,7 +90,17 @@ extern "C" int gr_quant_rows_fp8(const void* x, int x_is_f32, void* q, float* sc
                                  hipStream_t stream) {
   if (GR_SP) return GR_EINVAL;  // the streaming decode / e4m3 kernels do not exist in the split-operand build (gr_common.h)
   if (!x || !q || !scale || rows <= 0 || K <= 0 || K % 8 != 0 || ldx % 8 != 0) return GR_EINVAL;
-  if (x_is_f32)
+#ifndef FP8_QUANT_REG
+#define FP8_QUANT_REG 1
+#endif
+  if (FP8_QUANT_REG && !x_is_f32 && K <= 12288) {
+    const dim3 g(gr_cdiv(rows, 4)), b(256);
+    const bf16_t* xb = (const bf16_t*)x;
+    if (K <= 1024) hipLaunchKernelGGL(quant_rows_fp8_reg_kernel<2>, g, b, 0, stream, xb, (uint8_t*)q, scale, rows, K, ldx);
+    else if (K <= 4096) hipLaunchKernelGGL(quant_rows_fp8_reg_kernel<8>, g, b, 0, stream, xb, (uint8_t*)q, scale, rows, K, ldx);
+    else if (K <= 11264) hipLaunchKernelGGL(quant_rows_fp8_reg_kernel<22>, g, b, 0, stream, xb, (uint8_t*)q, scale, rows, K, ldx);
+    else hipLaunchKernelGGL(quant_rows_fp8_reg_kernel<24>, g, b, 0, stream, xb, (uint8_t*)q, scale, rows, K, ldx);
+  } else if (x_is_f32)
     hipLaunchKernelGGL(quant_rows_fp8_kernel<true>, dim3(gr_cdiv(rows, 4)), dim3(256), 0, stream, x, (uint8_t*)q, scale, rows,
                        K, ldx);
   else

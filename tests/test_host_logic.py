@@ -505,3 +505,31 @@ def test_e4m3_conv_scale_and_oracle_conv_agree_with_the_packer():
     assert float(xq.max()) == 448.0                   # the clamp, not a NaN code
     # and the format's own distance on this input stays at the e4m3 level (3 mantissa bits on both operands)
     assert util.relerr(y, F.conv2d(x.clamp(max=448 * s), w, padding=1)) < 8e-2
+
+
+def test_host_select_draws_like_the_reference_loop():
+    """GromaModel._host_select (round 5: the general-path shuffle of propose(), also what `bench.py --host-glue` times): the same
+    torch.randperm draws in image order as the reference's per-image loop (R: groma/model/groma.py:273-276, T4), the same global RNG
+    state afterwards, and a flat gather list that addresses [image * nmax + index]"""
+    from groma_amd.groma import GromaModel
+    g = torch.Generator().manual_seed(3)
+    keep = torch.stack([torch.randperm(300, generator=g)[:100] for _ in range(5)])
+    n_keep = [100, 37, 100, 1, 64]
+    torch.manual_seed(11)
+    want = [keep[i].index_select(0, torch.randperm(n)) for i, n in enumerate(n_keep)]
+    state = torch.get_rng_state()
+    torch.manual_seed(11)
+    sel, flat, img_of = GromaModel._host_select(keep, n_keep, 300)
+    assert torch.equal(torch.get_rng_state(), state)
+    assert all(torch.equal(a, b) for a, b in zip(sel, want))
+    assert torch.equal(flat, torch.cat([w + 300 * i for i, w in enumerate(want)]))
+    assert img_of.tolist() == sum(([i] * n for i, n in enumerate(n_keep)), [])
+    # malformed prompts fail like the reference's tensor comparison does (RuntimeError, not a silent first-match)
+    import pytest
+    from groma_amd import config, constants
+    m = GromaModel(config.groma_tiny())
+    m.init_special_token_id(constants.SyntheticTokenizer())
+    ids = torch.full((1, 12), 7, dtype=torch.int64)
+    ids[0, 2], ids[0, 4], ids[0, 6] = m.img_token_id, m.img_token_id, m.reg_token_id
+    with pytest.raises(RuntimeError):
+        m._splice(ids, 4, [2])
