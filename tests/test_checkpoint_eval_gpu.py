@@ -52,6 +52,19 @@ def test_from_pretrained_on_device_matches_state_dict_model_and_oracle(dev, tmp_
     assert torch.equal(m32._last_aux["nms_keep"][0], ref32["nms_inds"][0]) and torch.equal(m32._last_aux["input_ids"], ref32["input_ids"])
     assert util.relerr(o32.logits, ref32["logits"]) < 1e-4
     del m32
+    # precision="hybrid" through from_pretrained: the build bench.py runs -- the ViT packed as operand pairs, the rest bf16; bitwise the
+    # model built from the in-memory state dict, its index-valued results those of the UNCHAINED oracle given the pair ViT's states
+    mh = GromaModel.from_pretrained(str(d), precision="hybrid")
+    mh.init_special_token_id(constants.SyntheticTokenizer())
+    assert (mh.precision, mh.vit_precision, mh.mode) == ("bf16", "ref", "hybrid")
+    mh_ref = GromaModel.from_state_dict(cfg, sd, "cuda", precision="hybrid")
+    mh_ref.init_special_token_id(constants.SyntheticTokenizer())
+    torch.manual_seed(4)
+    oh = mh.forward(input_ids=ids.clone(), images=images, return_dict=True)
+    torch.manual_seed(4)
+    assert torch.equal(oh.logits, mh_ref.forward(input_ids=ids.clone(), images=images, return_dict=True).logits)
+    assert util.relerr(oh.logits, outs[0].logits) < 5e-1 and not torch.equal(mh._last_aux["hidden4"][-1], model._last_aux["hidden4"][-1])
+    del mh, mh_ref
     # .bin shards load the same
     d2 = tmp_path / "bin"
     cfg.save_pretrained(d2)

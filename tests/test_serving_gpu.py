@@ -185,3 +185,21 @@ def test_warm_admission_captures_before_live_traffic(setup):
         b2.submit(ids, image, max_new_tokens=6, seed=seed)
         b2.step()
         b2.warm_admission(ids, image)                                                   # too late: a slot is taken
+
+
+def test_batcher_over_a_hybrid_model_equals_its_generate(setup):
+    """the continuous batcher over precision="hybrid" (the benchmarked build: pair-operand ViT inside the admission prefill, bf16 decode
+    streams): a request's tokens equal generate() of the same model at batch 1, alone or beside a neighbour"""
+    from groma_amd import constants
+    from groma_amd.groma import GromaModel
+    from groma_amd.serving import ContinuousBatcher
+    cfg, model, reqs = setup
+    cfg0, sd, tk = util.tiny_setup(seed=0)
+    mh = GromaModel.from_state_dict(cfg0, sd, "cuda", precision="hybrid")
+    mh.init_special_token_id(constants.SyntheticTokenizer())
+    mh.generation_config.eos_token_id = None
+    b = ContinuousBatcher(mh, max_rows=2, max_len=1024)
+    rids = [b.submit(ids, image, max_new_tokens=n, seed=seed) for ids, image, n, seed in reqs[:3]]
+    res = b.run_until_done()
+    for rid, (ids, image, n, seed) in zip(rids, reqs[:3]):
+        assert res[rid].error is None and res[rid].tokens == _solo_generate(mh, ids, image, n, seed)
