@@ -643,10 +643,11 @@ class LlamaEngine:
             cache.grow(_ru(past + L + 64, 64))
         # (e4m3 weights, round 5: the streams read the e4m3 bytes on the matrix unit -- csrc/gemv_fp8.hip, half the HBM traffic per
         #  token; the quantised operand is staged as M x K bytes in LDS, plus the merged context as 16-bit values in the o-proj)
-        fits8 = not w["fp8"] or (_ru(bs, 4) * (max(T, self.I) + 16) <= 128 * 1024 and _ru(bs, 4) * (3 * T + 16) <= 128 * 1024 and T <= 4096)
+        fits8 = not w["fp8"] or (_ru(bs, 4) * (max(T, self.I) + 16) <= 128 * 1024 and _ru(bs, 4) * (3 * T + 16) <= 128 * 1024 and T <= 4096
+                                 and max(T, self.I) <= 12288 and T % 128 == 0 and self.I % 128 == 0 and self.Vpad % 16 == 0)
         if FUSED_DECODE and L == 1 and M <= 8 and fits8 and T <= 8192 and cache.smax <= 8192 and ops.SP() == 1 and states is None:
             return self._decode_forward(h, bs, cache, kv_len, pos_dev, pos_stride, past)
-        # A decode step that does not fit the weight-streaming path (more than 8 rows, e4m3 operands, > 8192 keys) runs the
+        # A decode step that does not fit the weight-streaming path (more than 8 rows, pair operands, > 8192 keys) runs the
         # general kernels below.  Its scratch may be baked into GreedyDecoder's captured hipGraph, so -- like _decode_forward --
         # it uses dedicated never-moved tensors (a later, larger prefill regrows the shared arenas and would free memory the
         # graph still addresses) and leaves its logits in the same `dec_logits` buffer the sampler reads.
