@@ -309,7 +309,8 @@ def gemv_partials(a, w, M=None, a_parts=None):
 
 
 def gemv_fused(w, *, M, x=None, norm=None, a_parts=None, out=None, resid=None, swiglu_out=None, qkv=None, w_scale=None):
-    """One decode-step weight stream y[M <= 8, N] = x . w[N,K]^T with its producer and consumer fused (csrc/gemv_fused.hip).
+    """One decode-step weight stream y[M <= 8, N] = x . w[N,K]^T with its producer and consumer fused (csrc/gemv_fused.hip; with
+    e4m3 weights + w_scale csrc/gemv_fp8.hip: the operand is quantised per row in the prologue, the products run on the matrix unit).
     Operand (exactly one): x = 16-bit [M,K]; norm = (h f32 [M,K], gamma, eps) -> RMSNorm in the prologue; a_parts = the
     un-merged output of decode_attention(nsplit > 1).
     Result (exactly one): out f32 [M,N]; resid f32 [M,N] (+= y in place); swiglu_out 16-bit [M, N/2] (interleaved gate / up rows);
