@@ -533,3 +533,21 @@ def test_host_select_draws_like_the_reference_loop():
     ids[0, 2], ids[0, 4], ids[0, 6] = m.img_token_id, m.img_token_id, m.reg_token_id
     with pytest.raises(RuntimeError):
         m._splice(ids, 4, [2])
+
+
+def test_bench_extras_summary_shape():
+    """bench.extras_summary: {line: [images/s, roofline fraction | None]} + the decode-step entries, robust to lines that failed"""
+    import importlib.util, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod2", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    ex = {"forward_4_images_per_call": {"value": 75.2512, "roofline": {"frac": 0.49881}},
+          "forward_1_image_per_call": {"value": 37.2},
+          "generate_4_images_per_call": {"value": 24.2, "roofline": {"frac": 0.4986}, "decode_step": {"ms_per_token": 3.6109, "frac_of_8TBps": 0.4571}},
+          "generate_fp8_4_images_per_call": {"value": 29.5, "roofline": {"frac": 0.294}, "decode_step": {"ms_per_token": 3.0582, "frac_of_8TBps": 0.2699}},
+          "forward_ref": {"error": "RuntimeError: out of memory"}}
+    s = bench.extras_summary(ex)
+    assert s["forward_4_images_per_call"] == [75.25, 0.499] and s["forward_1_image_per_call"] == [37.2, None]
+    assert s["decode_ms_per_token"] == [3.611, 0.457] and s["decode_fp8_ms_per_token"] == [3.058, 0.27]
+    assert "forward_ref" not in s and bench.extras_summary({"error": "x"}) == {} and bench.extras_summary(None) == {}
