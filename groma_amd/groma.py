@@ -62,6 +62,7 @@ def _box_iou(b1, b2):  # torchvision.ops.box_iou on a handful of host-side boxes
 
 # precision="hybrid" / "hybrid-fp16": (operand type behind the ViT, operand type of the ViT)
 HYBRID_MODES = {"hybrid": ("bf16", "ref"), "hybrid-fp16": ("fp16", "ref")}
+SPECULATIVE_EXTRACT = os.environ.get("GROMA_SPECULATIVE_EXTRACT", "1") != "0"   # forward(): queue the region extraction before the NMS counts reach the host (off: tests / A-B only)
 
 def _img_of(counts):
     """[0] * counts[0] + [1] * counts[1] + ... as an int64 tensor.  Not torch.repeat_interleave: with a many-thread intra-op pool it
@@ -292,8 +293,9 @@ class GromaModel:
         return hidden4, selected, aux
 
     @_entry
-    def propose(self, hidden4, refer_boxes=None, ground_boxes=None, debug=None, seeds=None):
-        """Steps C-E: DDETR proposer -> fused scores -> on-device NMS -> host randperm (one D2H of <1 KB/image)."""
+    def propose(self, hidden4, refer_boxes=None, ground_boxes=None, debug=None, seeds=None, _defer=False):
+        """Steps C-E: DDETR proposer -> fused scores -> on-device NMS -> host randperm (one D2H of <1 KB/image).
+        _defer=True (internal): returns (spec, finish) right after the launches -- see the comment at the copy below."""
         cfg = self.config
         bs = hidden4[0].shape[0]
         dev = self.device
@@ -339,14 +341,30 @@ class GromaModel:
         # ONE host round trip: kept indices + counts in one D2H copy (the reference syncs at nms / len / randperm too), the
         # CPU-RNG shuffles (T4), then ONE pinned H2D copy of the flat selection and ONE device gather -- the per-image
         # index_select / .to(device) sequence this replaces cost ~1.2 ms of idle GPU per forward in pageable synchronous copies
-        kk_h = torch.cat([keep, n_keep.to(I64)[:, None]], dim=1).cpu()   # (polling an event instead of this blocking copy measured no gain: profiles/r04_host_sync_ab.txt)
+        kk = torch.cat([keep, n_keep.to(I64)[:, None]], dim=1)
+        # _defer (round 5, forward() only): the copy goes over the copy stream into pinned memory and the caller gets `finish` back
+        # BEFORE waiting for it -- it queues the speculative region extraction on the main stream first, so the GPU works through
+        # the RoIAlign / per-ROI conv launches while the host waits for the counts and does its glue (the timeline showed ~1 ms of
+        # idle GPU per step around this sync under the profiler, ~0.5 ms without)
+        wait = self._to_host_async(kk, "kk") if (_defer and spec is not None) else None
+
+        def finish():
+            kk_h = wait().clone() if wait is not None else kk.cpu()   # (polling an event instead of a blocking copy measured no gain: profiles/r04_host_sync_ab.txt)
+            return self._propose_finish(kk_h, spec, pred_boxes, scores, topk_idx, boxes_all, scores_all, nmax, Q, n_extra, seeds, bs)
+        if _defer:
+            return spec, finish
+        return finish()
+
+    def _propose_finish(self, kk_h, spec, pred_boxes, scores, topk_idx, boxes_all, scores_all, nmax, Q, n_extra, seeds, bs):
+        """the host half of propose(): counts checked, CPU-RNG shuffles drawn (or the speculative ones accepted), selection gathered"""
+        dev = self.device
         keep_h, n_keep_l = kk_h[:, :-1], kk_h[:, -1].tolist()
         if spec is not None:
             if all(int(nk) == spec["n"] for nk in n_keep_l):
                 sel = keep_h.gather(1, spec["perms"])                      # [bs, n]: what keep_h[i].index_select(0, perm_i) gives
                 sel_idx = list(sel.unbind(0))
                 aux = dict(pred_boxes=pred_boxes, scores=scores, topk_idx=topk_idx, nms_keep=list(keep_h[:, : spec["n"]].unbind(0)),
-                           sel_idx=sel_idx, boxes_cat=spec["boxes_cat"], img_idx=spec["img_idx"])
+                           sel_idx=sel_idx, boxes_cat=spec["boxes_cat"], img_idx=spec["img_idx"], spec_hit=True)
                 return list(spec["boxes_cat"].split([spec["n"]] * bs)), aux
             if spec["rng"] is not None:
                 torch.set_rng_state(spec["rng"])   # mis-speculated: nothing was consumed as far as the ordinary path can tell
@@ -419,17 +437,22 @@ class GromaModel:
         the one window in which the GPU sits idle (profiles/r04_timeline_b14.txt: 0.6 ms between the two copies)."""
         if not input_ids.is_cuda or input_ids.dtype != I64:
             return None
+        return self._to_host_async(input_ids, "ids_in")
+
+    def _to_host_async(self, t, name):
+        """int64 device tensor -> the pinned buffer `name`, over the copy stream; returns wait() -> the host view (valid until the
+        next copy into the same buffer)"""
         cp = self.__dict__.get("_copy_stream")
         if cp is None:
             cp = self._copy_stream = torch.cuda.Stream(device=self.device)
         cur = torch.cuda.current_stream()
-        host = self._pinned("ids_in", input_ids.numel())[: input_ids.numel()].view(input_ids.shape)  # (reused page-locked buffer)
-        cp.wait_stream(cur)        # (whoever produced the ids did so on the caller's stream)
+        host = self._pinned(name, t.numel())[: t.numel()].view(t.shape)  # (reused page-locked buffer)
+        cp.wait_stream(cur)        # (whoever produced the values did so on the caller's stream)
         with torch.cuda.stream(cp):
-            host.copy_(input_ids, non_blocking=True)
+            host.copy_(t, non_blocking=True)
             ev = torch.cuda.Event()
             ev.record(cp)
-        input_ids.record_stream(cp)
+        t.record_stream(cp)
 
         def wait():
             ev.synchronize()
@@ -544,12 +567,21 @@ class GromaModel:
                     mid = engine._trace("bridge.mid", ops.gemm(s2d, self.bridge["w0"], bias=self.bridge["b0"], act=1))
                     image_features = ops.gemm(mid, self.bridge["w2"], bias=self.bridge["b2"], out_f32=True)
                     image_features.record_stream(main)
-                selected_boxes, aux = self.propose(hidden4, refer_boxes, ground_boxes, seeds=_seeds)
+                # region tokens (groma.py:312-315).  With CPU-RNG shuffles and every image expected to keep >= nmax boxes the
+                # selection is already on the device before the NMS counts reach the host (propose(): _speculate_shuffle), so the
+                # extraction is queued BEFORE the host waits for them and the GPU never drains; a mis-speculation (an image kept
+                # fewer boxes) discards it and extracts again from the ordinary selection -- same results either way.
+                spec, finish = self.propose(hidden4, refer_boxes, ground_boxes, seeds=_seeds, _defer=True)
                 main.wait_stream(side)
+                region_features = None
+                if spec is not None and SPECULATIVE_EXTRACT and engine.TRACE is None:   # (a trace wants each tensor recorded once)
+                    region_features = self.region.extract(feats, S, spec["boxes_cat"], spec["img_idx"])
+                selected_boxes, aux = finish()
                 bs = len(selected_boxes)
-                # region tokens (groma.py:312-315): launched FIRST -- nothing below changes its inputs, and every host op placed
-                # between the NMS sync and this launch is GPU-idle time
-                region_features = self.region.extract(feats, S, aux["boxes_cat"], aux["img_idx"])  # f32 [R, T]
+                if region_features is None or not aux.get("spec_hit"):
+                    # launched FIRST -- nothing below changes its inputs, and every host op placed between the NMS sync and this
+                    # launch is GPU-idle time
+                    region_features = self.region.extract(feats, S, aux["boxes_cat"], aux["img_idx"])  # f32 [R, T]
                 ids_h = ids_early() if ids_early is not None else input_ids.cpu()
                 writeback = input_ids.is_cuda
                 if not input_ids.is_cuda and input_ids.is_inference():  # a CPU tensor the caller made under inference mode:

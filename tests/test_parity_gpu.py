@@ -155,9 +155,12 @@ def test_speculative_shuffle_is_invisible(setup, monkeypatch):
     cfg, sd, tk, model, images, ids = setup
     from groma_amd.groma import GromaModel
 
-    def run(spec, thres):
+    import groma_amd.groma as G
+
+    def run(spec, thres, early=True):
         old = model.config.box_score_thres
         model.config.box_score_thres = thres
+        monkeypatch.setattr(G, "SPECULATIVE_EXTRACT", early)   # (the region extraction queued before the counts reach the host)
         if not spec:
             monkeypatch.setattr(GromaModel, "_speculate_shuffle", lambda self, *a, **k: None)
         try:
@@ -171,6 +174,8 @@ def test_speculative_shuffle_is_invisible(setup, monkeypatch):
     a, b = run(True, 0.0), run(False, 0.0)
     assert all(len(x) == 100 for x in a[1])
     assert torch.equal(a[0], b[0]) and all(torch.equal(x, y) for x, y in zip(a[1], b[1])) and torch.equal(a[2], b[2])
+    c = run(True, 0.0, early=False)
+    assert torch.equal(a[0], c[0]) and all(torch.equal(x, y) for x, y in zip(a[1], c[1])) and torch.equal(a[2], c[2])
     # miss: a threshold between the 40th and 41st fused score of image 0 leaves it with fewer than 100 boxes
     thr = float(model._last_aux["scores"][0].sort(descending=True).values[40])   # 40 candidates pass in image 0
     a, b = run(True, thr), run(False, thr)
