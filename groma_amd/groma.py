@@ -62,7 +62,7 @@ def _box_iou(b1, b2):  # torchvision.ops.box_iou on a handful of host-side boxes
 
 # precision="hybrid" / "hybrid-fp16": (operand type behind the ViT, operand type of the ViT)
 HYBRID_MODES = {"hybrid": ("bf16", "ref"), "hybrid-fp16": ("fp16", "ref")}
-SPECULATIVE_EXTRACT = os.environ.get("GROMA_SPECULATIVE_EXTRACT", "1") != "0"   # forward(): queue the region extraction before the NMS counts reach the host (off: tests / A-B only)
+SPECULATIVE_EXTRACT = True   # forward(): queue the region extraction before the NMS counts reach the host (False: tests / tests/diag A-B only)
 
 def _img_of(counts):
     """[0] * counts[0] + [1] * counts[1] + ... as an int64 tensor.  Not torch.repeat_interleave: with a many-thread intra-op pool it

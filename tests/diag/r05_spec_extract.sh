@@ -3,7 +3,7 @@
 T=${1:-r05n}; O=gpurun_out/$T; mkdir -p $O
 B="--no-cpu-baseline --no-traffic --no-extras --steps 20 --warmup 5"
 for r in 1; do for b in 14 1; do for s in 0 1; do
-  echo "round $r batch $b speculative_extract=$s $(GROMA_SPECULATIVE_EXTRACT=$s timeout 200 python bench.py $B --batch $b 2>/dev/null | python -c 'import sys,json; d=json.loads(sys.stdin.read()); print(round(d["value"],2), "img/s", round(d["ms_per_step"],3), "ms")')" >> $O/spec_extract_ab.txt
+  echo "round $r batch $b speculative_extract=$s $(timeout 200 python tests/diag/bench_spec_extract.py $s $B --batch $b 2>/dev/null | python -c 'import sys,json; d=json.loads(sys.stdin.read()); print(round(d["value"],2), "img/s", round(d["ms_per_step"],3), "ms")')" >> $O/spec_extract_ab.txt
 done; done; done
 cat $O/spec_extract_ab.txt
 (timeout 1500 python -m pytest tests -q -m gpu --timeout 900 2>&1 | tail -30 > $O/gpu_tests.log)
