@@ -6,8 +6,10 @@ The reference serves one request at a time, one python-driven forward per token
 stop id).  Decode is HBM-bound on the 13.2 GB weight stream, and that stream is shared by every row of
 a step -- so the MI355X design batches the decode steps of *different requests*:
 
-  * a fixed arena of `max_rows` KV slots ([rows, H, max_len, hd] per layer, K and V^T) -- the KV manager hands a slot
-    to a request at admission and takes it back when the request finishes; nothing is copied or compacted;
+  * an arena of `max_rows` KV slots ([rows, H, max_len, hd] per layer, K and V^T) -- the KV manager hands a slot
+    to a request at admission and takes it back when the request finishes; nothing is copied or compacted.  With
+    `grow_to` the arena is re-allocated at a larger `max_len` (live rows copied, the step re-captured) when a request
+    arrives that would not fit -- the reference's cache has no bound but the model's positions (model_worker.py:287-338);
   * a request is prefilled ALONE (batch 1) straight into its slot, so its prompt pass is bit-identical to
     `GromaModel.forward` on that request and independent of whatever else is being served;
   * every decode step advances ALL occupied rows with one captured hipGraph: per-row positions live on the device
@@ -104,11 +106,14 @@ class _RowView:
 
 class ContinuousBatcher:
     @engine.model_entry(lambda self, *a, **kw: (a[0] if a else kw["model"]).precision)
-    def __init__(self, model, max_rows=8, max_len=1024, use_graph=True):
+    def __init__(self, model, max_rows=8, max_len=1024, use_graph=True, grow_to=None):
         if max_rows < 1 or max_rows > 8:
             raise ValueError("max_rows must be in 1..8 (decode GEMV row block)")
         if max_len % 64 or max_len > 8192:
             raise ValueError("max_len must be a multiple of 64 and <= 8192")
+        if grow_to is not None and (grow_to % 64 or grow_to < max_len or grow_to > 8192):
+            raise ValueError("grow_to must be a multiple of 64 in max_len..8192")
+        self.grow_to = int(grow_to or max_len)   # the arena may be re-allocated up to this many positions per slot (default: fixed)
         if model.fp8:
             raise NotImplementedError("the continuous batcher drives the bf16 decode kernels")
         self.model, self.llm = model, model.llm
@@ -189,6 +194,41 @@ class ContinuousBatcher:
             self._decode()
         self.graph = g
 
+    # ------------------------------------------------------------------ KV arena growth
+    def _bound(self, r):
+        """upper bound of a request's context: the expanded prompt (groma.py:317-357: <image> -> the image tokens, <region> -> two ids
+        per selected region, at most max_region_num + the caller's refer / ground boxes) + its new tokens"""
+        m = self.model
+        extra = sum(int(b.shape[0]) for b in (r.refer_boxes, r.ground_boxes) if b is not None)
+        return int(r.input_ids.numel()) + (m.vit.G // 2) ** 2 + 2 * (int(m.config.max_region_num) + extra) + r.max_new_tokens
+
+    def _grow(self, need):
+        """Re-allocate the arena (and the staging cache) at max(2 x max_len, need) positions per slot, capped by grow_to.  Live rows
+        keep their KV prefix (K rows / V^T columns are copied; (hi, lo) pair storage interleaves in blocks of 32, so a prefix of
+        64-multiples is a prefix there too) and their loop state; the decode step is re-captured on the new addresses."""
+        old = self.max_len
+        new_len = min(self.grow_to, max(2 * old, -(-int(need) // 64) * 64))
+        if new_len <= old:
+            return
+        dev = self.tok.device
+        self.staging = None
+        self.staging = self.llm.new_cache(self.rows, new_len, dev)
+        arena = self.llm.new_cache(self.rows, new_len, dev)
+        sp = getattr(arena, "sp", 1)
+        for l in range(len(arena.k)):
+            arena.k[l][:, :, :old].copy_(self.arena.k[l])
+            arena.vt[l][..., : old * sp].copy_(self.arena.vt[l])
+        self.arena, self.max_len = arena, new_len
+        if self.graph is not None:
+            # the three eager warm-up steps in front of a capture advance every row: keep the loop state aside and put it back (what they
+            # wrote into live rows' KV lies at positions >= pos, which the next real step rewrites before it attends to them)
+            keep = (self.tok, self.nxt, self.occupied, self.pos, self.step_ctr, self.n_live, self._seq, self.h)
+            saved = [t.clone() for t in keep]
+            self.graph = None
+            self._capture()
+            for t, v in zip(keep, saved):
+                t.copy_(v)
+
     # ------------------------------------------------------------------ admission: one batched prefill per tick
     def _admit(self, reqs):
         """Prefill `reqs` (<= free slots) in ONE forward and move each row's KV into its slot.  Row results of the
@@ -196,6 +236,10 @@ class ContinuousBatcher:
         image-independent, tests/test_fullsize_properties_gpu.py), so admission order and company never change a
         request's tokens; each request's region shuffle draws from its own seed."""
         m, k = self.model, len(reqs)
+        if self.max_len < self.grow_to:
+            need = max(self._bound(r) for r in reqs)
+            if need > self.max_len:
+                self._grow(need)
         P = max(r.input_ids.numel() for r in reqs)
         ids = torch.full((k, P), int(m.pad_token_id), dtype=I64)
         for i, r in enumerate(reqs):

@@ -203,3 +203,32 @@ def test_batcher_over_a_hybrid_model_equals_its_generate(setup):
     res = b.run_until_done()
     for rid, (ids, image, n, seed) in zip(rids, reqs[:3]):
         assert res[rid].error is None and res[rid].tokens == _solo_generate(mh, ids, image, n, seed)
+
+
+@pytest.mark.parametrize("use_graph", [True, False])
+def test_arena_grows_under_a_live_row(setup, use_graph):
+    """grow_to: a request whose context bound exceeds max_len re-allocates the KV arena (live rows' prefixes copied, the step
+    re-captured) instead of being rejected; the live row and the newcomer produce the tokens a large fixed arena gives them."""
+    from groma_amd.serving import ContinuousBatcher
+    cfg, model, reqs = setup
+    (ids0, img0, _, s0), (ids1, img1, _, s1) = reqs[0], reqs[1]
+    ref = ContinuousBatcher(model, max_rows=2, max_len=1024, use_graph=use_graph)
+    a, b = ref.submit(ids0, img0, max_new_tokens=40, seed=s0), ref.submit(ids1, img1, max_new_tokens=120, seed=s1)
+    want = ref.run_until_done()
+    assert want[a].error is None and len(want[a].tokens) == 40 and len(want[b].tokens) == 120
+    g = ContinuousBatcher(model, max_rows=2, max_len=640, use_graph=use_graph, grow_to=2048)
+    ga = g.submit(ids0, img0, max_new_tokens=40, seed=s0)       # bound 128 + 256 + 2*100 + 40 = 624: fits
+    for _ in range(5):
+        g.step()
+    assert g.max_len == 640 and not g.live[ga].done
+    gb = g.submit(ids1, img1, max_new_tokens=120, seed=s1)      # bound 704 > 640: the arena doubles while row 0 is five tokens in
+    got = g.run_until_done()
+    assert g.max_len == 1280 and g.arena.smax == 1280 and g.staging.smax == 1280
+    assert got[ga].error is None and got[gb].error is None
+    assert got[ga].tokens == want[a].tokens and got[gb].tokens == want[b].tokens
+    # a fixed arena (the default) still turns the long request away, and grow_to is validated
+    f = ContinuousBatcher(model, max_rows=2, max_len=640, use_graph=use_graph)
+    fb = f.submit(ids1, img1, max_new_tokens=300, seed=s1)      # (128 - 2 + 256 image tokens + 300 > 640 whatever the region count)
+    assert f.run_until_done()[fb].error is not None and f.max_len == 640
+    with pytest.raises(ValueError):
+        ContinuousBatcher(model, max_rows=2, max_len=640, grow_to=512)
