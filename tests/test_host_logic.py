@@ -266,7 +266,8 @@ def test_graph_pool_policy(monkeypatch):
     launch eagerly and leave the pool alone."""
     import contextlib
     import pytest
-    from groma_amd import engine
+    import pytest
+    from groma_amd import engine, ops
 
     log = []
 
@@ -551,3 +552,41 @@ def test_bench_extras_summary_shape():
     assert s["forward_4_images_per_call"] == [75.25, 0.499] and s["forward_1_image_per_call"] == [37.2, None]
     assert s["decode_ms_per_token"] == [3.611, 0.457] and s["decode_fp8_ms_per_token"] == [3.058, 0.27]
     assert "forward_ref" not in s and bench.extras_summary({"error": "x"}) == {} and bench.extras_summary(None) == {}
+
+
+def test_batcher_arena_growth_keeps_live_prefixes():
+    """serving.ContinuousBatcher(grow_to=...): the context bound of a request and the re-allocation of the KV arena (host logic; the
+    decode-step re-capture and the tokens are covered on the GPU: tests/test_serving_gpu.py::test_arena_grows_under_a_live_row)."""
+    from types import SimpleNamespace
+    import pytest
+    from groma_amd import engine, ops
+    from groma_amd.serving import ContinuousBatcher, Request
+
+    class LLM:
+        H, hd, T, w = 2, 32, 16, {"layers": [None, None]}
+
+        def new_cache(self, bs, smax, device):
+            return engine.KVCache(2, bs, self.H, self.hd, smax, device)
+    for prec, sp in (("bf16", 1), ("ref", 2)):
+        model = SimpleNamespace(device=torch.device("cpu"), fp8=False, precision=prec, llm=LLM(), vit=SimpleNamespace(G=8),
+                                config=SimpleNamespace(max_region_num=5))
+        b = ContinuousBatcher(model, max_rows=2, max_len=64, use_graph=False, grow_to=256)
+        r = Request(0, torch.zeros(20, dtype=torch.int64), None, max_new_tokens=30, refer_boxes=torch.zeros(2, 4))
+        assert b._bound(r) == 20 + 16 + 2 * (5 + 2) + 30
+        old_k = [t.copy_(torch.randn(t.shape)).clone() for t in b.arena.k]
+        old_v = [t.copy_(torch.randn(t.shape)).clone() for t in b.arena.vt]
+        assert b.arena.k[0].shape[-1] == 32 * sp and b.arena.vt[0].shape[-1] == 64 * sp
+        with ops.precision(prec):
+            b._grow(100)                                   # max(2 x 64, 128) = 128
+        assert (b.max_len, b.arena.smax, b.staging.smax) == (128, 128, 128)
+        for l in range(2):
+            assert torch.equal(b.arena.k[l][:, :, :64], old_k[l]) and torch.equal(b.arena.vt[l][..., : 64 * sp], old_v[l])
+            if sp == 2:   # the VALUES the pairs stand for: the first 64 positions of V^T survive the move
+                assert torch.equal(ops.unsplit(b.arena.vt[l])[..., :64], ops.unsplit(old_v[l]))
+        with ops.precision(prec):
+            b._grow(10_000)                                # capped by grow_to
+            assert b.max_len == 256
+            b._grow(10_000)                                # already there: nothing happens
+        assert b.max_len == 256 and torch.equal(b.arena.k[1][:, :, :64], old_k[1])
+    with pytest.raises(ValueError):
+        ContinuousBatcher(model, max_rows=2, max_len=64, grow_to=100)
