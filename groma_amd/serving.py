@@ -114,8 +114,6 @@ class ContinuousBatcher:
         if grow_to is not None and (grow_to % 64 or grow_to < max_len or grow_to > 8192):
             raise ValueError("grow_to must be a multiple of 64 in max_len..8192")
         self.grow_to = int(grow_to or max_len)   # the arena may be re-allocated up to this many positions per slot (default: fixed)
-        if model.fp8:
-            raise NotImplementedError("the continuous batcher drives the bf16 decode kernels")
         self.model, self.llm = model, model.llm
         self.rows, self.max_len, self.use_graph = max_rows, max_len, use_graph
         dev = model.device

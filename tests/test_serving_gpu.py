@@ -232,3 +232,34 @@ def test_arena_grows_under_a_live_row(setup, use_graph):
     assert f.run_until_done()[fb].error is not None and f.max_len == 640
     with pytest.raises(ValueError):
         ContinuousBatcher(model, max_rows=2, max_len=640, grow_to=512)
+
+
+def test_batcher_over_an_e4m3_model(setup):
+    """fp8=True models: the batcher's step runs the e4m3 decode kernels (per-row positions), one row == generate(batch 1), and a
+    row's tokens do not depend on its neighbour (activations are quantised per row, weights per output row: nothing crosses rows)."""
+    from groma_amd.groma import GromaModel
+    from groma_amd.serving import ContinuousBatcher
+    from groma_amd import constants
+    cfg, model, reqs = setup
+    cfg8, sd, tk = util.tiny_setup(seed=0)
+    m8 = GromaModel.from_state_dict(cfg8, sd, device="cuda", fp8=True)
+    m8.init_special_token_id(constants.SyntheticTokenizer())
+    m8.generation_config.eos_token_id = None
+    (ids0, img0, _, s0), (ids1, img1, _, s1) = reqs[0], reqs[1]
+    solo = [_solo_generate(m8, ids0, img0, 10, s0), _solo_generate(m8, ids1, img1, 14, s1)]
+    b = ContinuousBatcher(m8, max_rows=1, max_len=1024)
+    r = b.submit(ids0, img0, max_new_tokens=10, seed=s0)
+    assert b.run_until_done()[r].tokens == solo[0]
+    alone = []
+    for ids, img, n, s in ((ids0, img0, 10, s0), (ids1, img1, 14, s1)):
+        b = ContinuousBatcher(m8, max_rows=2, max_len=1024)
+        r = b.submit(ids, img, max_new_tokens=n, seed=s)
+        alone.append(b.run_until_done()[r].tokens)
+    b = ContinuousBatcher(m8, max_rows=2, max_len=1024)
+    ra = b.submit(ids0, img0, max_new_tokens=10, seed=s0)
+    b.step(), b.step()
+    rb = b.submit(ids1, img1, max_new_tokens=14, seed=s1)
+    got = b.run_until_done()
+    assert got[ra].tokens == alone[0] and got[rb].tokens == alone[1]
+    assert len(set(alone[0])) > 1 or len(set(alone[1])) > 1   # (not a constant stream)
+    print("e4m3 batcher: rows=1 == generate; rows=2 alone == together;", alone[0][:5], solo[0][:5])
