@@ -612,8 +612,11 @@ def cache_addresses(cache):
 
 
 class LlamaEngine:
-    def __init__(self, w, cfg, ws):
-        self.w, self.ws = w, ws
+    def __init__(self, w, cfg, ws, prec=None):
+        """prec: None, or the operand type of each of the stack's three stages {"attn", "mlp", "head"} (round 6,
+        groma_amd.groma.parse_precision).  A stage's kernels run under ops.precision(its type) on weights packed in that storage;
+        the stages exchange the fp32 residual stream only, so nothing is converted between them.  The KV cache belongs to "attn"."""
+        self.w, self.ws, self.prec = w, ws, prec
         lc = cfg.llm_cfg
         self.T, self.H, self.eps, self.I = lc.hidden_size, lc.num_attention_heads, lc.rms_norm_eps, lc.intermediate_size
         self.hd = self.T // self.H
@@ -624,8 +627,14 @@ class LlamaEngine:
     def embed(self, ids, out=None):
         return ops.embed_gather(ids.reshape(-1).contiguous(), self.w["embed"], self.w["new_embed"], out=out)
 
+    def _st(self, stage):
+        """the operand type of `stage` active for the kernels launched inside (no-op for a single-type stack)"""
+        import contextlib
+        return ops.precision(self.prec[stage]) if self.prec is not None else contextlib.nullcontext()
+
     def new_cache(self, bs, smax, device):
-        return KVCache(len(self.w["layers"]), bs, self.H, self.hd, _ru(smax, 64), device)
+        with self._st("attn"):   # K / V^T are the attention stage's operands
+            return KVCache(len(self.w["layers"]), bs, self.H, self.hd, _ru(smax, 64), device)
 
     def forward(self, h, bs, L, cache, kv_len=None, all_logits=True, pos_dev=None, pos_stride=0, states=None):
         """h: f32 [bs*L, T] input embeddings (consumed as the residual stream, updated in place).
@@ -645,7 +654,8 @@ class LlamaEngine:
         #  token; the quantised operand is staged as M x K bytes in LDS, plus the merged context as 16-bit values in the o-proj)
         fits8 = not w["fp8"] or (_ru(bs, 4) * (max(T, self.I) + 16) <= 128 * 1024 and _ru(bs, 4) * (3 * T + 16) <= 128 * 1024 and T <= 4096
                                  and max(T, self.I) <= 12288 and T % 128 == 0 and self.I % 128 == 0 and self.Vpad % 16 == 0)
-        if FUSED_DECODE and L == 1 and M <= 8 and fits8 and T <= 8192 and cache.smax <= 8192 and ops.SP() == 1 and states is None:
+        if FUSED_DECODE and L == 1 and M <= 8 and fits8 and T <= 8192 and cache.smax <= 8192 and ops.SP() == 1 and states is None \
+                and self.prec is None:
             return self._decode_forward(h, bs, cache, kv_len, pos_dev, pos_stride, past)
         # A decode step that does not fit the weight-streaming path (more than 8 rows, pair operands, > 8192 keys) runs the
         # general kernels below.  Its scratch may be baked into GreedyDecoder's captured hipGraph, so -- like _decode_forward --
@@ -656,10 +666,17 @@ class LlamaEngine:
         def buf(name, shape, dtype):
             return ws.get(name + "_dec", shape, dtype, exact=True) if dec else ws.get(name, shape, dtype)
 
-        q = None if Q_IN_PLACE else buf("llm_q", h16(bs, H, L, hd), H16())
         fp8 = w["fp8"]
-        x_b, qkv_b = buf("llm_x", h16(M, T), H16()), buf("llm_qkv", h16(M, 3 * T), H16())
-        ctx_b, y_b = buf("llm_ctx", h16(M, T), H16()), buf("llm_y", h16(M, self.I), H16())
+        st = self._st
+        with st("attn"):
+            q = None if Q_IN_PLACE else buf("llm_q", h16(bs, H, L, hd), H16())
+            x_b, qkv_b = buf("llm_x", h16(M, T), H16()), buf("llm_qkv", h16(M, 3 * T), H16())
+            ctx_b = buf("llm_ctx", h16(M, T), H16())
+        with st("mlp"):
+            x2_b = buf("llm_x2", h16(M, T), H16()) if self.prec is not None else x_b
+            y_b = buf("llm_y", h16(M, self.I), H16())
+        with st("head"):
+            xh_b = buf("llm_xh", h16(M, T), H16()) if self.prec is not None else x_b
         n_sk = ops.plan_ws_elems(M, [(3 * T, T), (T, T), (2 * self.I, T), (T, self.I)]) if M > 8 else 0
         skw = buf("llm_splitk", (n_sk,), F32) if n_sk else None  # caller-owned split-K workspace: see VitEngine.forward
         # a prefill whose shape and memory repeat is replayed from a captured hipGraph (GraphPool): everything the launches
@@ -671,13 +688,13 @@ class LlamaEngine:
             kvl.copy_(kv_len)
             kv_len = kvl
 
-        def lin(x_f32, gain, wt, tag=None, **kw):
+        def lin(x_f32, gain, wt, tag=None, xb=None, **kw):
             """RMSNorm -> GEMM (bf16 operands, or e4m3 operands with dynamic per-row activation scales)"""
             if fp8:
                 x8, sx = ops.norm_fp8(x_f32, gain, None, self.eps, True, out=q8[x_f32.shape[-1]])
                 _trace_q8(tag, x8, sx)
                 return ops.gemm(x8, wt[0], a_scale=sx, w_scale=wt[1], **kw)
-            x = ops.rmsnorm(x_f32, gain, self.eps, out=x_b)
+            x = ops.rmsnorm(x_f32, gain, self.eps, out=x_b if xb is None else xb)
             if tag:
                 _trace(tag, x)
             return ops.gemm(x, wt[0], split_ws=skw, **kw)
@@ -696,37 +713,45 @@ class LlamaEngine:
                     _trace("llm0.h_in", h)
                 if states is not None:
                     states.append(h.view(bs, L, T).clone())
-                qkv = lin(h, Lw["n1"], Lw["wqkv"], tag="llm0.n1" if t0 else None, out=qkv_b)
-                ops.qkv_split(qkv, q, cache.k[i], cache.vt[i], B=bs, H=H, L=L, hd=hd, pos0=past,
-                              cos=w["cos"], sin=w["sin"], pos_dev=pos_dev, pos_stride=pos_stride)
-                att_kw = dict(Skv=cache.smax if dyn else past + L, causal=True, q_pos0=past, kv_len=kv_len,
-                              out=ctx_b, pos_dev=pos_dev, pos_stride=pos_stride)
-                if Q_IN_PLACE:  # q is read (and rotated) in place: no packed q copy, no round trip
-                    ctx = ops.attention(qkv, cache.k[i], cache.vt[i],
-                                        fused=dict(B=bs, H=H, Lq=L, hd=hd, cos=w["cos"], sin=w["sin"]), **att_kw)
-                else:
-                    ctx = ops.attention(q, cache.k[i], cache.vt[i], **att_kw)
-                if t0:
-                    _trace("llm0.qkv", qkv), _trace("llm0.ctx", ctx)
-                lin_bf16(ctx, Lw["wo"], tag="llm0.ctx" if t0 else None, resid=h, out=h, out_f32=True)
+                with st("attn"):
+                    qkv = lin(h, Lw["n1"], Lw["wqkv"], tag="llm0.n1" if t0 else None, out=qkv_b)
+                    ops.qkv_split(qkv, q, cache.k[i], cache.vt[i], B=bs, H=H, L=L, hd=hd, pos0=past,
+                                  cos=w["cos"], sin=w["sin"], pos_dev=pos_dev, pos_stride=pos_stride)
+                    att_kw = dict(Skv=cache.smax if dyn else past + L, causal=True, q_pos0=past, kv_len=kv_len,
+                                  out=ctx_b, pos_dev=pos_dev, pos_stride=pos_stride)
+                    if Q_IN_PLACE:  # q is read (and rotated) in place: no packed q copy, no round trip
+                        ctx = ops.attention(qkv, cache.k[i], cache.vt[i],
+                                            fused=dict(B=bs, H=H, Lq=L, hd=hd, cos=w["cos"], sin=w["sin"]), **att_kw)
+                    else:
+                        ctx = ops.attention(q, cache.k[i], cache.vt[i], **att_kw)
+                    if t0:
+                        _trace("llm0.qkv", qkv), _trace("llm0.ctx", ctx)
+                    lin_bf16(ctx, Lw["wo"], tag="llm0.ctx" if t0 else None, resid=h, out=h, out_f32=True)
                 if t0:
                     _trace("llm0.h_attn", h)
-                y = lin(h, Lw["n2"], Lw["wgu"], tag="llm0.n2" if t0 else None, act=3, out=y_b)
-                if t0:
-                    _trace("llm0.act", y)
-                lin_bf16(y, Lw["wd"], tag="llm0.act" if t0 else None, resid=h, out=h, out_f32=True)
+                with st("mlp"):
+                    y = lin(h, Lw["n2"], Lw["wgu"], tag="llm0.n2" if t0 else None, xb=x2_b, act=3, out=y_b)
+                    if t0:
+                        _trace("llm0.act", y)
+                    lin_bf16(y, Lw["wd"], tag="llm0.act" if t0 else None, resid=h, out=h, out_f32=True)
                 if t0:
                     _trace("llm0.h_out", h)
 
         if graph:
-            bufs = [h, x_b, qkv_b, ctx_b, y_b] + ([] if q is None else [q]) + ([] if kv_len is None else [kv_len]) + ([] if skw is None else [skw]) \
+            bufs = [h, x_b, x2_b, qkv_b, ctx_b, y_b] + ([] if q is None else [q]) + ([] if kv_len is None else [kv_len]) + ([] if skw is None else [skw]) \
                 + [t for pair in q8.values() for t in pair]
-            self.graphs.run(("llm", bs, L, past, kv_len is None, ops._PLAN[0], fp8) + tuple(t.data_ptr() for t in bufs)
+            self.graphs.run(("llm", bs, L, past, kv_len is None, ops._PLAN[0], fp8, ops.SP()) + tuple(t.data_ptr() for t in bufs)
                             + cache_addresses(cache), launch)
         else:
             launch()
         if not dyn:
             cache.seq_len = past + L
+        with st("head"):
+            return self._head(h, bs, L, xh_b, all_logits)
+
+    def _head(self, h, bs, L, x_b, all_logits):
+        """a21: final RMSNorm -> lm_head (+) extra_lm_head (under the head stage's operand type)"""
+        w, T, fp8 = self.w, self.T, self.w["fp8"]
         hn = ops.rmsnorm(h, w["norm"], self.eps, out=x_b)
         if len(w["layers"]) == 1:
             _trace("llm.final_norm", hn)

@@ -62,6 +62,38 @@ def _box_iou(b1, b2):  # torchvision.ops.box_iou on a handful of host-side boxes
 
 # precision="hybrid" / "hybrid-fp16": (operand type behind the ViT, operand type of the ViT)
 HYBRID_MODES = {"hybrid": ("bf16", "ref"), "hybrid-fp16": ("fp16", "ref")}
+# The operand type is a PER-STAGE choice (round 5: the ViT; round 6: every stage that exchanges fp32 tensors with its neighbours).
+# A stage is a run of kernels whose inputs and outputs are fp32 (residual streams, ViT states, region / image tokens, logits), so
+# nothing is converted where two stages of different operand types meet:
+#   vit     DINOv2 (a1)                       region  pyramid + RoIAlign + per-ROI conv + flatten + updims (a14-a17)
+#   bridge  img_txt_bridge (a3)               attn    RMSNorm -> QKV -> RoPE / KV cache -> attention -> o-proj (+ residual)
+#   mlp     RMSNorm -> gate/up -> SwiGLU -> down (+ residual)          head    final RMSNorm -> lm_head (+) extra_lm_head
+# precision = "<base>[+<stage>:<type>]..." with base one of bf16 | fp16 | ref | hybrid | hybrid-fp16 and type bf16 | fp16 | ref,
+# e.g. "hybrid-fp16+attn:ref" (tests/diag/precision_ablation.py measures what each stage's operand rounding costs the logits).
+STAGES = ("vit", "region", "bridge", "attn", "mlp", "head")
+_TYPES = ("bf16", "fp16", "ref")
+
+
+def parse_precision(spec, vit_precision=None):
+    """-> (stage -> operand type, base type behind the ViT).  `spec`: a name as above, or a dict {stage: type, "base": type}."""
+    if isinstance(spec, dict):
+        base = spec.get("base", "bf16")
+        table = {s: spec.get(s, base) for s in STAGES}
+    else:
+        name, *over = str(spec).split("+")
+        base, vit = HYBRID_MODES.get(name, (name, name))
+        table = {s: base for s in STAGES}
+        table["vit"] = vit
+        for o in over:
+            stage, _, typ = o.partition(":")
+            if stage not in STAGES:
+                raise ValueError(f"precision {spec!r}: unknown stage {stage!r} (stages: {', '.join(STAGES)})")
+            table[stage] = typ
+    if vit_precision is not None:
+        table["vit"] = vit_precision
+    if base not in _TYPES or any(t not in _TYPES for t in table.values()):
+        raise ValueError(f"precision must be 'bf16', 'fp16', 'ref', 'hybrid' or 'hybrid-fp16' (+ '<stage>:<type>' overrides), got {spec!r}")
+    return table, base
 SPECULATIVE_EXTRACT = True   # forward(): queue the region extraction before the NMS counts reach the host (False: tests / tests/diag A-B only)
 
 def _img_of(counts):
@@ -95,15 +127,15 @@ class GromaModel:
         # shuffled selection, the spliced token ids -- equal the reference's end to end, with no stage chaining
         # (R: groma/model/groma.py:222-280 in one fp32 pass; tests/test_e2e_unchained_gpu.py), at ~0.9x the bf16 throughput
         # instead of "ref"'s 0.4x.  The logits keep the 16-bit format's distance.
-        vit_precision = vit_precision or precision
-        if precision in HYBRID_MODES:
-            precision, vit_precision = HYBRID_MODES[precision]
-        if precision not in ("bf16", "fp16", "ref") or vit_precision not in ("bf16", "fp16", "ref"):
-            raise ValueError(f"precision must be 'bf16', 'fp16', 'ref', 'hybrid' or 'hybrid-fp16', got {precision!r} / ViT {vit_precision!r}")
-        if precision == "ref" and fp8:
-            raise ValueError("fp8=True and precision='ref' are exclusive")
-        # `precision`: operand type of everything behind the ViT (what serving / the KV cache / the decode arena are built for);
-        # `vit_precision`: the ViT's.  Equal except under "hybrid".
+        self.stage_precision, precision = parse_precision(precision, vit_precision)
+        vit_precision = self.stage_precision["vit"]
+        behind = {s: t for s, t in self.stage_precision.items() if s != "vit"}
+        if fp8 and any(t == "ref" for t in behind.values()):
+            raise ValueError("fp8=True and operand pairs ('ref') behind the ViT are exclusive")
+        if fp8 and len(set(behind.values())) > 1:
+            raise ValueError("fp8=True takes one 16-bit type behind the ViT")
+        # `precision`: the BASE operand type behind the ViT (the type the entry points switch to; what a stage without an override
+        # runs on); `vit_precision`: the ViT's.  Equal except under "hybrid".  `stage_precision`: the whole table.
         self.precision, self.vit_precision = precision, vit_precision
         self.decode_graph = True  # generate(): replay one captured hipGraph per token (False = eager per-kernel launches)
         # output_hidden_states=True: False = hidden_states[0] is the 1-tuple (final normed state,) -- every reference caller only
@@ -147,10 +179,15 @@ class GromaModel:
         self._ws = engine.Workspace(self.device)
         with ops.precision(self.vit_precision):   # ("hybrid": the ViT's weights are operand pairs, and never e4m3)
             self.vit = engine.VitEngine(weights.pack_vit(source, cfg, self.fp8 and self.vit_precision != "ref"), cfg, self._ws)
+        sp = self.stage_precision
         self.proposer = engine.ProposerEngine(weights.pack_ddetr(source, cfg), cfg, self._ws)
-        self.region = engine.RegionEngine(weights.pack_region(source, cfg, self.fp8), cfg, self._ws)
-        self.bridge = weights.pack_bridge(source, cfg)
-        self.llm = engine.LlamaEngine(weights.pack_llm(source, cfg, self.fp8), cfg, self._ws)
+        with ops.precision(sp["region"]):
+            self.region = engine.RegionEngine(weights.pack_region(source, cfg, self.fp8), cfg, self._ws)
+        with ops.precision(sp["bridge"]):
+            self.bridge = weights.pack_bridge(source, cfg)
+        # (one type for the whole LLaMA stack = the stage switches are no-ops and the streaming decode kernels apply)
+        llm_prec = None if sp["attn"] == sp["mlp"] == sp["head"] == self.precision else {k: sp[k] for k in ("attn", "mlp", "head")}
+        self.llm = engine.LlamaEngine(weights.pack_llm(source, cfg, self.fp8, prec=llm_prec), cfg, self._ws, prec=llm_prec)
         self._loaded = True
 
     @property
@@ -159,6 +196,7 @@ class GromaModel:
         name = next((k for k, v in HYBRID_MODES.items() if v == (self.precision, self.vit_precision)), None)
         if name is None:
             name = self.precision if self.precision == self.vit_precision else f"{self.precision}+vit:{self.vit_precision}"
+        name += "".join(f"+{s}:{t}" for s, t in self.stage_precision.items() if s != "vit" and t != self.precision)
         return name + ("+e4m3" if self.fp8 else "")
 
     def _vit_forward(self, images):
@@ -560,12 +598,15 @@ class GromaModel:
                 main = torch.cuda.current_stream()
                 side = self._side_stream()
                 side.wait_stream(main)
+                sp = self.stage_precision
                 with torch.cuda.stream(side):
-                    feats, S = self.region.fuse(hidden4[-3:])
+                    with ops.precision(sp["region"]):
+                        feats, S = self.region.fuse(hidden4[-3:])
                     last = hidden4[self.config.perceiver_cfg.vis_output_layer]
-                    s2d = engine._trace("bridge.s2d", ops.s2d_pack(last, self.vit.G))
-                    mid = engine._trace("bridge.mid", ops.gemm(s2d, self.bridge["w0"], bias=self.bridge["b0"], act=1))
-                    image_features = ops.gemm(mid, self.bridge["w2"], bias=self.bridge["b2"], out_f32=True)
+                    with ops.precision(sp["bridge"]):
+                        s2d = engine._trace("bridge.s2d", ops.s2d_pack(last, self.vit.G))
+                        mid = engine._trace("bridge.mid", ops.gemm(s2d, self.bridge["w0"], bias=self.bridge["b0"], act=1))
+                        image_features = ops.gemm(mid, self.bridge["w2"], bias=self.bridge["b2"], out_f32=True)
                     image_features.record_stream(main)
                 # region tokens (groma.py:312-315).  With CPU-RNG shuffles and every image expected to keep >= nmax boxes the
                 # selection is already on the device before the NMS counts reach the host (propose(): _speculate_shuffle), so the
@@ -575,13 +616,15 @@ class GromaModel:
                 main.wait_stream(side)
                 region_features = None
                 if spec is not None and SPECULATIVE_EXTRACT and engine.TRACE is None:   # (a trace wants each tensor recorded once)
-                    region_features = self.region.extract(feats, S, spec["boxes_cat"], spec["img_idx"])
+                    with ops.precision(sp["region"]):
+                        region_features = self.region.extract(feats, S, spec["boxes_cat"], spec["img_idx"])
                 selected_boxes, aux = finish()
                 bs = len(selected_boxes)
                 if region_features is None or not aux.get("spec_hit"):
                     # launched FIRST -- nothing below changes its inputs, and every host op placed between the NMS sync and this
                     # launch is GPU-idle time
-                    region_features = self.region.extract(feats, S, aux["boxes_cat"], aux["img_idx"])  # f32 [R, T]
+                    with ops.precision(sp["region"]):
+                        region_features = self.region.extract(feats, S, aux["boxes_cat"], aux["img_idx"])  # f32 [R, T]
                 ids_h = ids_early() if ids_early is not None else input_ids.cpu()
                 writeback = input_ids.is_cuda
                 if not input_ids.is_cuda and input_ids.is_inference():  # a CPU tensor the caller made under inference mode:
@@ -685,10 +728,11 @@ class GromaModel:
             logits = logits.clone()
         hidden_states = None
         if output_hidden_states:
-            if hn is None:  # decode step: the final norm lives in the head GEMV's prologue; `emb` is the residual stream, updated in place
-                hn = ops.rmsnorm(emb, self.llm.w["norm"], self.llm.eps)
-            # (precision "ref" holds the normed state as operand pairs: hand out the f32 values they stand for)
-            hidden_states = tuple(states or ()) + ((ops.unsplit(hn) if ops.SP() == 2 else hn.clone()).view(bs, -1, self.llm.T),)
+            with ops.precision(self.stage_precision["head"]):   # (the final norm's output is the head stage's operand)
+                if hn is None:  # decode step: the final norm lives in the head GEMV's prologue; `emb` is the residual stream, updated in place
+                    hn = ops.rmsnorm(emb, self.llm.w["norm"], self.llm.eps)
+                # (operand pairs: hand out the f32 values they stand for)
+                hidden_states = tuple(states or ()) + ((ops.unsplit(hn) if ops.SP() == 2 else hn.clone()).view(bs, -1, self.llm.T),)
         if not use_cache and past_key_values is None:
             cache = None  # HF returns past_key_values=None without use_cache; the scratch KV buffer is recycled
         if not return_dict:

@@ -273,29 +273,38 @@ def pack_region(W, cfg, fp8=False):
     return out
 
 
-def pack_llm(W, cfg, fp8=False):
+def pack_llm(W, cfg, fp8=False, prec=None):
+    """prec: None (everything in the active operand type) or {"attn", "mlp", "head": type} -- the per-stage operand types of
+    groma_amd.groma.parse_precision: each stage's weights are packed in ITS storage (the embedding tables stay in the active one)"""
+    import contextlib
     lc = cfg.llm_cfg
     T, I = lc.hidden_size, lc.intermediate_size
+    if prec is not None and fp8:
+        raise NotImplementedError("per-stage operand types and e4m3 weights are exclusive")
+    st = (lambda stage: ops.precision(prec[stage])) if prec is not None else (lambda stage: contextlib.nullcontext())
     out = dict(layers=[], fp8=fp8)
     out["embed"] = bf(W("llm.model.embed_tokens.weight"))
     out["new_embed"] = bf(W("new_input_embs.weight"))
     for i in range(lc.num_hidden_layers):
         p = f"llm.model.layers.{i}."
         gate, up = W(p + "mlp.gate_proj.weight"), W(p + "mlp.up_proj.weight")
-        out["layers"].append(dict(
-            n1=W(p + "input_layernorm.weight"),
-            wqkv=wq(torch.cat([W(p + "self_attn.q_proj.weight"), W(p + "self_attn.k_proj.weight"),
-                               W(p + "self_attn.v_proj.weight")], 0), fp8),
-            wo=wq(W(p + "self_attn.o_proj.weight"), fp8),
-            n2=W(p + "post_attention_layernorm.weight"),
-            wgu=wq(torch.stack([gate, up], 1).reshape(2 * I, T), fp8),  # interleaved rows: gate_0, up_0, gate_1, ...
-            wd=wq(W(p + "mlp.down_proj.weight"), fp8)))
+        with st("attn"):
+            ent = dict(n1=W(p + "input_layernorm.weight"),
+                       wqkv=wq(torch.cat([W(p + "self_attn.q_proj.weight"), W(p + "self_attn.k_proj.weight"),
+                                          W(p + "self_attn.v_proj.weight")], 0), fp8),
+                       wo=wq(W(p + "self_attn.o_proj.weight"), fp8))
+        with st("mlp"):
+            ent.update(n2=W(p + "post_attention_layernorm.weight"),
+                       wgu=wq(torch.stack([gate, up], 1).reshape(2 * I, T), fp8),  # interleaved rows: gate_0, up_0, gate_1, ...
+                       wd=wq(W(p + "mlp.down_proj.weight"), fp8))
+        out["layers"].append(ent)
     out["norm"] = W("llm.model.norm.weight")
     V = lc.vocab_size + cfg.num_new_token
     Vp = _ru(V, 128)
-    head = torch.zeros((Vp, T * ops.SP()), dtype=H16(), device=W.device)
-    head[: lc.vocab_size] = bf(W("llm.lm_head.weight"))
-    head[lc.vocab_size: V] = bf(W("extra_lm_head.weight"))
+    with st("head"):
+        head = torch.zeros((Vp, T * ops.SP()), dtype=H16(), device=W.device)
+        head[: lc.vocab_size] = bf(W("llm.lm_head.weight"))
+        head[lc.vocab_size: V] = bf(W("extra_lm_head.weight"))
     out["head"], out["V"], out["Vpad"] = head, V, Vp
     if fp8 and FP8_HEAD:  # BASELINE configs[4] names a21: lm_head (+) extra_lm_head as e4m3 rows with per-output-channel scales (padding rows: zeros)
         hf = torch.zeros((Vp, T), dtype=F32, device=W.device)

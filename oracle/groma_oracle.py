@@ -41,25 +41,80 @@ IGNORE_INDEX = -100
 # normalisation statistics, biases and the whole DDETR proposer stay fp32 (as on the device).  With rounding off (the
 # default) every _r() below is the identity, so the fp32 oracle and its goldens are untouched.
 _ROUND = [None]
+# Per-stage selection of the rounding points (round 6: the precision ablation, tests/diag/precision_ablation.py).  Every rounding
+# point carries a key "<stage>.<kind>": the stage is the innermost `with _st(name):` block it is evaluated in --
+#   vit | bridge | region.in / region.fuse / region.pconv / region.flat / region.up | embed |
+#   llm.qkv (norm1 output, q/k/v weights, projection outputs incl. RoPE) | llm.pv (soft-max probabilities, context) |
+#   llm.o | llm.gateup | llm.down (SwiGLU output, weights) | head
+# -- and the kind is "a" (an activation operand), "w" (a weight) or "o" (a stored output).  rounding(mode, only={...}) rounds
+# only the points whose key matches one of the patterns, rounding(mode, skip={...}) all but those; a pattern matches a key that
+# equals it or that it prefixes at a dot ("llm" = every LLaMA point, "llm.down.w" = the down-projection weights alone).
+# The device's per-stage operand types (groma_amd.groma.parse_precision) map onto it: a stage on operand pairs = its points skipped.
+_ONLY, _SKIP, _STAGE = [None], [None], ["-"]
 
 
 class rounding:
     """with rounding("bf16"): ...   -- evaluate the oracle with bf16-rounded operands (None = pure fp32).
-    "fp16": the same rounding points with IEEE half (the fp16 operand build of the device library, libgroma_hip_f16.so)."""
+    "fp16": the same rounding points with IEEE half (the fp16 operand build of the device library, libgroma_hip_f16.so).
+    only / skip: restrict the rounding to (all but) the points matching these "<stage>[.<kind>]" patterns (see above)."""
 
-    def __init__(self, mode):
+    def __init__(self, mode, only=None, skip=None):
         assert mode in (None, "bf16", "e4m3", "fp16")
-        self.mode = mode
+        assert (only is None and skip is None) or mode in ("bf16", "fp16"), "per-stage selection is defined for the 16-bit modes"
+        self.mode, self.only, self.skip = mode, (None if only is None else tuple(only)), (None if skip is None else tuple(skip))
 
     def __enter__(self):
-        self.prev, _ROUND[0] = _ROUND[0], self.mode
+        self.prev = (_ROUND[0], _ONLY[0], _SKIP[0])
+        _ROUND[0], _ONLY[0], _SKIP[0] = self.mode, self.only, self.skip
 
     def __exit__(self, *a):
-        _ROUND[0] = self.prev
+        _ROUND[0], _ONLY[0], _SKIP[0] = self.prev
 
 
-def _r(x):
+class _st:
+    """with _st("llm.qkv"): ...  -- names the stage of the rounding points evaluated inside (innermost block wins)"""
+
+    def __init__(self, name):
+        self.name = name
+
+    def __enter__(self):
+        self.prev, _STAGE[0] = _STAGE[0], self.name
+
+    def __exit__(self, *a):
+        _STAGE[0] = self.prev
+
+
+def _in_stage(name):
+    """decorator: the whole function body is the stage `name`"""
+    import functools
+
+    def deco(fn):
+        @functools.wraps(fn)
+        def wrapped(*a, **kw):
+            with _st(name):
+                return fn(*a, **kw)
+        return wrapped
+    return deco
+
+
+def _match(pats, key):
+    return any(key == p or key.startswith(p + ".") for p in pats)
+
+
+def rounds_here(kind="a"):
+    """does a rounding point of this kind, in the current stage, round under the active mode / selection?"""
     if _ROUND[0] is None:
+        return False
+    if _ONLY[0] is None and _SKIP[0] is None:
+        return True
+    key = _STAGE[0] + "." + kind
+    if _ONLY[0] is not None and not _match(_ONLY[0], key):
+        return False
+    return not (_SKIP[0] is not None and _match(_SKIP[0], key))
+
+
+def _r(x, kind="a"):
+    if not rounds_here(kind):
         return x
     return x.to(torch.float16 if _ROUND[0] == "fp16" else torch.bfloat16).to(torch.float32)
 
@@ -123,11 +178,11 @@ def _linA(x, sd, name, bias=True, src="act"):
 
 def _lin16(x, sd, name, bias=True):
     """a Linear the device runs as a bf16 MFMA GEMM: bf16 operands, fp32 accumulate, fp32 bias"""
-    return F.linear(_r(x), _r(sd[name + ".weight"]), sd.get(name + ".bias") if bias else None)
+    return F.linear(_r(x), _r(sd[name + ".weight"], "w"), sd.get(name + ".bias") if bias else None)
 
 
 def _conv16(x, w, b=None, **kw):
-    return F.conv2d(_r(x), _r(w), b, **kw)
+    return F.conv2d(_r(x), _r(w, "w"), b, **kw)
 
 
 # ------------------------------------------------------------------------------------------------ helpers
@@ -191,8 +246,9 @@ def _softmax_pv(scores, v):
     in fp32, the row sum is kept in fp32 from the un-rounded values, and the context is rounded to bf16 after the division.
     (With zero-mean V a different-but-equivalent rounding point -- e.g. exp(s - final_max) -- changes the context by
     ~1e-3 relative: the rounding errors of P do not average out, they random-walk like the signal.)"""
-    if _ROUND[0] is None:
-        return torch.softmax(scores, dim=-1, dtype=torch.float32) @ v
+    if _ROUND[0] is None or not (rounds_here("a") or rounds_here("o")):
+        # (float64 inputs stay float64: tests/diag/index_survival.py evaluates this restatement in double to apportion the fp32 noise)
+        return torch.softmax(scores, dim=-1, dtype=torch.float64 if scores.dtype == torch.float64 else torch.float32) @ v
     S = scores.shape[-1]
     nt = (S + ATT_KEY_TILE - 1) // ATT_KEY_TILE
     pad = nt * ATT_KEY_TILE - S
@@ -203,9 +259,10 @@ def _softmax_pv(scores, v):
     m_fin = m_run[..., -1:]
     e = torch.exp(scores - m_key)
     w = torch.exp(m_key - m_fin)                                       # fp32 rescale of earlier tiles (product of alphas)
-    return _r(((_r(e) * w) @ v) / (e * w).sum(dim=-1, keepdim=True))
+    return _r(((_r(e) * w) @ v) / (e * w).sum(dim=-1, keepdim=True), "o")
 
 
+@_in_stage("vit")
 def vit_forward(sd, cfg, images, prefix="perceiver.vis_encoder."):
     """HF Dinov2Model(images, output_hidden_states=True).hidden_states  (called at R: groma/model/groma.py:222).
     Returns the tuple (embeddings, layer_1, ..., layer_N); the final LayerNorm is never applied."""
@@ -224,9 +281,9 @@ def vit_forward(sd, cfg, images, prefix="perceiver.vis_encoder."):
     for i in range(vc["num_hidden_layers"]):
         p = f"{prefix}encoder.layer.{i}."
         y = _ln(x, sd, p + "norm1", eps)
-        q = _r(_linA(y, sd, p + "attention.attention.query", src="norm")).view(bs, -1, heads, hd).transpose(1, 2)
-        k = _r(_linA(y, sd, p + "attention.attention.key", src="norm")).view(bs, -1, heads, hd).transpose(1, 2)
-        v = _r(_linA(y, sd, p + "attention.attention.value", src="norm")).view(bs, -1, heads, hd).transpose(1, 2)
+        q = _r(_linA(y, sd, p + "attention.attention.query", src="norm"), "o").view(bs, -1, heads, hd).transpose(1, 2)
+        k = _r(_linA(y, sd, p + "attention.attention.key", src="norm"), "o").view(bs, -1, heads, hd).transpose(1, 2)
+        v = _r(_linA(y, sd, p + "attention.attention.value", src="norm"), "o").view(bs, -1, heads, hd).transpose(1, 2)
         ctx = _softmax_pv(q @ k.transpose(-1, -2) / math.sqrt(hd), v).transpose(1, 2).reshape(bs, -1, D)
         x = x + sd[p + "layer_scale1.lambda1"] * _linA(ctx, sd, p + "attention.output.dense")
         y = _ln(x, sd, p + "norm2", eps)
@@ -481,7 +538,8 @@ def region_fuse(sd, cfg, mlvl_tokens, prefix="region_encoder."):
         y, x = torch.meshgrid(y_range, x_range, indexing="ij")
         coord = torch.cat([x.expand(bs, 1, -1, -1), y.expand(bs, 1, -1, -1)], 1)
         f = torch.cat([f, coord], dim=1)
-        new.append(_r(_conv16(f, sd[f"{m}input_conv.{lvl}.weight"], sd[f"{m}input_conv.{lvl}.bias"])))
+        with _st("region.in"):
+            new.append(_r(_conv16(f, sd[f"{m}input_conv.{lvl}.weight"], sd[f"{m}input_conv.{lvl}.bias"]), "o"))
     inputs = new
     shuffle, remain = C // 4, C - 2 * (C // 4)
     for r in range(rc["num_fuse"]):
@@ -498,14 +556,16 @@ def region_fuse(sd, cfg, mlvl_tokens, prefix="region_encoder."):
         # (rounded mode: the conv output is stored as bf16 and the GN statistics are taken from the stored values; the
         #  normalised map is only rounded again where it is consumed -- as the next conv's / RoIAlign's bf16 input)
         wr = sd[f"{m}fuse_convs.{r}.conv.weight"]
-        if _ROUND[0] == "e4m3" and r >= 1 and C % 128 == 0:  # (the device's e4m3 conv gather needs C % 128 == 0: weights.pack_region)
-            s_in = conv_act_scale(sd[f"{m}fuse_convs.{r - 1}.gn.weight"], sd[f"{m}fuse_convs.{r - 1}.gn.bias"])
-            convs = [_conv8(x, wr, s_in, padding=1) for x in fused]
-        else:
-            convs = [_conv16(x, wr, None, padding=1) for x in fused]
-        inputs = [F.relu(F.group_norm(_r(y), rc["gn_groups"], sd[f"{m}fuse_convs.{r}.gn.weight"],
-                                      sd[f"{m}fuse_convs.{r}.gn.bias"], 1e-5)) for y in convs]
-    return [_r(x) for x in inputs]
+        with _st("region.fuse"):
+            if _ROUND[0] == "e4m3" and r >= 1 and C % 128 == 0:  # (the device's e4m3 conv gather needs C % 128 == 0: weights.pack_region)
+                s_in = conv_act_scale(sd[f"{m}fuse_convs.{r - 1}.gn.weight"], sd[f"{m}fuse_convs.{r - 1}.gn.bias"])
+                convs = [_conv8(x, wr, s_in, padding=1) for x in fused]
+            else:
+                convs = [_conv16(x, wr, None, padding=1) for x in fused]
+            inputs = [F.relu(F.group_norm(_r(y, "o"), rc["gn_groups"], sd[f"{m}fuse_convs.{r}.gn.weight"],
+                                          sd[f"{m}fuse_convs.{r}.gn.bias"], 1e-5)) for y in convs]
+    with _st("region.fuse"):
+        return [_r(x, "o") for x in inputs]
 
 
 def roi_extract(sd, cfg, feats, rois_list, prefix="region_encoder.roi_align."):
@@ -527,19 +587,22 @@ def roi_extract(sd, cfg, feats, rois_list, prefix="region_encoder.roi_align."):
     rfs = [torch.from_numpy(cref.roi_align_avg(f.float().contiguous().numpy(), rois.float().numpy(), (P, P),
                                                1.0 / strides[lvl], 2, True)) for lvl, f in enumerate(feats)]
     nf = rc["num_fuse"]
-    if _ROUND[0] == "e4m3" and nf >= 1 and feats[0].shape[1] % 128 == 0:  # one e4m3 conv over the three levels' taps (as the device)
-        m = prefix.replace("roi_align.", "mlvl_fuse.")
-        s_in = conv_act_scale(sd[f"{m}fuse_convs.{nf - 1}.gn.weight"], sd[f"{m}fuse_convs.{nf - 1}.gn.bias"])
-        acc = _conv8(torch.cat(rfs, 1), torch.cat([sd[f"{prefix}pconvs.{l}.weight"] for l in range(len(rfs))], 1), s_in,
-                     sum(sd[f"{prefix}pconvs.{l}.bias"] for l in range(len(rfs))), padding=1)
-    else:
-        for lvl, rf in enumerate(rfs):
-            y = _conv16(rf, sd[f"{prefix}pconvs.{lvl}.weight"], sd[f"{prefix}pconvs.{lvl}.bias"], padding=1)
-            acc = y if acc is None else acc + y
+    with _st("region.pconv"):
+        if _ROUND[0] == "e4m3" and nf >= 1 and feats[0].shape[1] % 128 == 0:  # one e4m3 conv over the three levels' taps (as the device)
+            m = prefix.replace("roi_align.", "mlvl_fuse.")
+            s_in = conv_act_scale(sd[f"{m}fuse_convs.{nf - 1}.gn.weight"], sd[f"{m}fuse_convs.{nf - 1}.gn.bias"])
+            acc = _conv8(torch.cat(rfs, 1), torch.cat([sd[f"{prefix}pconvs.{l}.weight"] for l in range(len(rfs))], 1), s_in,
+                         sum(sd[f"{prefix}pconvs.{l}.bias"] for l in range(len(rfs))), padding=1)
+        else:
+            for lvl, rf in enumerate(rfs):
+                y = _conv16(rf, sd[f"{prefix}pconvs.{lvl}.weight"], sd[f"{prefix}pconvs.{lvl}.bias"], padding=1)
+                acc = y if acc is None else acc + y
     x = F.relu(acc).flatten(1, -1)
-    x = _lin16(x, sd, prefix + "flatten_linear")
+    with _st("region.flat"):
+        x = _lin16(x, sd, prefix + "flatten_linear")
     x = x + pe
-    x = _lin16(x, sd, prefix + "updims")
+    with _st("region.up"):
+        x = _lin16(x, sd, prefix + "updims")
     return [x[rois[:, 0] == i] for i in range(len(rois_list))]
 
 
@@ -586,31 +649,37 @@ def llama_forward(sd, cfg, inputs_embeds, attention_mask, past=None, prefix="llm
     for i in range(lc["num_hidden_layers"]):
         p = f"{prefix}layers.{i}."
         x = rms(h, sd[p + "input_layernorm.weight"])
-        q = _r(_linA(x, sd, p + "self_attn.q_proj", False, src="norm")).view(bs, L, H, hd).transpose(1, 2)
-        k = _r(_linA(x, sd, p + "self_attn.k_proj", False, src="norm")).view(bs, L, H, hd).transpose(1, 2)
-        v = _r(_linA(x, sd, p + "self_attn.v_proj", False, src="norm")).view(bs, L, H, hd).transpose(1, 2)
-        q = _r(q * cos + _rot_half(q) * sin)
-        k = _r(k * cos + _rot_half(k) * sin)
+        with _st("llm.qkv"):
+            q = _r(_linA(x, sd, p + "self_attn.q_proj", False, src="norm"), "o").view(bs, L, H, hd).transpose(1, 2)
+            k = _r(_linA(x, sd, p + "self_attn.k_proj", False, src="norm"), "o").view(bs, L, H, hd).transpose(1, 2)
+            v = _r(_linA(x, sd, p + "self_attn.v_proj", False, src="norm"), "o").view(bs, L, H, hd).transpose(1, 2)
+            q = _r(q * cos + _rot_half(q) * sin, "o")
+            k = _r(k * cos + _rot_half(k) * sin, "o")
         if past is not None:
             k = torch.cat([past[i][0], k], dim=2)
             v = torch.cat([past[i][1], v], dim=2)
         new_past.append((k, v))
         att = q @ k.transpose(2, 3) / math.sqrt(hd) + mask
         att = torch.max(att, torch.tensor(fmin))
-        y = _softmax_pv(att, v).transpose(1, 2).reshape(bs, L, D)
-        h = h + _linA(y, sd, p + "self_attn.o_proj", False)
+        with _st("llm.pv"):
+            y = _softmax_pv(att, v).transpose(1, 2).reshape(bs, L, D)
+        with _st("llm.o"):
+            h = h + _linA(y, sd, p + "self_attn.o_proj", False)
         x = rms(h, sd[p + "post_attention_layernorm.weight"])
-        x = _linA(F.silu(_linA(x, sd, p + "mlp.gate_proj", False, src="norm")) * _linA(x, sd, p + "mlp.up_proj", False, src="norm"),
-                  sd, p + "mlp.down_proj", False)
+        with _st("llm.gateup"):
+            x = F.silu(_linA(x, sd, p + "mlp.gate_proj", False, src="norm")) * _linA(x, sd, p + "mlp.up_proj", False, src="norm")
+        with _st("llm.down"):
+            x = _linA(x, sd, p + "mlp.down_proj", False)
         h = h + x
         if layer_hook is not None:
             layer_hook(i, h)
     return rms(h, sd[prefix + "norm.weight"]), new_past
 
 
+@_in_stage("embed")
 def get_input_embeddings(sd, input_ids):
     """R: groma/model/groma.py:165-174"""
-    W0, W1 = _r(sd["llm.model.embed_tokens.weight"]), _r(sd["new_input_embs.weight"])  # bf16 tables on the device
+    W0, W1 = _r(sd["llm.model.embed_tokens.weight"], "w"), _r(sd["new_input_embs.weight"], "w")  # bf16 tables on the device
     mask = input_ids >= W0.shape[0]
     ori = F.embedding(input_ids.masked_fill(mask, 0), W0)
     new = F.embedding((input_ids - W0.shape[0]).masked_fill(~mask, 0), W1)
@@ -618,6 +687,7 @@ def get_input_embeddings(sd, input_ids):
     return ori
 
 
+@_in_stage("head")
 def lm_logits(sd, hidden):
     """R: groma/model/groma.py:399-402"""
     if _ROUND[0] == "e4m3":  # a21 in e4m3: `hidden` is the final RMSNorm output, quantised straight from fp32
@@ -625,6 +695,7 @@ def lm_logits(sd, hidden):
     return torch.cat((_lin16(hidden, sd, "llm.lm_head", False), _lin16(hidden, sd, "extra_lm_head", False)), dim=-1)
 
 
+@_in_stage("bridge")
 def bridge(sd, image_features):
     """img_txt_bridge: Linear -> GELU -> Linear (R: groma/model/groma.py:112-116, applied :361)"""
     return _lin16(F.gelu(_lin16(image_features, sd, "img_txt_bridge.0")), sd, "img_txt_bridge.2")

@@ -258,6 +258,22 @@ def test_precision_context_selects_library_and_dtype():
         GromaModel(config.groma_tiny(), precision="ref", fp8=True)
     with pytest.raises(ValueError):
         GromaModel(config.groma_tiny(), precision="bf16", vit_precision="fp8")
+    # round 6: the table covers every stage that exchanges fp32 tensors with its neighbours ("<base>+<stage>:<type>...")
+    from groma_amd.groma import parse_precision, STAGES
+    t, base = parse_precision("hybrid-fp16+attn:ref+head:ref")
+    assert base == "fp16" and t == dict(vit="ref", region="fp16", bridge="fp16", attn="ref", mlp="fp16", head="ref") and tuple(t) == STAGES
+    assert parse_precision("hybrid")[0] == dict(vit="ref", region="bf16", bridge="bf16", attn="bf16", mlp="bf16", head="bf16")
+    assert parse_precision(dict(base="fp16", vit="ref", mlp="ref")) == (dict(vit="ref", region="fp16", bridge="fp16", attn="fp16", mlp="ref", head="fp16"), "fp16")
+    m = GromaModel(config.groma_tiny(), precision="hybrid-fp16+mlp:ref")
+    assert (m.precision, m.vit_precision, m.mode, m.stage_precision["mlp"]) == ("fp16", "ref", "hybrid-fp16+mlp:ref", "ref")
+    assert GromaModel(config.groma_tiny(), precision="bf16+region:fp16").mode == "bf16+region:fp16"
+    for bad in ("hybrid+llm:ref", "hybrid+attn:fp8", "hybrid+attn"):
+        with pytest.raises(ValueError):
+            GromaModel(config.groma_tiny(), precision=bad)
+    with pytest.raises(ValueError):
+        GromaModel(config.groma_tiny(), precision="hybrid+mlp:ref", fp8=True)      # pairs behind the ViT and e4m3 are exclusive
+    with pytest.raises(ValueError):
+        GromaModel(config.groma_tiny(), precision="hybrid+mlp:fp16", fp8=True)     # e4m3 takes one 16-bit type behind the ViT
 
 
 def test_graph_pool_policy(monkeypatch):
@@ -590,3 +606,23 @@ def test_batcher_arena_growth_keeps_live_prefixes():
         assert b.max_len == 256 and torch.equal(b.arena.k[1][:, :, :64], old_k[1])
     with pytest.raises(ValueError):
         ContinuousBatcher(model, max_rows=2, max_len=64, grow_to=100)
+
+
+def test_valid_ranking_rule_of_the_index_survival_scan():
+    """tests/diag/index_survival.py::valid_ranking -- the property asserted on every unselected seed: the device's top-k order is a
+    ranking of the ORACLE's values up to a tolerance (near-ties may swap, nothing else)"""
+    import importlib.util, os
+    here = os.path.dirname(os.path.abspath(__file__))
+    spec = importlib.util.spec_from_file_location("index_survival", os.path.join(here, "diag", "index_survival.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    v = torch.tensor([5.0, 4.0, 3.9999, 3.0, 1.0, 0.5])
+    ok = mod.valid_ranking
+    assert ok(torch.tensor([0, 1, 2, 3]), v, 1e-3)
+    assert ok(torch.tensor([0, 2, 1, 3]), v, 1e-3)             # the near-tie swapped
+    assert not ok(torch.tensor([0, 2, 1, 3]), v, 1e-5)         # ... which a tighter tolerance rejects
+    assert not ok(torch.tensor([0, 1, 3, 2]), v, 1e-3)         # a real inversion
+    assert not ok(torch.tensor([0, 1, 2, 4]), v, 1e-3)         # a better candidate was left out
+    assert ok(torch.tensor([0, 1, 3]), v, 1e-3) is False       # (2 left out although within the top 3)
+    assert ok(torch.tensor([0, 2, 1]), v, 1e-3)
+    assert ok(torch.arange(6), v, 0.0)

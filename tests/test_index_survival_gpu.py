@@ -1,0 +1,42 @@
+"""Index parity of the benchmarked build on image seeds nobody selected (tests/diag/index_survival.py).
+
+`precision="hybrid"` against the fp32 oracle running its OWN ViT on CONSECUTIVE seeds, tiny architecture and Groma-7B width
+(R: groma/model/ddetr_transformer.py:546-559 top-300, groma/model/groma.py:266-276 NMS + shuffle).  Asserted on EVERY scanned seed:
+ * a seed whose ranking resolves (oracle min adjacent gap of the top-301 logits > 2 x the measured class-logit error) has all 300
+   ids equal -- no seed is exempted by hand;
+ * on every seed, resolved or not, the device's top-300 order is a valid ranking of the ORACLE's logits within 2 x that error (every
+   inversion is a near-tie of two fp32 evaluations), and the top-300 SET overlaps the oracle's by >= 99 %;
+ * the class-logit error stays at fp32-noise level (< 1e-4 on logits of magnitude ~10).
+What fraction of ordinary seeds ends up with all ids equal is a measurement, printed here and committed in
+profiles/r06_index_survival.txt; the sanity floor asserted on it is deliberately loose."""
+import importlib.util
+import os
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _diag():
+    here = os.path.dirname(os.path.abspath(__file__))
+    spec = importlib.util.spec_from_file_location("index_survival", os.path.join(here, "diag", "index_survival.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+@pytest.mark.parametrize("name,n", [("tiny", 100), ("width", 40)])
+def test_hybrid_indices_on_unselected_seeds(dev, name, n):
+    s, rows = _diag().run(name, n, "hybrid", n64=4)
+    assert s["n"] == n
+    for r in rows:
+        assert r["err"] < 1e-4, r
+        assert r["valid"], r                                   # every seed: a valid ranking of the oracle's logits within 2 err
+        assert r["set_overlap"] >= 0.99, r
+        if r["gap"] > 2 * r["err"]:                            # every seed that resolves: equal ids, nothing pre-selected
+            assert r["topk_equal"], r
+        if r["topk_equal"] and r["nms_equal"]:
+            assert r["sel_equal"] and r["boxes"], r            # same kept set + same CPU-RNG draw -> same shuffled selection
+    assert s["slots_mean"] >= 0.97 and s["topk_all_equal"] >= 0.3, s
+    # the device's fp32 evaluation is no noisier than ~3x the oracle's own distance from float64 arithmetic
+    assert s["dev_vs_f64"] <= 3.0 * s["orc_vs_f64"] + 1e-6, s

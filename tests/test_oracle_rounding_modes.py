@@ -33,3 +33,64 @@ def test_rounding_modes_scale_with_the_format():
             assert O._ROUND[0] is None
         assert O._ROUND[0] == "fp16"
     assert O._ROUND[0] is None
+
+
+def test_per_stage_selection_of_the_rounding_points():
+    """round 6 (tests/diag/precision_ablation.py): rounding(mode, only= / skip=) restricts the 16-bit roundings to (all but) the
+    named stages.  Selecting every stage is the plain mode; skipping every stage is fp32; a stage's own contribution is smaller
+    than the whole and the contributions of disjoint stages add up (in quadrature, roughly) to it."""
+    cfg, sd, tk = util.tiny_setup(seed=0)
+    from groma_amd import synth
+    images, ids = synth.make_inputs(cfg, tk, bs=1, seed=1234)
+    cd = cfg.to_dict()
+    stages = ("bridge", "region", "embed", "llm", "head")    # everything behind the ViT (fed identical ViT states here)
+
+    def run(mode, **sel):
+        torch.manual_seed(5)
+        with O.rounding(mode, **sel):
+            return O.groma_forward(sd, cd, util.tok_dict(tk), ids.clone(), images, hidden_states=hs)["logits"]
+    with torch.no_grad():
+        hs = tuple(O.vit_forward(sd, cd, images)[-4:])
+        f32, full = run(None), run("bf16")
+        assert torch.equal(run("bf16", only=stages), full)
+        assert torch.equal(run("bf16", skip=stages), f32)
+        assert torch.equal(run("bf16", only=("llm.qkv", "llm.pv", "llm.o", "llm.gateup", "llm.down")), run("bf16", only=("llm",)))
+        e_full = util.relerr(full, f32)
+        parts = {s: util.relerr(run("bf16", only=(s,)), f32) for s in stages}
+        # weights alone and activations alone of one GEMM are different selections
+        e_w, e_a = util.relerr(run("bf16", only=("llm.down.w",)), f32), util.relerr(run("bf16", only=("llm.down.a",)), f32)
+    print("per-stage bf16 contributions:", {k: f"{v:.2e}" for k, v in parts.items()}, f"all {e_full:.2e}; llm.down w {e_w:.2e} a {e_a:.2e}")
+    assert all(0 < v < e_full * 1.05 for v in parts.values())
+    quad = sum(v * v for v in parts.values()) ** 0.5
+    assert 0.5 * e_full < quad < 2.0 * e_full
+    assert 0 < e_w < parts["llm"] and 0 < e_a < parts["llm"] and e_w != e_a
+    # the selection nests and restores like the mode
+    with O.rounding("fp16", only=("head",)):
+        assert O.rounds_here() is False            # (no stage is open here)
+        with O._st("head"):
+            assert O.rounds_here("w") and O.rounds_here("a")
+        with O._st("llm.o"):
+            assert not O.rounds_here("w")
+    assert O._ONLY[0] is None and O._SKIP[0] is None
+
+
+def test_precision_ablation_script_dry_run_on_the_tiny_model():
+    """tests/diag/precision_ablation.py, oracle side only, on the tiny architecture (the full-depth run needs the GPU box): the
+    script's group tables name existing rounding points (a group that rounds nothing would report 0) and its report is complete"""
+    import importlib.util, io, os
+    here = os.path.dirname(os.path.abspath(__file__))
+    spec = importlib.util.spec_from_file_location("precision_ablation", os.path.join(here, "diag", "precision_ablation.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    cfg, sd, tk = util.tiny_setup(seed=0)
+    buf = io.StringIO()
+    res = mod.run(out=buf, device_side=False, cfg=cfg, sd=sd)
+    for fmt in ("fp16", "bf16"):
+        whole = res["oracle"][fmt]["whole"]["rel"]
+        assert whole > 0
+        for name, s in res["oracle"][fmt]["rows"].items():
+            assert 0 < s["rel"] <= whole * 1.05, (fmt, name, s["rel"], whole)
+    fine = res["oracle"]["fp16"]["rows"]
+    assert len(fine) == len(mod.FINE) + len(mod.COARSE)
+    assert res["oracle"]["fp16"]["skip attn + mlp exact, rest fp16"]["rel"] < res["oracle"]["fp16"]["whole"]["rel"]
+    assert "share of var." in buf.getvalue()
