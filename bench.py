@@ -368,7 +368,7 @@ def launch_roofline(m, step, n, kind):
         ms = sum(r[4] for r in gv)
         nbytes = sum((1.0 if r[3] & 16 else 2.0) * r[1] * r[2] for r in gv)   # (tag 16: e4m3 weights, one byte per element)
         ach = nbytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
-        return {"bound": "hbm", "kernel": "gemv_fused_kernel<MB, XG, W8>(GemvFArgs) -- decode-step weight streaming, one launch per weight matrix", "achieved": ach, "peak": 8000.0,
+        return {"bound": "hbm", "kernel": _stream_kernel_name(bool(m.fp8)), "achieved": ach, "peak": 8000.0,
                 "unit": "GB/s", "frac": ach / 8000.0, "traffic": None, "launches_per_step": len(gv) / n,
                 "avg_launch_us": ms * 1e3 / max(len(gv), 1), "bytes_per_launch": nbytes / max(len(gv), 1)}
     fp8 = bool(m.fp8)
@@ -388,6 +388,12 @@ def launch_roofline(m, step, n, kind):
     if vit_recs is not None:
         out["vit_pair_gemms"] = pair_block(vit_recs, n)
     return out
+
+
+def _stream_kernel_name(fp8):
+    """the decode step's weight-streaming kernel as it appears in a trace (csrc/gemv_fused.hip / csrc/gemv_fp8.hip)"""
+    return ("gemv_fp8_kernel<MB>(GemvFArgs) -- e4m3 weight stream on the matrix unit" if fp8 else
+            "gemv_fused_kernel<MB, XG>(GemvFArgs) -- 16-bit weight stream") + ", one launch per weight matrix"
 
 
 def profiled_steps(m, step, n, base):
@@ -754,7 +760,7 @@ def main():
             # command (the decode steps are graph replays there; the counters see the same kernels)
             gv_traffic = measure_traffic(args.batch, "gemv_fused_kernel", ["--mode", "generate", "--new-tokens", str(args.new_tokens),
                                                                              "--vit-operands", args.vit_operands])
-        out["roofline"] = {"bound": "hbm", "kernel": "gemv_fused_kernel<MB, XG, W8>(GemvFArgs) -- decode-step weight streaming, one launch per weight matrix",
+        out["roofline"] = {"bound": "hbm", "kernel": _stream_kernel_name(fp8),
                            "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0, "traffic": gv_traffic,
                            "traffic_note": "bytes/launch at the L2<->fabric boundary (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, gfx950 correction), averaged over the fused-stream launches; algorithmic = bytes_per_launch" if gv_traffic else None,
                            "launches_per_step": len(gv) / max(args.steps, 1),

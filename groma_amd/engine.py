@@ -172,6 +172,30 @@ class GraphPool:
                 cls._first_sight[0] = prev
         return ctx()
 
+    _eager = ops._lib.ThreadSlot(False)          # per thread: launch eagerly, leave every pool alone (GraphPool.eager())
+
+    @classmethod
+    def eager(cls):
+        """with GraphPool.eager(): ...  -- the calling thread's launch sequences run eagerly and are neither counted nor captured
+        (the settling pass of a warm-up: arenas grow, kernels see their first launch)"""
+        import contextlib
+
+        @contextlib.contextmanager
+        def ctx():
+            prev, cls._eager[0] = cls._eager[0], True
+            try:
+                yield
+            finally:
+                cls._eager[0] = prev
+        return ctx()
+
+    def drop(self, pred):
+        """forget the graphs (and sighting counts) whose key satisfies pred(key) -- keys that bake in memory which no longer exists"""
+        for d in (self._graphs, self._seen):
+            for key in [k for k in d if pred(k)]:
+                d.pop(key, None)
+                self._bytes.pop(key, None)
+
     def __init__(self, cap=16, byte_budget=2 << 30):
         # cap: graphs kept (LRU); byte_budget: device memory the graphs' private pools may pin in total (what a capture reserved is
         # measured around it) -- the least recently used graphs go first when either bound is exceeded
@@ -180,7 +204,7 @@ class GraphPool:
         self.replays = self.captures = 0
 
     def run(self, key, launch):
-        if not GraphPool.enabled or TRACE is not None or torch.cuda.is_current_stream_capturing():
+        if not GraphPool.enabled or GraphPool._eager[0] or TRACE is not None or torch.cuda.is_current_stream_capturing():
             launch()
             return
         g = self._graphs.get(key)
@@ -653,7 +677,8 @@ class LlamaEngine:
         # (e4m3 weights, round 5: the streams read the e4m3 bytes on the matrix unit -- csrc/gemv_fp8.hip, half the HBM traffic per
         #  token; the quantised operand is staged as M x K bytes in LDS, plus the merged context as 16-bit values in the o-proj)
         fits8 = not w["fp8"] or (_ru(bs, 4) * (max(T, self.I) + 16) <= 128 * 1024 and _ru(bs, 4) * (3 * T + 16) <= 128 * 1024 and T <= 4096
-                                 and max(T, self.I) <= 12288 and T % 128 == 0 and self.I % 128 == 0 and self.Vpad % 16 == 0)
+                                 and max(T, self.I) <= 12288 and T % 128 == 0 and self.I % 128 == 0 and self.Vpad % 16 == 0
+                                 and self.hd % 32 == 0)   # (the e4m3 QKV stream rotates heads in 32-dim halves)
         if FUSED_DECODE and L == 1 and M <= 8 and fits8 and T <= 8192 and cache.smax <= 8192 and ops.SP() == 1 and states is None \
                 and self.prec is None:
             return self._decode_forward(h, bs, cache, kv_len, pos_dev, pos_stride, past)

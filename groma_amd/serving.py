@@ -10,8 +10,9 @@ a step -- so the MI355X design batches the decode steps of *different requests*:
     to a request at admission and takes it back when the request finishes; nothing is copied or compacted.  With
     `grow_to` the arena is re-allocated at a larger `max_len` (live rows copied, the step re-captured) when a request
     arrives that would not fit -- the reference's cache has no bound but the model's positions (model_worker.py:287-338);
-  * a request is prefilled ALONE (batch 1) straight into its slot, so its prompt pass is bit-identical to
-    `GromaModel.forward` on that request and independent of whatever else is being served;
+  * the requests admitted in one tick are prefilled TOGETHER (one batched forward into a staging cache, then each row's KV is moved
+    to its slot).  Every kernel of the path is row- / image-independent, so a row of that batch is bit-identical to a batch-1
+    `GromaModel.forward` of the same request (tests/test_fullsize_properties_gpu.py) and independent of its company;
   * every decode step advances ALL occupied rows with one captured hipGraph: per-row positions live on the device
     (`pos_dev`, stride 1 -- csrc/decode.hip), idle rows are masked, the host only reads back the `max_rows` new ids;
   * rows are computed independently by every kernel of the step (GEMV rows, per-(row, head) attention), so a
@@ -151,10 +152,16 @@ class ContinuousBatcher:
         k = max(1, min(int(rows), self.rows))
         ids = input_ids.reshape(1, -1).to(I64).cpu().repeat(k, 1)
         imgs = torch.stack([image] * k)
+        def once():
+            self.model.forward(input_ids=ids.clone(), images=imgs, use_cache=True, return_dict=True,
+                               _cache=_RowView(self.staging, k), _seeds=[0] * k)
+        # first pass EAGER: the workspace arenas grow to their working size and every kernel has had its first launch (lazy
+        # function attributes, module load) -- a graph captured on this pass would be keyed on pre-growth addresses, never be
+        # replayed, and sit in the LRU pools evicting useful ones.  Second pass: capture, on the settled addresses.
+        with engine.GraphPool.eager():
+            once()
         with engine.GraphPool.first_sight():
-            for _ in range(2):   # first pass: arenas grow to their size (new addresses = new keys); second: capture on stable addresses
-                self.model.forward(input_ids=ids.clone(), images=imgs, use_cache=True, return_dict=True,
-                                   _cache=_RowView(self.staging, k), _seeds=[0] * k)
+            once()
 
     # ------------------------------------------------------------------ request intake
     def submit(self, input_ids, image, max_new_tokens=256, refer_boxes=None, ground_boxes=None, eos_token_id="config",
@@ -203,20 +210,34 @@ class ContinuousBatcher:
     def _grow(self, need):
         """Re-allocate the arena (and the staging cache) at max(2 x max_len, need) positions per slot, capped by grow_to.  Live rows
         keep their KV prefix (K rows / V^T columns are copied; (hi, lo) pair storage interleaves in blocks of 32, so a prefix of
-        64-multiples is a prefix there too) and their loop state; the decode step is re-captured on the new addresses."""
+        64-multiples is a prefix there too) and their loop state; the decode step is re-captured on the new addresses.
+        Failure-atomic: both new caches are allocated and the prefixes copied BEFORE anything of the batcher changes; if the device
+        cannot hold them (peak = old arena + old staging + both new caches) the old caches stay in service, False is returned and
+        the over-long request is refused by the ordinary length checks of _admit() -- live rows are never stranded.
+        Cost of a successful growth in the middle of live traffic: the copy, three eager steps + one capture, one device sync."""
         old = self.max_len
         new_len = min(self.grow_to, max(2 * old, -(-int(need) // 64) * 64))
-        if new_len <= old:
-            return
+        if new_len <= old or new_len >= getattr(self, "_grow_failed_at", 1 << 30):
+            return False
         dev = self.tok.device
-        self.staging = None
-        self.staging = self.llm.new_cache(self.rows, new_len, dev)
-        arena = self.llm.new_cache(self.rows, new_len, dev)
-        sp = getattr(arena, "sp", 1)
-        for l in range(len(arena.k)):
-            arena.k[l][:, :, :old].copy_(self.arena.k[l])
-            arena.vt[l][..., : old * sp].copy_(self.arena.vt[l])
-        self.arena, self.max_len = arena, new_len
+        try:
+            staging = self.llm.new_cache(self.rows, new_len, dev)
+            arena = self.llm.new_cache(self.rows, new_len, dev)
+            sp = getattr(arena, "sp", 1)
+            for l in range(len(arena.k)):
+                arena.k[l][:, :, :old].copy_(self.arena.k[l])
+                arena.vt[l][..., : old * sp].copy_(self.arena.vt[l])
+        except RuntimeError as e:   # (torch.cuda.OutOfMemoryError is a RuntimeError)
+            staging = arena = None
+            self._grow_failed_at = new_len       # do not retry this size for every over-long request of the queue
+            self.last_grow_error = str(e)
+            torch.cuda.empty_cache()
+            return False
+        # commit: from here on nothing can fail half-way
+        stale = set(engine.cache_addresses(self.staging)[1:])
+        self.staging, self.arena, self.max_len = staging, arena, new_len
+        # prefill graphs captured against the old staging cache can never be replayed again: free their slots in the LRU pool
+        self.llm.graphs.drop(lambda key: any(a in stale for a in key))
         if self.graph is not None:
             # the three eager warm-up steps in front of a capture advance every row: keep the loop state aside and put it back (what they
             # wrote into live rows' KV lies at positions >= pos, which the next real step rewrites before it attends to them)
@@ -226,6 +247,7 @@ class ContinuousBatcher:
             self._capture()
             for t, v in zip(keep, saved):
                 t.copy_(v)
+        return True
 
     # ------------------------------------------------------------------ admission: one batched prefill per tick
     def _admit(self, reqs):
@@ -235,9 +257,11 @@ class ContinuousBatcher:
         request's tokens; each request's region shuffle draws from its own seed."""
         m, k = self.model, len(reqs)
         if self.max_len < self.grow_to:
+            # (_bound is a worst case -- the real spliced length is only known after the prefill -- so a request that would just
+            #  have fitted can trigger a growth; the alternative, prefilling first and re-admitting, costs a second prefill)
             need = max(self._bound(r) for r in reqs)
             if need > self.max_len:
-                self._grow(need)
+                self._grow(need)   # False: the old caches stay; the length checks below refuse what does not fit
         P = max(r.input_ids.numel() for r in reqs)
         ids = torch.full((k, P), int(m.pad_token_id), dtype=I64)
         for i, r in enumerate(reqs):

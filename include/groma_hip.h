@@ -121,7 +121,10 @@ typedef struct gr_gemv_desc {
   /* ABI 9 -- OCP e4m3 weights (BASELINE configs[4] at L = 1): w8 != 0: W is [N, K] e4m3 BYTES (ldw in elements) with the per-row
    * scale w_scale [N]; the operand is quantised by the prologue exactly as the e4m3 prefill path forms it (per row, s = max|x| / 448,
    * q = e4m3_rne(x * (1 / s)): x_mode 1 from the fp32 normalisation output, x_mode 0 / 2 from the 16-bit-rounded activation) and
-   * y = acc * w_scale[n] * s[m] before the epilogue.  M * K * 2 <= 128 KB (the staged operand); x_mode 1 needs K <= 4096. */
+   * y = acc * w_scale[n] * s[m] before the epilogue.  Limits (GR_EINVAL beyond; engine.LlamaEngine.forward `fits8` checks them and
+   * falls back to the general kernels): the staged operand MB * (K + 16) bytes (MB = M rounded up to 4 / 8; + MB * K * 2 bytes for
+   * x_mode 2, whose merged context is held 16-bit before it is quantised) <= 128 KB; K % 128 == 0; K <= 12288 for x_mode 0 / 2 (the
+   * register-resident row quantiser) and K <= 4096 for x_mode 1; N % 16 == 0; HD % 32 == 0 for epi 3. */
   int w8; const float* w_scale;
 } gr_gemv_desc;
 int gr_gemv_fused(const gr_gemv_desc* d, hipStream_t stream);

@@ -580,8 +580,15 @@ def test_batcher_arena_growth_keeps_live_prefixes():
 
     class LLM:
         H, hd, T, w = 2, 32, 16, {"layers": [None, None]}
+        fail_after = None       # new_cache raises once this many caches have been handed out (an allocation failure)
+
+        def __init__(self):
+            self.graphs, self.made = engine.GraphPool(), 0
 
         def new_cache(self, bs, smax, device):
+            if self.fail_after is not None and self.made >= self.fail_after:
+                raise RuntimeError("HIP out of memory (simulated)")
+            self.made += 1
             return engine.KVCache(2, bs, self.H, self.hd, smax, device)
     for prec, sp in (("bf16", 1), ("ref", 2)):
         model = SimpleNamespace(device=torch.device("cpu"), fp8=False, precision=prec, llm=LLM(), vit=SimpleNamespace(G=8),
@@ -606,6 +613,30 @@ def test_batcher_arena_growth_keeps_live_prefixes():
         assert b.max_len == 256 and torch.equal(b.arena.k[1][:, :, :64], old_k[1])
     with pytest.raises(ValueError):
         ContinuousBatcher(model, max_rows=2, max_len=64, grow_to=100)
+    # round 6: a growth that cannot be allocated leaves the batcher exactly as it was -- whichever of the two new caches
+    # fails -- and the size is not retried for every over-long request of the queue; prefill graphs keyed on the old staging cache
+    # are dropped from the LRU pool after a successful growth
+    for fail_at in (2, 3):     # (the batcher's own two caches are #0 and #1: fail on the new staging cache, or on the new arena)
+        model = SimpleNamespace(device=torch.device("cpu"), fp8=False, precision="bf16", llm=LLM(), vit=SimpleNamespace(G=8),
+                                config=SimpleNamespace(max_region_num=5))
+        b = ContinuousBatcher(model, max_rows=2, max_len=64, use_graph=False, grow_to=256)
+        model.llm.fail_after = fail_at
+        arena, staging = b.arena, b.staging
+        snap = [t.copy_(torch.randn(t.shape)).clone() for t in b.arena.k]
+        assert b._grow(100) is False
+        assert b.arena is arena and b.staging is staging and (b.max_len, b.arena.smax, b.staging.smax) == (64, 64, 64)
+        assert all(torch.equal(a, c) for a, c in zip(b.arena.k, snap)) and "simulated" in b.last_grow_error
+        made = model.llm.made
+        assert b._grow(100) is False and model.llm.made == made          # the failed size is not attempted again
+        model.llm.fail_after = None
+        assert b._grow(90) is False                                       # (same target size 128: still refused without an attempt)
+    model.llm.fail_after = None
+    del b._grow_failed_at
+    stale_key = ("llm", 2, 70, 0, True, "throughput", False, 1) + engine.cache_addresses(b.staging)
+    live_key = ("llm", 2, 70, 0, True, "throughput", False, 1, 64, 12345678)
+    b.llm.graphs._graphs[stale_key], b.llm.graphs._graphs[live_key] = object(), object()
+    assert b._grow(100) is True and b.max_len == 128
+    assert stale_key not in b.llm.graphs._graphs and live_key in b.llm.graphs._graphs
 
 
 def test_valid_ranking_rule_of_the_index_survival_scan():

@@ -109,6 +109,64 @@ def test_roi_align_forward_bit_exact_avg_and_max(dev, aligned, sampling_ratio):
     assert np.array_equal(ay.cpu().numpy(), w_ay) and np.array_equal(ax.cpu().numpy(), w_ax)
 
 
+@pytest.mark.parametrize("case", ["table_in_passes", "taps_on_the_fly", "degenerate_grid", "many_rois"])
+def test_roi_align_forward_table_passes_and_large_grids(dev, case):
+    """the compat kernel's three regimes (csrc/roi_align.hip roi_align_planes_kernel): the ROI's sample table built in several passes
+    over bin ranges (more samples than the 1024-entry LDS table), taps evaluated on the fly (one bin alone exceeds the table), bins
+    without samples (adaptive grid <= 0 on a negative-extent ROI), and the 32-planes-per-workgroup split -- all bit-exact against the
+    C oracle, avg and max; a non-finite pixel never leaks through a sample that lies outside the map"""
+    from groma_amd import ops
+    rng = np.random.default_rng(23)
+    N, C, H, W = 2, 40, 48, 64
+    K = {"many_rois": 40}.get(case, 9)
+    if case == "many_rois":
+        C = 44           # (a channel count that is not a multiple of the 8-plane chunk)
+    x = rng.standard_normal((N, C, H, W)).astype(np.float32)
+    rois = np.zeros((K, 5), dtype=np.float32)
+    rois[:, 0] = rng.integers(0, N, K)
+    if case == "table_in_passes":      # grid ~ 8 x 12 = 96 samples x 35 bins > 1024 entries
+        sr, scale = 0, 1.0
+        rois[:, 1:3] = rng.random((K, 2)) * 8
+        rois[:, 3] = rois[:, 1] + 50 + rng.random(K) * 9     # width / 5 bins -> grid_w 10..12
+        rois[:, 4] = rois[:, 2] + 44 + rng.random(K) * 4     # height / 7 bins -> grid_h 7
+    elif case == "taps_on_the_fly":    # one bin: ceil(300 / 7) x ceil(300 / 5) = 43 x 60 samples > 1024
+        sr, scale = 0, 1.0
+        rois[:, 1:3] = -100 + rng.random((K, 2)) * 50
+        rois[:, 3:] = rois[:, 1:3] + 280 + rng.random((K, 2)) * 20
+    elif case == "degenerate_grid":    # negative extents with an adaptive grid: ceil(negative) <= 0 -> no samples at all
+        sr, scale = 0, 1.0
+        rois[:, 1:3] = 20 + rng.random((K, 2)) * 20
+        rois[:, 3:] = rois[:, 1:3] - 1 - rng.random((K, 2)) * 15
+    else:
+        sr, scale = 2, 1 / 7.0
+        rois[:, 1:] = rng.random((K, 4)) * 448
+    x[0, :, 0, :] = np.inf                # row 0 of image 0 is non-finite: samples clamped ONTO it see it, samples outside the map must not
+    x[1, :, :, W - 1] = np.nan
+    xt, rt = torch.from_numpy(x).to(dev), torch.from_numpy(rois).to(dev)
+    out = torch.empty((K, C, 7, 5), device=dev)
+    ops.roi_align_forward(xt, rt, out, None, None, 7, 5, scale, sr, 1, True)
+    want = cref.roi_align_avg(x, rois, (7, 5), scale, sr, True)
+    assert np.array_equal(out.cpu().numpy(), want, equal_nan=True)
+    ay, ax = torch.empty_like(out), torch.empty_like(out)
+    ops.roi_align_forward(xt, rt, out, ay, ax, 7, 5, scale, sr, 0, True)
+    w_out, w_ay, w_ax = cref.roi_align_max(x, rois, (7, 5), scale, sr, True)
+    assert np.array_equal(out.cpu().numpy(), w_out, equal_nan=True)
+    assert np.array_equal(ay.cpu().numpy(), w_ay) and np.array_equal(ax.cpu().numpy(), w_ax)
+
+
+def test_roi_align_forward_wide_channel_split(dev):
+    """K * ceil(C / 32) >= 1024 workgroups: 32 channel planes per workgroup (the other tests run the 8-plane split)"""
+    from groma_amd import ops
+    rng = np.random.default_rng(29)
+    N, C, H, W, K = 1, 256, 16, 16, 130
+    x = rng.standard_normal((N, C, H, W)).astype(np.float32)
+    rois = np.zeros((K, 5), dtype=np.float32)
+    rois[:, 1:] = rng.random((K, 4)) * 448
+    out = torch.empty((K, C, 14, 14), device=dev)
+    ops.roi_align_forward(torch.from_numpy(x).to(dev), torch.from_numpy(rois).to(dev), out, None, None, 14, 14, 1 / 28.0, 2, 1, True)
+    assert np.array_equal(out.cpu().numpy(), cref.roi_align_avg(x, rois, (14, 14), 1 / 28.0, 2, True))
+
+
 def test_nchw_entry_equals_packed_hot_path_entry(dev):
     """gr_roi_align_forward (NCHW f32, reference layout) and gr_roi_align_pack (NHWC bf16 -> f32, the hot-path entry)
     are the same operator on bf16-representable inputs"""
