@@ -2,8 +2,7 @@
 // proposer (kept fp32 so top-k / NMS indices are reproducible) and the
 // small region-encoder MLPs (groma/model/roi_align.py:254-261).
 //   C[M,N] = act(A[M,K] . W[N,K]^T + bias) (+ resid)      A, W, C row-major fp32
-// Every product and sum is plain IEEE fp32 (the MFMA accumulates an fmaf chain per output element); only the ORDER of the
-// K summation differs from a CPU loop.
+// fp32 operands, products and sums in float64 (round 6, below), one rounding to fp32 per output element.
 //
 // Round-2 kernel.  Round 1's 64x64x16 tile read its operands with scalar ds_read_b32 (4 LDS reads per 4 MFMAs) and
 // measured 17 TF/s = 11 % of the 157 TF/s f32-MFMA peak -- 11.8 ms of a 138 ms step at 14 images, and NOT hidden: the
@@ -20,7 +19,16 @@
 #include "gr_common.h"
 #include "../../include/groma_hip.h"
 
+//
+// Round 6: float64 ACCUMULATION (v_mfma_f64_16x16x4_f64 on the fp32 operands widened in registers, the bias / residual added in
+// float64, ONE rounding to fp32 at the store).  Why: the proposer's class logits decide the top-300 ranking against gaps of
+// ~1e-5 (profiles/r06_index_survival.txt), and two fp32 evaluations of the same proposer -- this kernel's sequential fmaf chains
+// over K and the reference's host / cuBLAS blocking -- differ by about that much; measured against the oracle re-evaluated in
+// float64 the device's logits were 1.5x noisier than the oracle's own fp32 (rms 3.8e-6 vs 2.5e-6).  With the dot products exact
+// to fp32 rounding the device stops adding its own summation noise: what is left between the two is the reference's.  The fp64 matrix
+// pipe runs at half the fp32 one's rate (78 vs 157 TF/s); the proposer is 14.5 GFLOP per image and runs beside the region pyramid.
 #define FBK 16
+typedef __attribute__((ext_vector_type(4))) double f64x4;
 
 template <int BM, int BN>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__ A, const float* __restrict__ W,
@@ -63,11 +71,11 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
 #pragma unroll
   for (int i = 0; i < NW; ++i) rw[i] = *(const f32x4*)wp[i];
 
-  f32x4 acc[TM][TN];
+  f64x4 acc[TM][TN];
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
-    for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < TN; ++j) acc[i][j] = (f64x4){0., 0., 0., 0.};
 
   // fragment reads: row R = base + 16*i + fr -> (R >> 2) & 3 == (fr >> 2) & 3 (bases are multiples of 16)
   const int fsw = ((fk ^ ((fr >> 2) & 3)) << 2);
@@ -94,12 +102,18 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
 #pragma unroll
     for (int j = 0; j < TN; ++j) wf[j] = *(const f32x4*)(&ws[buf][w_lane + j * 16 * FBK]);
 #pragma unroll
-    for (int k4 = 0; k4 < 4; ++k4)
+    for (int k4 = 0; k4 < 4; ++k4) {
+      double ad[TM], wd[TN];   // fp32 -> fp64 is exact
+#pragma unroll
+      for (int i = 0; i < TM; ++i) ad[i] = (double)af[i][k4];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) wd[j] = (double)wf[j][k4];
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j)  // swapped operands: MFMA rows = n, columns = m (a lane gets 4 consecutive n)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[j][k4], af[i][k4], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(wd[j], ad[i], acc[i][j], 0, 0, 0);
+    }
     // the next iteration writes the other buffer; the barrier at its top orders those writes after these reads
   }
   const bool vec = (ldc & 3) == 0 && (N & 3) == 0 && (((uintptr_t)C) & 15) == 0 && (!resid || (((uintptr_t)resid) & 15) == 0) &&
@@ -112,24 +126,32 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
     for (int j = 0; j < TN; ++j) {
       const int n = n0 + wn * (BN / 2) + j * 16 + fk * 4;
       if (n >= N) continue;
-      f32x4 v = acc[i][j];
+      f64x4 v = acc[i][j];   // bias, activation and residual in float64 too: one rounding, at the store
       if (vec) {
-        if (bias) v += *(const f32x4*)(bias + n);
+        if (bias) {
+          const f32x4 b = *(const f32x4*)(bias + n);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] += (double)b[e];
+        }
         if (act == 2) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+          for (int e = 0; e < 4; ++e) v[e] = v[e] > 0. ? v[e] : 0.;
         }
-        if (resid) v += *(const f32x4*)(resid + (long)m * ldc + n);
-        *(f32x4*)(C + (long)m * ldc + n) = v;
+        if (resid) {
+          const f32x4 r = *(const f32x4*)(resid + (long)m * ldc + n);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] += (double)r[e];
+        }
+        *(f32x4*)(C + (long)m * ldc + n) = (f32x4){(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
       } else {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           if (n + e < N) {
-            float x = v[e];
-            if (bias) x += bias[n + e];
-            if (act == 2) x = fmaxf(x, 0.f);
-            if (resid) x += resid[(long)m * ldc + n + e];
-            C[(long)m * ldc + n + e] = x;
+            double x = v[e];
+            if (bias) x += (double)bias[n + e];
+            if (act == 2) x = x > 0. ? x : 0.;
+            if (resid) x += (double)resid[(long)m * ldc + n + e];
+            C[(long)m * ldc + n + e] = (float)x;
           }
         }
       }

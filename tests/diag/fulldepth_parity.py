@@ -157,5 +157,63 @@ def run(seed=0, precision="bf16"):
     return res
 
 
+def run_fp8(seed=0):
+    """BASELINE configs[4] at the real depth: the e4m3 model ("hybrid" + fp8=True: DINOv2 on operand pairs, the
+    LLaMA linears, lm_head and the region encoder's 3x3 convs on OCP e4m3 with per-row / static scales) against
+      (a) the bf16 device path of the same weights ("hybrid") -- configs[4]'s "logits within stated tol vs bf16",
+      (b) the fp32 oracle, unchained,  (c) the e4m3-rounded oracle (oracle.groma_oracle.rounding("e4m3")) on the same fp32 ViT states,
+    and (d) what the e4m3 FORMAT costs the oracle itself at this depth (e4m3-rounded oracle <-> fp32 oracle)."""
+    torch.set_num_threads(min(64, os.cpu_count() or 8))
+    full = gconfig.groma_7b(box_score_thres=0.0)
+    dev = torch.device("cuda")
+    tk = util.TokenIds()
+    images, ids = synth.make_inputs(full, tk, 1, seed=1234)
+    sd = LazyDeviceStateDict(full, seed, dev)
+    cd = full.to_dict()
+    rel = util.relerr
+    outs = {}
+    with torch.no_grad():
+        for name, kw in (("bf16", dict(precision="hybrid")), ("e4m3", dict(precision="hybrid", fp8=True))):
+            t = time.time()
+            model = GromaModel.from_synthetic(full, seed=seed, device=dev, **kw)
+            model.init_special_token_id(constants.SyntheticTokenizer())
+            torch.manual_seed(77)
+            o = model.forward(input_ids=ids.clone(), images=images, return_dict=True, use_cache=True)
+            aux = model._last_aux
+            outs[name] = dict(logits=o.logits.float().cpu(), ids=aux["input_ids"], topk=aux["topk_idx"].cpu().long(), nms=aux["nms_keep"][0],
+                              k31=o.past_key_values[31][0].float().cpu(), region=o.hidden_states[1]["region_features"].float().cpu(), mode=model.mode)
+            print(f"device {model.mode}: packed + forward in {time.time() - t:.1f} s")
+            del model, o, aux
+            torch.cuda.empty_cache()
+        t = time.time()
+        own = O.vit_forward(sd, cd, images)
+        ref = {}
+        for mode in (None, "e4m3"):
+            torch.manual_seed(77)
+            with O.rounding(mode):
+                ref[mode] = O.groma_forward(sd, cd, util.tok_dict(tk), ids.clone(), images, hidden_states=tuple(own))
+            print(f"oracle ({'fp32' if mode is None else 'e4m3-rounded'}, its own fp32 ViT): {time.time() - t:.1f} s")
+    d8, d16, o32, o8 = outs["e4m3"], outs["bf16"], ref[None], ref["e4m3"]
+    eq = dict(topk_equal=torch.equal(d8["topk"], o32["det"]["topk_idx"]), nms_equal=torch.equal(d8["nms"], o32["nms_inds"][0]),
+              ids_equal=torch.equal(d8["ids"], o32["input_ids"]) and torch.equal(d16["ids"], o32["input_ids"]))
+    print("e4m3 model: top-300 ids equal:", eq["topk_equal"], "| NMS ids equal:", eq["nms_equal"], "| spliced ids equal:", eq["ids_equal"])
+    res = dict(eq)
+    for name, f_dev, f_or in (("region tokens", lambda d: d["region"], lambda r: r["region_features"]),
+                              ("K cache layer 31", lambda d: d["k31"], lambda r: r["past"][31][0]),
+                              ("logits (32 layers deep, all 582 positions)", lambda d: d["logits"], lambda r: r["logits"]),
+                              ("last-position region logits <r0..r99>", lambda d: d["logits"][:, -1, 32014:32114], lambda r: r["logits"][:, -1, 32014:32114])):
+        a = dict(vs_bf16_device=rel(f_dev(d8), f_dev(d16)), vs_fp32=rel(f_dev(d8), f_or(o32)), vs_e4m3_oracle=rel(f_dev(d8), f_or(o8)),
+                 format=rel(f_or(o8), f_or(o32)), bf16_device_vs_fp32=rel(f_dev(d16), f_or(o32)))
+        res[name] = a
+        print(f"{name:44s} e4m3 device<->bf16 device {a['vs_bf16_device']:.3e} | <->fp32 oracle {a['vs_fp32']:.3e} | <->e4m3-rounded oracle {a['vs_e4m3_oracle']:.3e} | "
+              f"e4m3-rounded oracle<->fp32 (the format) {a['format']:.3e} | bf16 device<->fp32 {a['bf16_device_vs_fp32']:.3e}")
+    am = lambda a, b: (a.argmax(-1) == b.argmax(-1)).float().mean().item()
+    res["argmax_vs_bf16_device"], res["argmax_vs_fp32"], res["argmax_oracle_e4m3_vs_fp32"] = am(d8["logits"], d16["logits"]), am(d8["logits"], o32["logits"]), am(o8["logits"], o32["logits"])
+    print(f"arg-max of the e4m3 model equal to the bf16 device's at {res['argmax_vs_bf16_device']:.3f} of positions, to the fp32 oracle's at {res['argmax_vs_fp32']:.3f} "
+          f"(e4m3-rounded oracle vs fp32: {res['argmax_oracle_e4m3_vs_fp32']:.3f})")
+    return res
+
+
 if __name__ == "__main__":
-    run(precision=sys.argv[1] if len(sys.argv) > 1 else "bf16")
+    a = sys.argv[1] if len(sys.argv) > 1 else "bf16"
+    run_fp8() if a == "fp8" else run(precision=a)

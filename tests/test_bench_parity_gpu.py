@@ -1,0 +1,45 @@
+"""bench.py's `parity` block (round 6): the benchmarked MODE against the unchained fp32 oracle on the bench's own inputs at reduced
+depth -- the function the driver's BENCH record carries the result of, asserted here on those same inputs (seed 1234, the first
+timed step's CPU-RNG seed).  Nothing about these inputs was selected: an image whose oracle ranking does not resolve against the
+device's fp32 evaluation error may legitimately differ in a near-tie, and then the block must SAY so (resolves = False, valid
+ranking = True) rather than hide it."""
+import importlib.util
+import os
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench():
+    spec = importlib.util.spec_from_file_location("bench_parity_mod", os.path.join(ROOT, "bench.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+@pytest.mark.parametrize("precision", ["hybrid", "hybrid-fp16"])
+def test_parity_block_of_the_benchmarked_modes_on_the_bench_inputs(dev, precision):
+    from groma_amd import config as gconfig, synth
+    from tests import util
+    bench = _bench()
+    cfg = gconfig.groma_7b(box_score_thres=0.0)
+    images, ids = synth.make_inputs(cfg, util.TokenIds(), 14, seed=1234, prompt_len=128)      # bench.measure(): rank 0, 14 images
+    r = bench.parity_block(precision, False, images[:2].to(dev), ids[:2].to(dev), seed=1000 + 3)   # default --warmup 3
+    print(r)
+    assert r["mode"] == precision and len(r["images"]) == 2
+    assert r["vit_states_rel_l2"] < 1e-5                                   # the pair-operand ViT
+    for p in r["images"]:
+        assert p["class_logit_err"] < 1e-4
+        assert p["valid_ranking_within_2err"]                              # always: every inversion is a near-tie of two fp32 evaluations
+        assert p["top300_slots_equal"] >= 0.9
+        if p["resolves"]:
+            assert p["top300_ids_equal"]
+        if p["top300_ids_equal"] and p["nms_ids_equal"]:
+            assert p["selection_equal"]
+    if r["all_index_results_equal"]:
+        assert r["spliced_ids_equal"] and r["logits_rel_l2"] <= r["logits_tolerance"], r
+        assert r["argmax_agree"] >= 0.9
+    assert r["logits_tolerance"] == {"hybrid": 1.5e-2, "hybrid-fp16": 2e-3}[precision]

@@ -122,7 +122,9 @@ def test_mixed_stack_prefill_graph_equals_eager_and_generates(world):
     torch.manual_seed(world["seed"])
     out = m.forward(input_ids=world["ids"].clone(), images=world["images"], return_dict=True, use_cache=True)
     k0 = out.past_key_values[0][0]
-    assert k0.dtype == torch.float32 and util.relerr(k0, world["ref"]["past"][0][0]) < 1e-4
+    # (pairs hold what the stage computed from its fp32 input; that input -- embeddings, image / region tokens -- carries the fp16
+    #  stages' rounding, 3.4e-4 here, where the all-fp16 build's layer-0 K is at ~1e-3)
+    assert k0.dtype == torch.float32 and util.relerr(k0, world["ref"]["past"][0][0]) < 6e-4
     # greedy tokens (boosted <r_k> rows as in tests/test_parity_gpu.py::gen_setup so that no step is a near-tie)
     sd = dict(world["sd"])
     w = sd["extra_lm_head.weight"].clone()
