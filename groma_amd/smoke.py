@@ -20,7 +20,11 @@ def run_smoke():
     model = GromaModel.from_state_dict(cfg, sd, "cuda:0")
     tk = constants.SyntheticTokenizer()
     model.init_special_token_id(tk)
-    images, ids = synth.make_inputs(cfg, model, bs=1, seed=1)
+    # image seed 648: the first committed UNCHAINED fixture at this width (tests/golden/e2e_seeds.json: the oracle's smallest adjacent gap
+    # among its top-301 class logits is 1.4e-4, ~10x the distance between two fp32 evaluations of the proposer), so the torch.equal
+    # assertions on index-valued results below are decided by the implementation, never by a near-tie (what happens on unselected
+    # seeds is measured: profiles/r06_index_survival.txt, and reported per run by bench.py's `parity` block)
+    images, ids = synth.make_inputs(cfg, model, bs=1, seed=648)
     torch.manual_seed(3)
     out = model.forward(input_ids=ids.clone(), images=images, return_dict=True)
     torch.cuda.synchronize()
@@ -60,24 +64,29 @@ def run_smoke():
     assert ids_eq and same_shape and err < 1e-3, f"precision='ref' unchained: spliced ids equal {ids_eq}, logits relative error {err}"
     print(f"smoke ok (precision='ref', oracle UNCHAINED = its own fp32 ViT): logits rel-L2 {err:.2e} (north star 1e-3), top-300 ids equal "
           f"{topk_eq}, NMS ids equal {nms_eq}, spliced ids equal {ids_eq}")
-    # third leg (round 5): precision="hybrid" -- the build bench.py's headline runs.  Only the ViT is on operand pairs; the index-valued
-    # results must equal the UNCHAINED oracle's (same `ref` as above), the logits keep the bf16 format's distance behind the ViT
+    # third / fourth leg: the per-stage builds -- only the ViT on operand pairs, everything behind it on 16-bit operands.  Round 6's
+    # benchmarked build is "hybrid-fp16" (IEEE half behind the ViT), round 5's was "hybrid" (bf16).  The index-valued results must equal the
+    # UNCHAINED oracle's (same `ref` as above); the logits keep the 16-bit format's distance behind the ViT (stated tolerances)
     del mref, out
     torch.cuda.empty_cache()
-    mh = GromaModel.from_state_dict(cfg, sd, "cuda:0", precision="hybrid")
-    mh.init_special_token_id(tk)
-    torch.manual_seed(3)
-    out = mh.forward(input_ids=ids.clone(), images=images, return_dict=True)
-    torch.cuda.synchronize()
-    aux = mh._last_aux
-    a = out.logits.float().cpu()
-    topk_eq = torch.equal(aux["topk_idx"].cpu().long(), ref["det"]["topk_idx"])
-    nms_eq = torch.equal(aux["nms_keep"][0], ref["nms_inds"][0])
-    sel_eq = torch.equal(aux["sel_idx"][0], ref["nms_inds"][0][ref["perms"][0]])
-    ids_eq = torch.equal(aux["input_ids"], ref["input_ids"])
-    vit_err = max(((h.float().cpu() - r).norm() / r.norm()).item() for h, r in zip(aux["hidden4"], ref["hidden_states"][-4:]))
-    err = ((a - b).norm() / b.norm()).item() if a.shape == b.shape else float("inf")
-    assert topk_eq and nms_eq and sel_eq and ids_eq, f"precision='hybrid' unchained: top-300 {topk_eq}, NMS {nms_eq}, selection {sel_eq}, spliced ids {ids_eq}"
-    assert vit_err < 1e-5 and err < 1.5e-2, f"precision='hybrid' unchained: ViT states {vit_err}, logits {err}"
-    print(f"smoke ok (precision='hybrid' = the benchmarked build: ViT on operand pairs, rest bf16; oracle UNCHAINED): top-300 ids equal {topk_eq}, "
-          f"NMS ids equal {nms_eq}, shuffled selection equal {sel_eq}, spliced ids equal {ids_eq}; ViT states rel-L2 {vit_err:.2e}, logits rel-L2 {err:.2e} (bf16 format)")
+    for prec, tol, what in (("hybrid-fp16", 2e-3, "the benchmarked build: ViT on operand pairs, rest IEEE half"),
+                            ("hybrid", 1.5e-2, "ViT on operand pairs, rest bf16")):
+        mh = GromaModel.from_state_dict(cfg, sd, "cuda:0", precision=prec)
+        mh.init_special_token_id(tk)
+        torch.manual_seed(3)
+        out = mh.forward(input_ids=ids.clone(), images=images, return_dict=True)
+        torch.cuda.synchronize()
+        aux = mh._last_aux
+        a = out.logits.float().cpu()
+        topk_eq = torch.equal(aux["topk_idx"].cpu().long(), ref["det"]["topk_idx"])
+        nms_eq = torch.equal(aux["nms_keep"][0], ref["nms_inds"][0])
+        sel_eq = torch.equal(aux["sel_idx"][0], ref["nms_inds"][0][ref["perms"][0]])
+        ids_eq = torch.equal(aux["input_ids"], ref["input_ids"])
+        vit_err = max(((h.float().cpu() - r).norm() / r.norm()).item() for h, r in zip(aux["hidden4"], ref["hidden_states"][-4:]))
+        err = ((a - b).norm() / b.norm()).item() if a.shape == b.shape else float("inf")
+        assert topk_eq and nms_eq and sel_eq and ids_eq, f"precision={prec!r} unchained: top-300 {topk_eq}, NMS {nms_eq}, selection {sel_eq}, spliced ids {ids_eq}"
+        assert vit_err < 1e-5 and err < tol, f"precision={prec!r} unchained: ViT states {vit_err}, logits {err} (stated tolerance {tol})"
+        print(f"smoke ok (precision={prec!r} = {what}; oracle UNCHAINED): top-300 ids equal {topk_eq}, NMS ids equal {nms_eq}, shuffled selection "
+              f"equal {sel_eq}, spliced ids equal {ids_eq}; ViT states rel-L2 {vit_err:.2e}, logits rel-L2 {err:.2e} (stated tolerance {tol:g})")
+        del mh, out, aux
+        torch.cuda.empty_cache()
