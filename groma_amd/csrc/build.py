@@ -14,6 +14,7 @@ SOURCES = {
     "gemv_fused.hip": [],
     "gemv_fp8.hip": [],
     "gemm_fp8_256.hip": [],
+    "gemm_skinny.hip": [],
     "fp8.hip": [],
     "gemm_f32.hip": [],
     "attention.hip": [],

@@ -321,7 +321,9 @@ extern "C" int gr_gemm_bf16(const gr_gemm_desc* d, hipStream_t stream) {
   const bool gemv = d->tile == 1 || d->tile == 2;  // decode-step shape: weights streamed once, no MFMA (gemv_bf16.hip)
   const bool partials_only = d->tile == 2;         // the caller's next kernel consumes ws[splits, M, N] (decode.hip)
   if (gemv && (p.M > 8 || p.conv_C > 0 || splits != gr_cdiv(p.K, 512) || !p.ws)) return GR_EINVAL;
-  if (d->tile != 0 && d->tile != 1 && d->tile != 2 && d->tile != 128 && d->tile != 256 && d->tile != GR_TILE_PP192) return GR_EINVAL;
+  const bool skinny = d->tile == 3;                // decode steps of 9..64 rows: the weight stream on the matrix unit (gemm_skinny.hip)
+  if (skinny && (d->fp8 || splits > 1)) return GR_EINVAL;
+  if (d->tile != 0 && d->tile != 1 && d->tile != 2 && d->tile != 3 && d->tile != 128 && d->tile != 256 && d->tile != GR_TILE_PP192) return GR_EINVAL;
   if (d->tile == 256 || d->fp8) use256 = true;  // fp8 exists for the 256x256 kernel only
   else if (d->tile == GR_TILE_PP192) { use256 = true; pp_rows = 192; }
   else if (d->tile == 0) {
@@ -355,10 +357,13 @@ extern "C" int gr_gemm_bf16(const gr_gemm_desc* d, hipStream_t stream) {
     (void)hipEventCreate(&rec.a);
     (void)hipEventCreate(&rec.b);
     rec.flops = 2.0 * p.M * (double)p.N * d->K;  // algorithmic (logical K; the split build issues 3x this in MFMA work); fp8 launches are tagged 16
-    rec.M = p.M; rec.N = p.N; rec.K = d->K; rec.tag = (p.conv_C > 0 ? 1 : 0) | (splits > 1 ? 2 : 0) | (use256 ? 4 : 0) | (gemv ? 8 : 0) | (d->fp8 ? 16 : 0);
+    rec.M = p.M; rec.N = p.N; rec.K = d->K; rec.tag = (p.conv_C > 0 ? 1 : 0) | (splits > 1 ? 2 : 0) | (use256 ? 4 : 0) | (gemv || skinny ? 8 : 0) | (d->fp8 ? 16 : 0) | (skinny ? 64 : 0);
     (void)hipEventRecord(rec.a, stream);
   }
-  if (gemv) {
+  if (skinny) {
+    const int rc = gr_launch_gemm_skinny(p, stream);
+    if (rc != GR_OK) return rc;
+  } else if (gemv) {
     const int rc = gr_launch_gemv(p, stream);
     if (rc != GR_OK) return rc;
   } else if (use256) {

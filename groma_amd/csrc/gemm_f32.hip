@@ -30,11 +30,54 @@
 #define FBK 16
 typedef __attribute__((ext_vector_type(4))) double f64x4;
 
+// Which accumulator element of which lane holds which output row of v_mfma_f64_16x16x4_f64 is a property of the instruction; this file
+// does not assume it, it ASKS: the first call multiplies A[i][k] = i (k = 0) by B[k][j] = (k == 0) and reads the row index every
+// (lane, element) ends up with -- 4 * (lane / 16) + v (the fp32 16x16x4 form) or 4 * v + lane / 16 -- and the epilogue takes the
+// answer as `rowmap`.  Anything else fails the call (GR_EINVAL) instead of storing rows in the wrong place.
+__global__ void mfma64_probe_kernel(int* out) {
+  const int lane = threadIdx.x & 63, fr = lane & 15, fk = lane >> 4;
+  f64x4 r = {0., 0., 0., 0.}, c = {0., 0., 0., 0.}, kk = {0., 0., 0., 0.};
+  r = __builtin_amdgcn_mfma_f64_16x16x4f64(fk == 0 ? (double)fr : 0., fk == 0 ? 1. : 0., r, 0, 0, 0);   // D[i][j] = i
+  c = __builtin_amdgcn_mfma_f64_16x16x4f64(fk == 0 ? 1. : 0., fk == 0 ? (double)fr : 0., c, 0, 0, 0);   // D[i][j] = j
+  // both operands index k by lane / 16: A[i][k] = 10^k, B[k][j] = k + 1  ->  D = 1 + 20 + 300 + 4000 everywhere
+  kk = __builtin_amdgcn_mfma_f64_16x16x4f64(fk == 0 ? 1. : fk == 1 ? 10. : fk == 2 ? 100. : 1000., (double)(fk + 1), kk, 0, 0, 0);
+#pragma unroll
+  for (int v = 0; v < 4; ++v) {
+    out[lane * 8 + v] = (int)r[v];
+    out[lane * 8 + 4 + v] = kk[v] == 4321. ? (int)c[v] : -1;
+  }
+}
+// -> 0: row = 4 * (lane / 16) + v;  1: row = 4 * v + lane / 16;  -1: neither (or the column is not lane % 16)
+static int mfma64_rowmap(hipStream_t stream) {
+  static int cached = -2;
+  if (cached != -2) return cached;
+  int* d = nullptr;
+  int h[64 * 8];
+  if (hipMalloc(&d, sizeof(h)) != hipSuccess) return -1;
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  (void)hipStreamIsCapturing(stream, &cs);
+  if (cs != hipStreamCaptureStatusNone) { (void)hipFree(d); return -1; }   // (the first call of a process is never inside a capture: warm-ups run eagerly)
+  hipLaunchKernelGGL(mfma64_probe_kernel, dim3(1), dim3(64), 0, stream, d);
+  const bool ok = hipMemcpyAsync(h, d, sizeof(h), hipMemcpyDeviceToHost, stream) == hipSuccess && hipStreamSynchronize(stream) == hipSuccess;
+  (void)hipFree(d);
+  if (!ok) return -1;
+  bool m0 = true, m1 = true, col = true;
+  for (int l = 0; l < 64; ++l)
+    for (int v = 0; v < 4; ++v) {
+      m0 = m0 && h[l * 8 + v] == 4 * (l >> 4) + v;
+      m1 = m1 && h[l * 8 + v] == 4 * v + (l >> 4);
+      col = col && h[l * 8 + 4 + v] == (l & 15);
+    }
+  cached = !col ? -1 : m0 ? 0 : m1 ? 1 : -1;
+  return cached;
+}
+extern "C" int gr_diag_mfma64_rowmap(void) { return mfma64_rowmap(nullptr); }
+
 template <int BM, int BN>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__ A, const float* __restrict__ W,
                                                        float* __restrict__ C, const float* __restrict__ bias,
                                                        const float* __restrict__ resid, int M, int N, int K, long lda,
-                                                       long ldw, long ldc, int act) {
+                                                       long ldw, long ldc, int act, int rowmap) {
   constexpr int TM = BM / 32, TN = BN / 32;         // 16x16 MFMA tiles per wave in m / n
   constexpr int NA = BM * 4 / 256, NW = BN * 4 / 256;  // 16-B chunks staged per thread and step
   __shared__ __attribute__((aligned(16))) float as[2][BM * FBK];
@@ -111,52 +154,30 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j)  // swapped operands: MFMA rows = n, columns = m (a lane gets 4 consecutive n)
-          acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(wd[j], ad[i], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < TN; ++j)  // MFMA rows = m, columns = n: the 16 lanes of a row group store 16 consecutive n
+          acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(ad[i], wd[j], acc[i][j], 0, 0, 0);
     }
     // the next iteration writes the other buffer; the barrier at its top orders those writes after these reads
   }
-  const bool vec = (ldc & 3) == 0 && (N & 3) == 0 && (((uintptr_t)C) & 15) == 0 && (!resid || (((uintptr_t)resid) & 15) == 0) &&
-                   (!bias || (((uintptr_t)bias) & 15) == 0);
+  // epilogue: element v of lane (fr, fk) is output row rowmap(v, fk) of the 16 x 16 tile, column fr; bias, activation and residual
+  // in float64 too -- one rounding, at the store
 #pragma unroll
-  for (int i = 0; i < TM; ++i) {
-    const int m = m0 + wm * (BM / 2) + i * 16 + fr;
-    if (m >= M) continue;
+  for (int i = 0; i < TM; ++i)
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
-      const int n = n0 + wn * (BN / 2) + j * 16 + fk * 4;
+      const int n = n0 + wn * (BN / 2) + j * 16 + fr;
       if (n >= N) continue;
-      f64x4 v = acc[i][j];   // bias, activation and residual in float64 too: one rounding, at the store
-      if (vec) {
-        if (bias) {
-          const f32x4 b = *(const f32x4*)(bias + n);
+      const double b = bias ? (double)bias[n] : 0.;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] += (double)b[e];
-        }
-        if (act == 2) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = v[e] > 0. ? v[e] : 0.;
-        }
-        if (resid) {
-          const f32x4 r = *(const f32x4*)(resid + (long)m * ldc + n);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] += (double)r[e];
-        }
-        *(f32x4*)(C + (long)m * ldc + n) = (f32x4){(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
-      } else {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          if (n + e < N) {
-            double x = v[e];
-            if (bias) x += (double)bias[n + e];
-            if (act == 2) x = x > 0. ? x : 0.;
-            if (resid) x += (double)resid[(long)m * ldc + n + e];
-            C[(long)m * ldc + n + e] = (float)x;
-          }
-        }
+      for (int v = 0; v < 4; ++v) {
+        const int m = m0 + wm * (BM / 2) + i * 16 + (rowmap ? 4 * v + fk : 4 * fk + v);
+        if (m >= M) continue;
+        double x = acc[i][j][v] + b;
+        if (act == 2) x = x > 0. ? x : 0.;
+        if (resid) x += (double)resid[(long)m * ldc + n];
+        C[(long)m * ldc + n] = (float)x;
       }
     }
-  }
 }
 
 extern "C" int gr_gemm_f32(const float* A, const float* W, float* C, const float* bias, const float* resid, int M, int N,
@@ -164,13 +185,15 @@ extern "C" int gr_gemm_f32(const float* A, const float* W, float* C, const float
   if (!A || !W || !C || M <= 0 || N <= 0 || K <= 0 || K % FBK != 0) return GR_EINVAL;
   if (lda % 4 != 0 || ldw % 4 != 0) return GR_EINVAL;
   if ((((uintptr_t)A) & 15) != 0 || (((uintptr_t)W) & 15) != 0) return GR_EINVAL;
+  const int rowmap = mfma64_rowmap(stream);
+  if (rowmap < 0) return GR_EINVAL;
   const long big = (long)gr_cdiv(M, 128) * gr_cdiv(N, 128);
   if (big >= 128 && N >= 96) {
     dim3 grid(gr_cdiv(N, 128), gr_cdiv(M, 128));
-    hipLaunchKernelGGL((gemm_f32_kernel<128, 128>), grid, dim3(256), 0, stream, A, W, C, bias, resid, M, N, K, lda, ldw, ldc, act);
+    hipLaunchKernelGGL((gemm_f32_kernel<128, 128>), grid, dim3(256), 0, stream, A, W, C, bias, resid, M, N, K, lda, ldw, ldc, act, rowmap);
   } else {
     dim3 grid(gr_cdiv(N, 64), gr_cdiv(M, 64));
-    hipLaunchKernelGGL((gemm_f32_kernel<64, 64>), grid, dim3(256), 0, stream, A, W, C, bias, resid, M, N, K, lda, ldw, ldc, act);
+    hipLaunchKernelGGL((gemm_f32_kernel<64, 64>), grid, dim3(256), 0, stream, A, W, C, bias, resid, M, N, K, lda, ldw, ldc, act, rowmap);
   }
   GR_CHECK_LAUNCH();
   return GR_OK;

@@ -20,6 +20,7 @@ H16 = ops.H16  # dtype of the active 16-bit operand type (bf16 / fp16: ops.preci
 
 Q_IN_PLACE = True  # prefill attention reads q (and applies RoPE) straight from the fused QKV projection
 FUSED_DECODE = True  # a decode step of <= 8 rows runs on the fused weight streams (False: the general kernels -- tests compare the two)
+WIDE_DECODE = True   # a decode step of 9..64 rows runs on the matrix-unit weight stream (csrc/gemm_skinny.hip); False: the general kernels
 
 
 def _ru(x, m):
@@ -682,8 +683,11 @@ class LlamaEngine:
         if FUSED_DECODE and L == 1 and M <= 8 and fits8 and T <= 8192 and cache.smax <= 8192 and ops.SP() == 1 and states is None \
                 and self.prec is None:
             return self._decode_forward(h, bs, cache, kv_len, pos_dev, pos_stride, past)
-        # A decode step that does not fit the weight-streaming path (more than 8 rows, pair operands, > 8192 keys) runs the
-        # general kernels below.  Its scratch may be baked into GreedyDecoder's captured hipGraph, so -- like _decode_forward --
+        if WIDE_DECODE and L == 1 and 8 < M <= 64 and not w["fp8"] and ops.SP() == 1 and self.prec is None and states is None \
+                and T % 32 == 0 and self.I % 32 == 0 and cache.smax <= 8192:
+            return self._decode_forward_wide(h, bs, cache, kv_len, pos_dev, pos_stride, past)
+        # A decode step that does not fit the weight-streaming paths (more than 64 rows, pair operands, e4m3 beyond 8 rows, > 8192 keys)
+        # runs the general kernels below.  Its scratch may be baked into GreedyDecoder's captured hipGraph, so -- like _decode_forward --
         # it uses dedicated never-moved tensors (a later, larger prefill regrows the shared arenas and would free memory the
         # graph still addresses) and leaves its logits in the same `dec_logits` buffer the sampler reads.
         dec = dyn or L == 1
@@ -809,6 +813,36 @@ class LlamaEngine:
         """the padded f32 [bs, Vpad] buffer every single-position step (either path) leaves its logits in: a dedicated tensor,
         so a captured decode graph and its sampler keep addressing the same memory"""
         return self.ws.get("dec_logits", (bs, self.Vpad), F32, exact=True)
+
+    def _decode_forward_wide(self, h, bs, cache, kv_len, pos_dev, pos_stride, past):
+        """One new position per row for 9..64 rows (round 6: continuous batching past the 8-row streams).  Every weight matrix is
+        still read ONCE per step -- csrc/gemm_skinny.hip puts the weights through the matrix unit against up to 64 batch rows -- so a
+        step costs about what an 8-row step does and the tokens per second scale with the rows.  7 launches per layer: RMSNorm, QKV,
+        RoPE + cache write, single-query attention, o-proj (+ residual), RMSNorm, gate/up (+ SwiGLU), down (+ residual); the norms are
+        kernels of their own here (a 64-row operand no longer fits a workgroup's prologue).  Never-moved buffers: the step is captured."""
+        w, ws, T, H, hd = self.w, self.ws, self.T, self.H, self.hd
+        dyn = pos_dev is not None
+        x = ws.get("decw_x", (bs, T), H16(), exact=True)
+        qkv = ws.get("decw_qkv", (bs, 3 * T), H16(), exact=True)
+        q = ws.get("decw_q", (bs, H, 1, hd), H16(), exact=True)
+        ctx = ws.get("decw_ctx", (bs, T), H16(), exact=True)
+        y = ws.get("decw_y", (bs, self.I), H16(), exact=True)
+        for i, Lw in enumerate(w["layers"]):
+            ops.rmsnorm(h, Lw["n1"], self.eps, out=x)
+            ops.gemm(x, Lw["wqkv"][0], out=qkv, tile=3)
+            ops.qkv_split(qkv, q, cache.k[i], cache.vt[i], B=bs, H=H, L=1, hd=hd, pos0=past, cos=w["cos"], sin=w["sin"],
+                          pos_dev=pos_dev, pos_stride=pos_stride)
+            ops.decode_attention(q, cache.k[i], cache.vt[i], ctx, Smax=cache.smax if dyn else past + 1, q_pos0=past, kv_len=kv_len,
+                                 pos_dev=pos_dev, pos_stride=pos_stride, nsplit=1)
+            ops.gemm(ctx, Lw["wo"][0], resid=h, out=h, out_f32=True, tile=3)
+            ops.rmsnorm(h, Lw["n2"], self.eps, out=x)
+            ops.gemm(x, Lw["wgu"][0], act=3, out=y, tile=3)
+            ops.gemm(y, Lw["wd"][0], resid=h, out=h, out_f32=True, tile=3)
+        if not dyn:
+            cache.seq_len = past + 1
+        hn = ops.rmsnorm(h, w["norm"], self.eps, out=x)
+        logits = ops.gemm(hn, w["head"], out_f32=True, out=self.decode_logits(bs), tile=3)
+        return logits.view(bs, 1, self.Vpad)[:, :, : self.V], hn
 
     def _decode_forward(self, h, bs, cache, kv_len, pos_dev, pos_stride, past):
         """One new position per row: 5 launches per layer.  Every weight matrix is ONE streaming kernel whose

@@ -87,6 +87,9 @@ typedef struct gr_gemm_desc {
                          kernel (M <= 8; requires splits == ceil(K/512) and ws); 2 = the same kernel but
                          the split-K partials are LEFT in ws [splits, M, N] f32 for the caller
                          (round 1-3's decode step; the step now runs on gr_gemv_fused): C and the epilogue fields are unused;
+                         3 = the weight stream on the matrix unit for decode steps of 9..64 rows (round 6, csrc/gemm_skinny.hip:
+                         M <= 64, K % 32 == 0, plain row-major A, no split / conv / row remap / scale; epilogues bias, act 0-3,
+                         f32 or 16-bit out, fp32 residual; a row's result is independent of M; GR_EINVAL in the operand-pair build);
                          any other value: GR_EINVAL */
   /* OCP fp8 (e4m3) operands (BASELINE configs[4]): A, W are 1-byte elements, K % 128 == 0 (conv gather: conv_C % 128 == 0);
    * the result is dequantised as acc * a_scale[m] * w_scale[n] before the rest of the epilogue */

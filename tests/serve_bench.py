@@ -1,19 +1,30 @@
 """Continuous batching throughput on Groma-7B (random init): R requests x T new tokens through max_rows slots.
-   python tests/serve_bench.py [--fp8]   (e4m3 weights + activations: the batcher on the e4m3 decode streams)"""
-import sys, time, torch
-sys.path.insert(0, '/root/repo')
+   python tests/serve_bench.py [--fp8] [--rows 4,8,16,32] [--precision bf16] [--requests N]
+   (--fp8: e4m3 weights + activations, the batcher on the e4m3 decode streams, <= 8 rows;
+    rows > 8: the matrix-unit weight stream, csrc/gemm_skinny.hip -- round 6)"""
+import os, sys, time, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from groma_amd import config, constants, synth
 from groma_amd.groma import GromaModel
 from groma_amd.serving import ContinuousBatcher
+
+
+def arg(name, default):
+    return sys.argv[sys.argv.index(name) + 1] if name in sys.argv else default
+
+
 cfg = config.groma_7b(box_score_thres=0.0)
 FP8 = '--fp8' in sys.argv
-m = GromaModel.from_synthetic(cfg, seed=0, device='cuda', fp8=FP8)
+prec = arg('--precision', 'bf16')
+m = GromaModel.from_synthetic(cfg, seed=0, device='cuda', fp8=FP8, precision=prec)
 m.init_special_token_id(constants.SyntheticTokenizer())
 m.generation_config.eos_token_id = None
-R, T = 16, 32
-images, ids = synth.make_inputs(cfg, m, R, seed=5)
-images = images.cuda()
-for rows in (4, 8):
+T = 32
+rows_list = [int(x) for x in arg('--rows', '4,8' if FP8 else '4,8,16,32').split(',')]
+for rows in rows_list:
+    R = int(arg('--requests', max(16, 2 * rows)))   # two admission waves per slot
+    images, ids = synth.make_inputs(cfg, m, R, seed=5)
+    images = images.cuda()
     b = ContinuousBatcher(m, max_rows=rows, max_len=1024)
     b.step()  # capture
     for rep in range(2):
@@ -22,5 +33,14 @@ for rows in (4, 8):
             b.submit(ids[i], images[i], max_new_tokens=T, seed=i)
         res = b.run_until_done()
         torch.cuda.synchronize(); dt = time.perf_counter() - t
+        steps = b.steps
         for rid in list(res): b.result(rid)
-    print(("e4m3 " if FP8 else "") + f"max_rows={rows}: {R} requests x {T} tokens in {dt*1e3:.0f} ms -> {R/dt:.1f} img/s, {R*T/dt:.0f} tok/s, {b.steps} decode steps total", flush=True)
+    # one decode tick alone (all rows occupied is not needed: idle rows decode too)
+    torch.cuda.synchronize(); t = time.perf_counter()
+    for _ in range(20):
+        b.graph.replay()
+    torch.cuda.synchronize(); tick = (time.perf_counter() - t) / 20
+    print(("e4m3 " if FP8 else "") + f"{m.mode} max_rows={rows}: {R} requests x {T} tokens in {dt*1e3:.0f} ms -> {R/dt:.1f} img/s, {R*T/dt:.0f} tok/s, "
+          f"{steps} decode steps total; one decode tick {tick*1e3:.2f} ms = {rows/tick:.0f} tok/s at full occupancy", flush=True)
+    del b
+    torch.cuda.empty_cache()
