@@ -22,53 +22,65 @@
 // (the W ring has 3 slots, the x ring 2) and its steady state carries no guard.
 #include "gemm_common.h"
 
-#define SK_RW 64    // rows of W per workgroup
 #define SK_KS 256   // k-values per slice (512 B per row)
 
-template <int NB>  // 16-row blocks of x: M <= 16 NB
+// NB: 16-row blocks of x (M <= 16 NB).  KW: K-ways -- the four waves of a workgroup are 4 / KW row blocks x KW slices of the same
+// iteration, so a workgroup owns 64 / KW rows of W and a launch has N KW / 64 workgroups: the N = 4096 matrices (o-proj, down-proj)
+// would otherwise stream through 64 of the 256 CUs.  The KW partial sums of a row block meet in LDS in a fixed order.
+template <int NB, int KW>
 __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmArgs p) {
-  constexpr int XI = NB * 2;            // 16-B chunks of an x slice per thread (16 NB rows x 32 chunks / 256 threads)
-  constexpr int XBYTES = NB * 16 * 512;
-  extern __shared__ __attribute__((aligned(16))) char smem[];  // 2 x-slice images
+  // Ring depths.  Three W slices (24 KB) in flight per wave; six were measured and are SLOWER on every shape (QKV at 16 rows 27.5 -> 31.2
+  // us, gate/up 49.7 -> 54.1: profiles/r06_skinny_bench.txt -- the stream is not waiting for its own loads; 248 instead of 160 registers
+  // only cost occupancy).  The x register ring shrinks to one stage when a stage is large (x comes from L2, one iteration of lead is enough).
+  constexpr int WD = 3;                      // W slices in flight per wave
+  constexpr int XD = NB * KW > 4 ? 1 : 2;    // x stages held in registers
+  constexpr int XA = XD + 1;                 // ... so x loads run XA iterations ahead
+  constexpr int AHEAD = WD > XA ? WD : XA;
+  constexpr int RBW = 4 / KW;                // row blocks (waves along N) per workgroup
+  constexpr int XI = NB * 2 * KW;            // 16-B chunks of an x stage per thread (16 NB rows x 32 KW chunks / 256 threads)
+  constexpr int XROW = 512 * KW;             // bytes per staged x row
+  constexpr int XBYTES = NB * 16 * XROW;
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // 2 x stages (re-used by the KW reduction)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int rb = wave % RBW, kh = wave / RBW;
   const int fr = lane & 15, fg = lane >> 4;
-  const int n0 = blockIdx.x * SK_RW;
-  const int ns = (p.K + SK_KS - 1) / SK_KS;   // K % 32 == 0; a last partial slice multiplies zeros (its W loads re-read k = 0)
+  const int n0 = blockIdx.x * (16 * RBW);
+  const int nit = (p.K + SK_KS * KW - 1) / (SK_KS * KW);   // K % 32 == 0; slices past K multiply zeros (their W loads re-read k = 0)
 
-  int wr = n0 + 16 * wave + fr;
+  int wr = n0 + 16 * rb + fr;
   if (wr > p.N - 1) wr = p.N - 1;
-  const bf16_t* wrow = p.W + (long)wr * p.ldw + fg * 8;
+  const bf16_t* wrow = p.W + (long)wr * p.ldw + fg * 8 + kh * SK_KS;
   const bf16_t* xsrc[XI];
-  int xdst[XI];
+  int xdst[XI], xk[XI];
 #pragma unroll
   for (int i = 0; i < XI; ++i) {
-    const int s = i * 256 + tid, row = s >> 5, cpos = s & 31;
+    const int s = i * 256 + tid, row = s / (32 * KW), cpos = s % (32 * KW);
     int m = row;
     if (m > p.M - 1) m = p.M - 1;
-    xsrc[i] = p.A + (long)m * p.lda + ((cpos ^ (row & 15)) << 3);   // slot (row, cpos) holds logical chunk cpos ^ (row & 15)
+    xk[i] = (cpos ^ (row & 15)) << 3;                              // slot (row, cpos) holds logical chunk cpos ^ (row & 15)
+    xsrc[i] = p.A + (long)m * p.lda + xk[i];
     xdst[i] = s << 4;
   }
-  bf16x8 w[3][8], xr[2][XI];
+  bf16x8 w[WD][8], xr[XD][XI];
   f32x4 acc[NB];
 #pragma unroll
   for (int nb = 0; nb < NB; ++nb) acc[nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  // EDGE: the slice may be the last, partial one -- k-blocks / chunks at or beyond K read k = 0 of the row (finite) against x = 0
-  auto load_w = [&](int s, bf16x8* dst, bool edge) {
+  // EDGE: the iteration may reach past K -- k-blocks / chunks at or beyond K read k = 0 of the row (finite) against x = 0
+  auto load_w = [&](int t, bf16x8* dst, bool edge) {
 #pragma unroll
     for (int kb = 0; kb < 8; ++kb) {
-      long k = (long)s * SK_KS + kb * 32;
-      if (edge && k >= p.K) k = 0;
+      long k = (long)t * (SK_KS * KW) + kb * 32;
+      if (edge && k + kh * SK_KS >= p.K) k = -(long)kh * SK_KS;
       dst[kb] = __builtin_nontemporal_load((const bf16x8*)(wrow + k));
     }
   };
-  auto load_x = [&](int s, bf16x8* dst, bool edge) {
+  auto load_x = [&](int t, bf16x8* dst, bool edge) {
 #pragma unroll
     for (int i = 0; i < XI; ++i) {
-      const int cpos = (i * 256 + tid) & 31, row = (i * 256 + tid) >> 5;
-      const bool in = !edge || s * SK_KS + ((cpos ^ (row & 15)) << 3) < p.K;
-      dst[i] = in ? *(const bf16x8*)(xsrc[i] + (long)s * SK_KS) : (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+      const bool in = !edge || t * (SK_KS * KW) + xk[i] < p.K;
+      dst[i] = in ? *(const bf16x8*)(xsrc[i] + (long)t * (SK_KS * KW)) : (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
     }
   };
   auto put_x = [&](const bf16x8* src, int buf) {
@@ -82,46 +94,62 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmArgs p) {
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb) {
         const int row = nb * 16 + fr;
-        const bf16x8 xv = *(const bf16x8*)(xb + row * 512 + (((kb * 4 + fg) ^ fr) << 4));
+        const bf16x8 xv = *(const bf16x8*)(xb + row * XROW + (((kh * 32 + kb * 4 + fg) ^ fr) << 4));
         acc[nb] = GR_MFMA_16x16x32(wv[kb], xv, acc[nb]);
       }
   };
-  // slice s: W in w[s % 3], x in LDS image s % 2; x of s + 1, s + 2 in xr[(s + 1) % 2], xr[s % 2]
-  load_w(0, w[0], true);
-  if (ns > 1) load_w(1, w[1], true);
-  if (ns > 2) load_w(2, w[2], true);
+  // iteration t: W in w[t % WD], x in LDS stage t % 2; x of t + 1 (.. t + XD) in the register ring
+#pragma unroll
+  for (int d = 0; d < WD; ++d)
+    if (d < nit) load_w(d, w[d], true);
   load_x(0, xr[0], true);
-  if (ns > 1) load_x(1, xr[1], true);
+  if (XD == 2 && nit > 1) load_x(1, xr[XD - 1], true);
   put_x(xr[0], 0);
-  if (ns > 2) load_x(2, xr[0], true);
+  if (nit > XD) load_x(XD, xr[0], true);
   __syncthreads();
-  // one iteration: multiply slice s, refill its W slot with slice s + 3, publish x of s + 1 and refill that register slot with s + 3
-#define SK_ITER(S, D, GUARD)                                            \
-  {                                                                     \
-    const int s_ = (S);                                                 \
-    compute(w[(D) % 3], (D) & 1);                                       \
-    if (!(GUARD) || s_ + 3 < ns) load_w(s_ + 3, w[(D) % 3], GUARD);     \
-    if (!(GUARD) || s_ + 1 < ns) put_x(xr[((D) + 1) & 1], ((D) + 1) & 1); \
-    if (!(GUARD) || s_ + 3 < ns) load_x(s_ + 3, xr[((D) + 1) & 1], GUARD); \
-    __syncthreads();                                                    \
+  // one iteration: multiply, refill the W slot with iteration t + WD, publish x of t + 1 and refill that register stage with t + XA
+#define SK_XS(D) (XD == 2 ? (((D) + 1) & 1) : 0)
+#define SK_ITER(S, D, GUARD)                                                \
+  {                                                                         \
+    const int s_ = (S);                                                     \
+    compute(w[(D) % WD], (D) & 1);                                          \
+    if (!(GUARD) || s_ + WD < nit) load_w(s_ + WD, w[(D) % WD], GUARD);     \
+    if (!(GUARD) || s_ + 1 < nit) put_x(xr[SK_XS(D)], ((D) + 1) & 1);       \
+    if (!(GUARD) || s_ + XA < nit) load_x(s_ + XA, xr[SK_XS(D)], GUARD);    \
+    __syncthreads();                                                        \
   }
   int s = 0;
-  for (; s + 6 + 3 < ns; s += 6) {    // steady state: every slice touched below exists and is whole
+  for (; s + 6 + AHEAD < nit; s += 6) {   // steady state: every iteration touched below exists and is whole
     SK_ITER(s, 0, false) SK_ITER(s + 1, 1, false) SK_ITER(s + 2, 2, false)
     SK_ITER(s + 3, 3, false) SK_ITER(s + 4, 4, false) SK_ITER(s + 5, 5, false)
   }
-  for (; s < ns; s += 6) {            // the last rounds, guarded
+  for (; s < nit; s += 6) {               // the last rounds, guarded
     SK_ITER(s, 0, true)
-    if (s + 1 < ns) SK_ITER(s + 1, 1, true)
-    if (s + 2 < ns) SK_ITER(s + 2, 2, true)
-    if (s + 3 < ns) SK_ITER(s + 3, 3, true)
-    if (s + 4 < ns) SK_ITER(s + 4, 4, true)
-    if (s + 5 < ns) SK_ITER(s + 5, 5, true)
+    if (s + 1 < nit) SK_ITER(s + 1, 1, true)
+    if (s + 2 < nit) SK_ITER(s + 2, 2, true)
+    if (s + 3 < nit) SK_ITER(s + 3, 3, true)
+    if (s + 4 < nit) SK_ITER(s + 4, 4, true)
+    if (s + 5 < nit) SK_ITER(s + 5, 5, true)
   }
+#undef SK_XS
 #undef SK_ITER
 
-  // ---- epilogue: lane (fr, fg) holds y[m = 16 nb + fr][n = n0 + 16 wave + 4 fg .. + 3]
-  const int n = n0 + 16 * wave + 4 * fg;
+  if (KW > 1) {   // the K-ways of a row block: partial sums through LDS (the x stages are free), added in the fixed order kh = 1, 2, 3
+    f32x4* red = (f32x4*)smem;   // [KW - 1][RBW][NB][64]
+    if (kh > 0) {
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) red[(((kh - 1) * RBW + rb) * NB + nb) * 64 + lane] = acc[nb];
+    }
+    __syncthreads();
+    if (kh > 0) return;
+#pragma unroll
+    for (int j = 1; j < KW; ++j)
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) acc[nb] += red[(((j - 1) * RBW + rb) * NB + nb) * 64 + lane];
+  }
+
+  // ---- epilogue: lane (fr, fg) holds y[m = 16 nb + fr][n = n0 + 16 rb + 4 fg .. + 3]
+  const int n = n0 + 16 * rb + 4 * fg;
   if (n >= p.N) return;
   f32x4 bias = {0.f, 0.f, 0.f, 0.f};
   if (p.bias) bias = *(const f32x4*)(p.bias + n);
@@ -146,6 +174,25 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmArgs p) {
   }
 }
 
+static int g_skinny_kw = 0;   // 0: chosen per launch; 1 / 2 / 4: forced (tests/diag/skinny_bench.py)
+extern "C" int gr_diag_skinny_kw(int kw) {
+  if (kw != 0 && kw != 1 && kw != 2 && kw != 4) return GR_EINVAL;
+  g_skinny_kw = kw;
+  return GR_OK;
+}
+
+template <int NB, int KW>
+static int launch_skinny(const GemmArgs& p, hipStream_t stream) {
+  const size_t lds = 2 * (size_t)NB * 16 * 512 * KW;
+  static bool attr_set = false;
+  if (!attr_set && lds > 65536) {
+    if (hipFuncSetAttribute((const void*)gemm_skinny_kernel<NB, KW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return GR_EINVAL;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((gemm_skinny_kernel<NB, KW>), dim3(gr_cdiv(p.N, 64 / KW)), dim3(256), lds, stream, p);
+  return GR_OK;
+}
+
 int gr_launch_gemm_skinny(const GemmArgs& p, hipStream_t stream) {
   if (GR_SP) return GR_EINVAL;   // (operand pairs: the general kernels)
   if (p.M < 1 || p.M > 64 || p.K % 32 != 0 || p.N % 4 != 0 || p.lda % 8 != 0 || p.ldw % 8 != 0) return GR_EINVAL;
@@ -153,9 +200,15 @@ int gr_launch_gemm_skinny(const GemmArgs& p, hipStream_t stream) {
   if (p.act == 3 && (p.resid || p.out_f32 || (p.N & 7))) return GR_EINVAL;
   if ((((uintptr_t)p.A) | ((uintptr_t)p.W)) & 15) return GR_EINVAL;
   const int nb = (p.M + 15) / 16;
-  const dim3 grid(gr_cdiv(p.N, SK_RW));
-  if (nb <= 1) hipLaunchKernelGGL(gemm_skinny_kernel<1>, grid, dim3(256), 2 * 1 * 16 * 512, stream, p);
-  else if (nb == 2) hipLaunchKernelGGL(gemm_skinny_kernel<2>, grid, dim3(256), 2 * 2 * 16 * 512, stream, p);
-  else hipLaunchKernelGGL(gemm_skinny_kernel<4>, grid, dim3(256), 2 * 4 * 16 * 512, stream, p);
-  return GR_OK;
+  // K-ways: the N = 4096 matrices (o-proj, down-proj) are 64 workgroups at KW = 1 and measured 1.2-1.4 TB/s there against 2.7-3.3 at
+  // KW = 4; from N = 8192 up KW = 1 already fills the chip and the extra x traffic of KW > 1 costs (profiles/r06_skinny_bench.txt).
+  // A function of the layer shape and of the row-block count only -- i.e. of the batcher's row CAPACITY (a decode step always runs all
+  // its rows), never of which rows are occupied: a request's sums do not depend on its company.
+  const int nbt = nb <= 1 ? 1 : nb == 2 ? 2 : 4;
+  int kw = g_skinny_kw ? g_skinny_kw : (p.N >= 8192 ? 1 : 4);
+  if (nbt == 4 && kw > 2) kw = 2;   // (64 rows x 4 K-ways: the x stage alone would need 128 registers)
+  while (kw > 1 && p.K < SK_KS * kw * 2) kw >>= 1;
+  if (nbt == 1) return kw == 1 ? launch_skinny<1, 1>(p, stream) : kw == 2 ? launch_skinny<1, 2>(p, stream) : launch_skinny<1, 4>(p, stream);
+  if (nbt == 2) return kw == 1 ? launch_skinny<2, 1>(p, stream) : kw == 2 ? launch_skinny<2, 2>(p, stream) : launch_skinny<2, 4>(p, stream);
+  return kw == 1 ? launch_skinny<4, 1>(p, stream) : launch_skinny<4, 2>(p, stream);
 }
