@@ -523,7 +523,7 @@ def extras_block(model, cfg, args, dev, P):
     return ex
 
 
-def parity_block(precision, fp8, images, ids, seed, n_images=2):
+def parity_block(precision, fp8, images, ids, seed, n_images=4):
     """The benchmarked MODE checked against the oracle on the bench's OWN inputs: the first `n_images` images /
     prompts of the timed batch and the CPU-RNG seed of its first timed step, through a model of Groma-7B WIDTH at reduced depth
     (config.groma_7b_width: every GEMM / conv / attention shape of the benchmark, 3 ViT layers, 6+6 DDETR, 1 fusion round, 1 LLaMA
@@ -578,18 +578,32 @@ def parity_block(precision, fp8, images, ids, seed, n_images=2):
     same = aux["input_ids"].shape == ref["input_ids"].shape
     lg_d, lg_o = out.logits.float().cpu(), ref["logits"]
     rel = lambda a, b: ((a - b).norm() / b.norm()).item()
+    ids_row_eq = [bool(same and torch.equal(aux["input_ids"][i], ref["input_ids"][i])) for i in range(n)]
+    for i, pi in enumerate(per):
+        pi["spliced_ids_equal"] = ids_row_eq[i]
+        pi["all_index_results_equal"] = bool(pi["top300_ids_equal"] and pi["nms_ids_equal"] and pi["selection_equal"] and ids_row_eq[i])
+        pi["logits_rel_l2"] = rel(lg_d[i], lg_o[i]) if same else None
+    eq = [i for i, pi in enumerate(per) if pi["all_index_results_equal"]]
+    tol = PARITY_TOL.get(m.mode.split("+")[0] + ("+e4m3" if fp8 else ""), None)
     res = {"mode": m.mode, "inputs": f"images / prompts 0..{n - 1} of the timed batch (seed 1234 + rank), CPU-RNG seed {seed} (the first timed step's)",
            "model": "Groma-7B width at reduced depth (3 ViT / 6+6 DDETR / 1 fusion round / 1 LLaMA layer), random-init seed 0",
            "oracle": "fp32 CPU restatement running its own fp32 ViT (unchained)",
            "images": per,
+           "n_images": n, "images_with_all_index_results_equal": len(eq),
+           # an image whose oracle ranking hangs on a gap below the fp32 evaluation error of either implementation (resolves = false) may
+           # order that pair differently; its selected regions then differ and its logits are not comparable position by position
+           "near_tie_images": [i for i, pi in enumerate(per) if not pi["all_index_results_equal"] and not pi["resolves"]],
+           "unexplained_images": [i for i, pi in enumerate(per) if not pi["all_index_results_equal"] and (pi["resolves"] or not pi["valid_ranking_within_2err"])],
            "spliced_ids_equal": bool(same and torch.equal(aux["input_ids"], ref["input_ids"])),
            "vit_states_rel_l2": max(rel(h.float().cpu(), r) for h, r in zip(aux["hidden4"], ref["hidden_states"][-4:])),
-           "logits_rel_l2": rel(lg_d, lg_o) if same else None,
-           "logits_rel_l2_per_image": [rel(lg_d[i], lg_o[i]) for i in range(n)] if same else None,
-           "argmax_agree": (lg_d.argmax(-1) == lg_o.argmax(-1)).float().mean().item() if same else None,
-           "logits_tolerance": PARITY_TOL.get(m.mode.split("+")[0] + ("+e4m3" if fp8 else ""), None),
+           "logits_rel_l2": (rel(lg_d[eq], lg_o[eq]) if (same and eq) else None),
+           "logits_rel_l2_note": "over the images whose index-valued results equal the oracle's (the others are near-ties: see images[].resolves)",
+           "logits_rel_l2_all_images": rel(lg_d, lg_o) if same else None,
+           "argmax_agree": ((lg_d[eq].argmax(-1) == lg_o[eq].argmax(-1)).float().mean().item() if (same and eq) else None),
+           "logits_tolerance": tol,
            "seconds": round(time.time() - t0, 1)}
-    res["all_index_results_equal"] = bool(res["spliced_ids_equal"] and all(p["top300_ids_equal"] and p["nms_ids_equal"] and p["selection_equal"] for p in per))
+    res["all_index_results_equal"] = len(eq) == n
+    res["within_tolerance"] = bool(res["logits_rel_l2"] is not None and tol is not None and res["logits_rel_l2"] <= tol and not res["unexplained_images"])
     del m, out
     torch.cuda.empty_cache()
     return res
@@ -876,7 +890,7 @@ def main():
             try:   # the benchmarked MODE against the oracle on the bench's own inputs (reduced depth; see parity_block)
                 from groma_amd import synth as _synth
                 p_im, p_ids = _synth.make_inputs(cfg, model, job.rows, seed=1234 + rank, prompt_len=P)   # exactly what measure() timed
-                out["parity"] = parity_block(model.mode.replace("+e4m3", ""), fp8, p_im[:2].to(dev), p_ids[:2].to(dev), seed=1000 + args.warmup)
+                out["parity"] = parity_block(model.mode.replace("+e4m3", ""), fp8, p_im[:4].to(dev), p_ids[:4].to(dev), seed=1000 + args.warmup)
             except Exception as e:
                 out["parity"] = {"error": f"{type(e).__name__}: {e}"}
         if world == 1 and not args.no_cpu_baseline and not gen:
@@ -892,7 +906,8 @@ def main():
                                    # BASELINE configs[2]'s nominal dtype, unconditionally beside the headline (images/s)
                                    "bf16_operands_images_per_s": {"hybrid (pair ViT + bf16, round 5's headline)": round(exs.get("forward_hybrid_bf16", {}).get("value", 0.0), 2) or None,
                                                                   "bf16 in every stage (rounds 1-4's headline)": round(exs.get("forward_bf16_vit", {}).get("value", 0.0), 2) or None},
-                                   "parity": {k: out.get("parity", {}).get(k) for k in ("all_index_results_equal", "logits_rel_l2", "logits_tolerance")},
+                                   "parity": {k: out.get("parity", {}).get(k) for k in ("n_images", "images_with_all_index_results_equal", "near_tie_images", "unexplained_images",
+                                                                                        "logits_rel_l2", "logits_tolerance", "within_tolerance")},
                                    "extras [images/s, roofline frac]": out["extras_summary"]}
         print(json.dumps(out), flush=True)
     if use_dist:

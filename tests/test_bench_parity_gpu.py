@@ -27,9 +27,9 @@ def test_parity_block_of_the_benchmarked_modes_on_the_bench_inputs(dev, precisio
     bench = _bench()
     cfg = gconfig.groma_7b(box_score_thres=0.0)
     images, ids = synth.make_inputs(cfg, util.TokenIds(), 14, seed=1234, prompt_len=128)      # bench.measure(): rank 0, 14 images
-    r = bench.parity_block(precision, False, images[:2].to(dev), ids[:2].to(dev), seed=1000 + 3)   # default --warmup 3
+    r = bench.parity_block(precision, False, images[:4].to(dev), ids[:4].to(dev), seed=1000 + 5)   # the driver's --warmup 5
     print(r)
-    assert r["mode"] == precision and len(r["images"]) == 2
+    assert r["mode"] == precision and r["n_images"] == len(r["images"]) == 4
     assert r["vit_states_rel_l2"] < 1e-5                                   # the pair-operand ViT
     for p in r["images"]:
         assert p["class_logit_err"] < 1e-4
@@ -38,8 +38,10 @@ def test_parity_block_of_the_benchmarked_modes_on_the_bench_inputs(dev, precisio
         if p["resolves"]:
             assert p["top300_ids_equal"]
         if p["top300_ids_equal"] and p["nms_ids_equal"]:
-            assert p["selection_equal"]
-    if r["all_index_results_equal"]:
-        assert r["spliced_ids_equal"] and r["logits_rel_l2"] <= r["logits_tolerance"], r
-        assert r["argmax_agree"] >= 0.9
+            assert p["selection_equal"] and p["spliced_ids_equal"]
+        if p["all_index_results_equal"]:
+            assert p["logits_rel_l2"] <= r["logits_tolerance"], p          # per image: the stated tolerance of the mode
+    assert not r["unexplained_images"], r                                  # a differing image is a near-tie (gap < 2 err), nothing else
+    assert r["images_with_all_index_results_equal"] >= 2                   # (91-93 % of ordinary images: profiles/r06_index_survival.txt)
+    assert r["within_tolerance"] and r["logits_rel_l2"] <= r["logits_tolerance"] and r["argmax_agree"] >= 0.9
     assert r["logits_tolerance"] == {"hybrid": 1.5e-2, "hybrid-fp16": 2e-3}[precision]
