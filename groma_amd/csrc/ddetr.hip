@@ -16,11 +16,13 @@
 // ref    f32 [B*Q or Q, rdim] (rdim 2: loc = ref + off/(W,H); rdim 4: loc = ref_xy + off/P * ref_wh * 0.5)
 // out    f32 [B, Q, heads*32]
 // Work split (round 6): everything that depends on (b, q, head, point) alone -- the soft-max over the head's P points, the sampling
-// location, the four corner taps and their bilinear weights -- is evaluated ONCE by one lane per (group, point) into LDS; the 32
-// channel lanes of a group then only gather (128-B coalesced value rows) and accumulate.  Rounds 1-5 had every channel lane redo
-// the soft-max (4 expf) and the location arithmetic: 32x the transcendental / address work of the kernel for the same 16 gathers.
-// block = MSDA_G groups (b, q, head) x 32 channels.
-#define MSDA_G 8
+// location, the four corner taps and their bilinear weights -- is evaluated ONCE, one thread per (group, point), into LDS; the 32 channel
+// lanes of a group then only gather (128-B coalesced value rows) and accumulate.  Rounds 1-5 had every channel lane redo the soft-max
+// (4 expf) and the location arithmetic: 32x the transcendental / address work for the same 16 gathers.
+// block = 256 threads = MSDA_G (64) groups (b, q, head): phase 1 is one tap per thread (all lanes busy), phase 2 walks the block's groups
+// eight at a time with lane = (group, channel).  (A first cut with 8 groups per block left 7 of 8 lanes idle in phase 1 and measured 2x
+// SLOWER than the redundant form: 329 vs 163 us per encoder launch at 14 images, profiles/r06_timeline_b14.txt.)
+#define MSDA_G 64
 struct MsdaTap {
   int o[4];      // element index (row * Ws + col) of the four corners, -1: outside the map (zero padding)
   float w[4];    // bilinear weights uh*uw, uh*lw, lh*uw, lh*lw
@@ -28,13 +30,14 @@ struct MsdaTap {
   int inside;    // the sample touches the map at all
 };
 template <int P>
-__global__ __launch_bounds__(MSDA_G * 32) void msda_kernel(const float* __restrict__ value, const float* __restrict__ offw,
-                                                           const float* __restrict__ ref, float* __restrict__ out, int B, int Q,
-                                                           int heads, int Hs, int Ws, int ld, int rdim, int ref_batched) {
+__global__ __launch_bounds__(256) void msda_kernel(const float* __restrict__ value, const float* __restrict__ offw,
+                                                   const float* __restrict__ ref, float* __restrict__ out, int B, int Q,
+                                                   int heads, int Hs, int Ws, int ld, int rdim, int ref_batched) {
+  static_assert(MSDA_G * P == 256, "one tap per thread");
   __shared__ MsdaTap taps[MSDA_G][P];
   const long total_g = (long)B * Q * heads;
   const long g0 = (long)blockIdx.x * MSDA_G;
-  if (threadIdx.x < MSDA_G * P) {
+  {
     const int gl = threadIdx.x / P, p = threadIdx.x - gl * P;
     const long g = g0 + gl;
     if (g < total_g) {
@@ -42,7 +45,7 @@ __global__ __launch_bounds__(MSDA_G * 32) void msda_kernel(const float* __restri
       const long bq = g / heads;
       const float* ow = offw + bq * ld;
       const float* rp = ref + (ref_batched ? bq : bq % Q) * rdim;
-      float lg[P], mx = -INFINITY;   // soft-max over the P points of this head (single level), the order torch.softmax's result is compared in
+      float lg[P], mx = -INFINITY;   // soft-max over the P points of this head (single level)
 #pragma unroll
       for (int i = 0; i < P; ++i) {
         lg[i] = ow[heads * P * 2 + h * P + i];
@@ -81,33 +84,36 @@ __global__ __launch_bounds__(MSDA_G * 32) void msda_kernel(const float* __restri
     }
   }
   __syncthreads();
-  const int gl = threadIdx.x >> 5, c = threadIdx.x & 31;
-  const long g = g0 + gl;
-  if (g >= total_g) return;
-  const int h = (int)(g % heads);
-  const long b = g / heads / Q;
-  const float* vb = value + b * Hs * Ws * heads * 32 + h * 32 + c;
+  const int c = threadIdx.x & 31;
   const long vstride = (long)heads * 32;
-  float acc = 0.f;
+#pragma unroll 2
+  for (int gl = threadIdx.x >> 5; gl < MSDA_G; gl += 8) {
+    const long g = g0 + gl;
+    if (g >= total_g) break;
+    const int h = (int)(g % heads);
+    const long b = g / heads / Q;
+    const float* vb = value + b * Hs * Ws * heads * 32 + h * 32 + c;
+    float acc = 0.f;
 #pragma unroll
-  for (int p = 0; p < P; ++p) {
-    const MsdaTap& t = taps[gl][p];   // (one address per half-wave: an LDS broadcast)
-    float val = 0.f;
-    if (t.inside) {
-      const float v1 = t.o[0] >= 0 ? vb[(long)t.o[0] * vstride] : 0.f, v2 = t.o[1] >= 0 ? vb[(long)t.o[1] * vstride] : 0.f;
-      const float v3 = t.o[2] >= 0 ? vb[(long)t.o[2] * vstride] : 0.f, v4 = t.o[3] >= 0 ? vb[(long)t.o[3] * vstride] : 0.f;
-      val = t.w[0] * v1 + t.w[1] * v2 + t.w[2] * v3 + t.w[3] * v4;
+    for (int p = 0; p < P; ++p) {
+      const MsdaTap& t = taps[gl][p];   // (one address per half-wave: an LDS broadcast)
+      float val = 0.f;
+      if (t.inside) {
+        const float v1 = t.o[0] >= 0 ? vb[(long)t.o[0] * vstride] : 0.f, v2 = t.o[1] >= 0 ? vb[(long)t.o[1] * vstride] : 0.f;
+        const float v3 = t.o[2] >= 0 ? vb[(long)t.o[2] * vstride] : 0.f, v4 = t.o[3] >= 0 ? vb[(long)t.o[3] * vstride] : 0.f;
+        val = t.w[0] * v1 + t.w[1] * v2 + t.w[2] * v3 + t.w[3] * v4;
+      }
+      acc += val * t.aw;
     }
-    acc += val * t.aw;
+    out[g * 32 + c] = acc;
   }
-  out[g * 32 + c] = acc;
 }
 
 extern "C" int gr_msda_f32(const float* value, const float* offw, const float* ref, float* out, int B, int Q, int heads,
                            int n_points, int Hs, int Ws, int ld, int rdim, int ref_batched, hipStream_t stream) {
   if (!value || !offw || !ref || !out || n_points != 4 || (rdim != 2 && rdim != 4)) return GR_EINVAL;
   const long groups = (long)B * Q * heads;
-  hipLaunchKernelGGL(msda_kernel<4>, dim3(gr_cdiv(groups, MSDA_G)), dim3(MSDA_G * 32), 0, stream, value, offw, ref, out, B, Q, heads,
+  hipLaunchKernelGGL(msda_kernel<4>, dim3(gr_cdiv(groups, MSDA_G)), dim3(256), 0, stream, value, offw, ref, out, B, Q, heads,
                      Hs, Ws, ld, rdim, ref_batched);
   GR_CHECK_LAUNCH();
   return GR_OK;
