@@ -157,7 +157,7 @@ def run(seed=0, precision="bf16"):
     return res
 
 
-def run_fp8(seed=0):
+def run_fp8(seed=0, oracle=True):
     """BASELINE configs[4] at the real depth: the e4m3 model ("hybrid" + fp8=True: DINOv2 on operand pairs, the
     LLaMA linears, lm_head and the region encoder's 3x3 convs on OCP e4m3 with per-row / static scales) against
       (a) the bf16 device path of the same weights ("hybrid") -- configs[4]'s "logits within stated tol vs bf16",
@@ -185,6 +185,14 @@ def run_fp8(seed=0):
             print(f"device {model.mode}: packed + forward in {time.time() - t:.1f} s")
             del model, o, aux
             torch.cuda.empty_cache()
+        if not oracle:   # the test's form: the two device paths against each other (the oracle passes are profiles/r06_fulldepth_fp8.txt)
+            d8, d16 = outs["e4m3"], outs["bf16"]
+            res = dict(ids_equal=torch.equal(d8["ids"], d16["ids"]), topk_equal=torch.equal(d8["topk"], d16["topk"]), nms_equal=torch.equal(d8["nms"], d16["nms"]),
+                       logits=rel(d8["logits"], d16["logits"]), region_logits=rel(d8["logits"][:, -1, 32014:32114], d16["logits"][:, -1, 32014:32114]),
+                       k31=rel(d8["k31"], d16["k31"]), region_tokens=rel(d8["region"], d16["region"]),
+                       argmax=(d8["logits"].argmax(-1) == d16["logits"].argmax(-1)).float().mean().item())
+            print("e4m3 device <-> bf16 device at full depth:", res)
+            return res
         t = time.time()
         own = O.vit_forward(sd, cd, images)
         ref = {}

@@ -20,7 +20,7 @@ def _bench():
     return mod
 
 
-@pytest.mark.parametrize("precision", ["hybrid", "hybrid-fp16"])
+@pytest.mark.parametrize("precision", ["hybrid-fp16"])   # the benchmarked mode (HEADLINE_DTYPE)
 def test_parity_block_of_the_benchmarked_modes_on_the_bench_inputs(dev, precision):
     from groma_amd import config as gconfig, synth
     from tests import util

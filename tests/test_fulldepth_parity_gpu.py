@@ -6,8 +6,9 @@ most of it the two oracle passes on the host cores.  R: groma/model/groma.py:202
 Asserted: index-valued results identical (top-300 ids, NMS ids, spliced ids); the device is no further from the fp32 oracle
 than 1.5x what the bf16 format itself costs at this depth (bf16-rounded oracle <-> fp32 oracle), stage by stage; the
 bf16-rounded oracle is the closer reference; arg-max identical on every clear-margin position.
-Round 4: the same run with fp16 operands is asserted too, and precision="ref" (operand pairs) is held to north_star's 1e-3 against
-an UNCHAINED fp32 oracle.  Measured numbers: profiles/r04_fulldepth_*.txt."""
+Round 4: precision="ref" (operand pairs) is held to north_star's 1e-3 against an UNCHAINED fp32 oracle.  Round 6: the benchmarked build
+("hybrid-fp16") unchained with its stated tolerance (this replaces round 4's chained all-fp16 run: same format distance, 3.3e-3), and
+configs[4] (e4m3) at the real depth.  Measured numbers: profiles/r04_fulldepth_*.txt, r06_precision_ablation.txt, r06_fulldepth_fp8.txt."""
 import importlib.util
 import os
 
@@ -55,16 +56,6 @@ def test_full_depth_distinct_weights_vs_both_oracles(dev):
     assert d32 <= 1.1 * fmt                            # 32 layers deep: the bf16 format's own distance (2.6e-2), within 10 %
     assert r["argmax_agree_clear"] == 1.0
     assert r["argmax_agree"] >= r["argmax_agree_bf16_oracle"] - 0.05
-
-
-def test_full_depth_fp16_operands(dev):
-    """the fp16 operand build at the real depth (profiles/r03_fulldepth_fp16.txt was a diag print until round 4)"""
-    r = _diag().run(precision="fp16")
-    assert r["topk_equal"] and r["nms_equal"] and r["ids_equal"] and r["L"] == 582
-    _format_gates(r, 1.5)
-    d32, d16, fmt = r["logits"]
-    assert d32 <= 4e-3 and d32 <= 1.1 * fmt            # measured 3.3e-3 = the half format's own distance at this depth
-    assert r["argmax_agree"] >= 0.98 and r["argmax_agree_clear"] == 1.0
 
 
 def test_full_depth_reference_precision_unchained(dev):
@@ -120,14 +111,12 @@ def test_full_depth_benchmarked_build_hybrid_fp16_unchained(dev):
 
 def test_full_depth_fp8(dev):
     """BASELINE configs[4] at the real depth ("logits within stated tol vs bf16"): the e4m3 model ("hybrid" + fp8=True) against the bf16
-    device path of the same weights and against both oracles.  The stated tolerance is the e4m3 FORMAT's own distance at this depth (the
-    e4m3-rounded oracle vs the fp32 oracle, measured 3.3e-1 on the logits) -- the device must not add to it -- not the one-layer 1e-1 of
-    tests/test_fp8_width_gpu.py.  R: groma/model/groma.py:389-397 (the 32-layer stack)."""
-    r = _diag().run_fp8()
+    device path of the same weights, 32 LLaMA layers deep.  The stated tolerance is the e4m3 FORMAT's own distance at this depth -- the
+    e4m3-rounded oracle is 3.27e-1 from the fp32 oracle on the logits, the device 3.26e-1 from both the bf16 device and the fp32 oracle
+    (profiles/r06_fulldepth_fp8.txt, tests/diag/fulldepth_parity.py fp8: the oracle passes take two minutes and are not repeated here) -- not
+    the one-layer 1e-1 of tests/test_fp8_width_gpu.py.  R: groma/model/groma.py:389-397 (the 32-layer stack)."""
+    r = _diag().run_fp8(oracle=False)
     assert r["topk_equal"] and r["nms_equal"] and r["ids_equal"]          # the ViT / proposer are not e4m3: the index contract holds
-    lg = r["logits (32 layers deep, all 582 positions)"]
-    assert lg["vs_bf16_device"] <= 4e-1 and lg["vs_bf16_device"] <= 1.1 * lg["format"]
-    assert lg["vs_fp32"] <= 1.1 * lg["format"] and lg["vs_e4m3_oracle"] <= lg["format"]
-    rt = r["region tokens"]
-    assert rt["vs_bf16_device"] <= 1.2 * rt["format"] and rt["vs_e4m3_oracle"] <= rt["format"]
-    assert r["argmax_vs_fp32"] >= r["argmax_oracle_e4m3_vs_fp32"] - 0.05
+    assert 1e-1 < r["logits"] <= 4e-1, r                                  # measured 3.27e-1 (the format's 3.27e-1)
+    assert r["k31"] <= 4e-1 and r["region_tokens"] <= 8e-2 and r["region_logits"] <= 4.5e-1, r
+    assert r["argmax"] >= 0.35, r                                         # (measured 0.46; the e4m3-rounded oracle agrees with fp32 at 0.44)

@@ -25,7 +25,7 @@ def _diag():
     return mod
 
 
-@pytest.mark.parametrize("name,n", [("tiny", 100), ("width", 40)])
+@pytest.mark.parametrize("name,n", [("tiny", 60), ("width", 30)])   # (100 + 100 seeds: tests/diag/index_survival.py -> profiles/r06_index_survival.txt)
 def test_hybrid_indices_on_unselected_seeds(dev, name, n):
     s, rows = _diag().run(name, n, "hybrid", n64=4)
     assert s["n"] == n
