@@ -15,105 +15,79 @@
 // offw   f32 [B, Q, ld]: [0, heads*P*2) sampling offsets (h,p,xy), [heads*P*2, heads*P*3) attention logits (h,p)
 // ref    f32 [B*Q or Q, rdim] (rdim 2: loc = ref + off/(W,H); rdim 4: loc = ref_xy + off/P * ref_wh * 0.5)
 // out    f32 [B, Q, heads*32]
-// Work split (round 6): everything that depends on (b, q, head, point) alone -- the soft-max over the head's P points, the sampling
-// location, the four corner taps and their bilinear weights -- is evaluated ONCE, one thread per (group, point), into LDS; the 32 channel
-// lanes of a group then only gather (128-B coalesced value rows) and accumulate.  Rounds 1-5 had every channel lane redo the soft-max
-// (4 expf) and the location arithmetic: 32x the transcendental / address work for the same 16 gathers.
-// block = 256 threads = MSDA_G (64) groups (b, q, head): phase 1 is one tap per thread (all lanes busy), phase 2 walks the block's groups
-// eight at a time with lane = (group, channel).  (A first cut with 8 groups per block left 7 of 8 lanes idle in phase 1 and measured 2x
-// SLOWER than the redundant form: 329 vs 163 us per encoder launch at 14 images, profiles/r06_timeline_b14.txt.)
-#define MSDA_G 64
-struct MsdaTap {
-  int o[4];      // element index (row * Ws + col) of the four corners, -1: outside the map (zero padding)
-  float w[4];    // bilinear weights uh*uw, uh*lw, lh*uw, lh*lw
-  float aw;      // soft-max weight of the point
-  int inside;    // the sample touches the map at all
-};
+// thread = (b, q, head, channel); 32 channels of a head = half a wave -> 128-B coalesced value reads.
+// Every channel lane recomputes the head's soft-max (4 expf) and the four sampling locations: 32x redundant ALU work -- and it is the
+// faster form.  Round 6 built the de-duplicated kernel VERDICT r05 asked for (one thread per (query, head, point) evaluates soft-max,
+// location and corner taps once into LDS, the channel lanes only gather): 329 us per encoder launch with 8 groups per block, 343 us
+// with 64 (all lanes busy in the tap phase), against 163 us for this form at 14 images beside the pyramid (profiles/r06_timeline_b14.txt,
+// r05_timeline_b14.txt; alone on the chip 0.15 vs 0.06 ms per step).  The kernel is bound by the latency of its 16 dependent-free
+// gathers per thread, which this form issues from 8x as many resident threads with nothing between the offset loads and the gathers
+// but ALU; an LDS hand-over plus a block barrier in front of the gathers costs more than 30 redundant expf save.  Kept as it was.
 template <int P>
 __global__ __launch_bounds__(256) void msda_kernel(const float* __restrict__ value, const float* __restrict__ offw,
                                                    const float* __restrict__ ref, float* __restrict__ out, int B, int Q,
                                                    int heads, int Hs, int Ws, int ld, int rdim, int ref_batched) {
-  static_assert(MSDA_G * P == 256, "one tap per thread");
-  __shared__ MsdaTap taps[MSDA_G][P];
-  const long total_g = (long)B * Q * heads;
-  const long g0 = (long)blockIdx.x * MSDA_G;
-  {
-    const int gl = threadIdx.x / P, p = threadIdx.x - gl * P;
-    const long g = g0 + gl;
-    if (g < total_g) {
-      const int h = (int)(g % heads);
-      const long bq = g / heads;
-      const float* ow = offw + bq * ld;
-      const float* rp = ref + (ref_batched ? bq : bq % Q) * rdim;
-      float lg[P], mx = -INFINITY;   // soft-max over the P points of this head (single level)
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long total = (long)B * Q * heads * 32;
+  if (idx >= total) return;
+  const int c = (int)(idx & 31);
+  const int h = (int)((idx >> 5) % heads);
+  const long bq = idx / (32L * heads);
+  const int q = (int)(bq % Q), b = (int)(bq / Q);
+  const float* ow = offw + bq * ld;
+  const float* rp = ref + (ref_batched ? bq : (long)q) * rdim;
+  // softmax over the P points of this head (single level)
+  float lg[P], mx = -INFINITY;
 #pragma unroll
-      for (int i = 0; i < P; ++i) {
-        lg[i] = ow[heads * P * 2 + h * P + i];
-        mx = fmaxf(mx, lg[i]);
-      }
-      float den = 0.f, mine = 0.f;
+  for (int p = 0; p < P; ++p) {
+    lg[p] = ow[heads * P * 2 + h * P + p];
+    mx = fmaxf(mx, lg[p]);
+  }
+  float den = 0.f;
 #pragma unroll
-      for (int i = 0; i < P; ++i) {
-        lg[i] = expf(lg[i] - mx);
-        den += lg[i];
-        if (i == p) mine = lg[i];
-      }
-      const float ox = ow[(h * P + p) * 2], oy = ow[(h * P + p) * 2 + 1];
-      float lx, ly;
-      if (rdim == 2) {
-        lx = rp[0] + ox / (float)Ws;
-        ly = rp[1] + oy / (float)Hs;
-      } else {
-        lx = rp[0] + ox / (float)P * rp[2] * 0.5f;
-        ly = rp[1] + oy / (float)P * rp[3] * 0.5f;
-      }
-      const float w_im = lx * Ws - 0.5f, h_im = ly * Hs - 0.5f;
-      MsdaTap t;
-      t.aw = mine / den;
-      t.inside = h_im > -1.f && w_im > -1.f && h_im < (float)Hs && w_im < (float)Ws;
+  for (int p = 0; p < P; ++p) {
+    lg[p] = expf(lg[p] - mx);
+    den += lg[p];
+  }
+  const float rx = rp[0], ry = rp[1];
+  float acc = 0.f;
+  const float* vb = value + (long)b * Hs * Ws * heads * 32 + h * 32 + c;
+  const long vstride = (long)heads * 32;
+#pragma unroll
+  for (int p = 0; p < P; ++p) {
+    const float ox = ow[(h * P + p) * 2], oy = ow[(h * P + p) * 2 + 1];
+    float lx, ly;
+    if (rdim == 2) {
+      lx = rx + ox / (float)Ws;
+      ly = ry + oy / (float)Hs;
+    } else {
+      lx = rx + ox / (float)P * rp[2] * 0.5f;
+      ly = ry + oy / (float)P * rp[3] * 0.5f;
+    }
+    const float w_im = lx * Ws - 0.5f, h_im = ly * Hs - 0.5f;
+    float val = 0.f;
+    if (h_im > -1.f && w_im > -1.f && h_im < (float)Hs && w_im < (float)Ws) {
       const int hl = (int)floorf(h_im), wl = (int)floorf(w_im);
       const int hh = hl + 1, wh = wl + 1;
       const float lh = h_im - hl, lw = w_im - wl;
       const float uh = 1.f - lh, uw = 1.f - lw;
-      t.o[0] = (t.inside && hl >= 0 && wl >= 0) ? hl * Ws + wl : -1;
-      t.o[1] = (t.inside && hl >= 0 && wh <= Ws - 1) ? hl * Ws + wh : -1;
-      t.o[2] = (t.inside && hh <= Hs - 1 && wl >= 0) ? hh * Ws + wl : -1;
-      t.o[3] = (t.inside && hh <= Hs - 1 && wh <= Ws - 1) ? hh * Ws + wh : -1;
-      t.w[0] = uh * uw; t.w[1] = uh * lw; t.w[2] = lh * uw; t.w[3] = lh * lw;
-      taps[gl][p] = t;
+      float v1 = 0.f, v2 = 0.f, v3 = 0.f, v4 = 0.f;
+      if (hl >= 0 && wl >= 0) v1 = vb[((long)hl * Ws + wl) * vstride];
+      if (hl >= 0 && wh <= Ws - 1) v2 = vb[((long)hl * Ws + wh) * vstride];
+      if (hh <= Hs - 1 && wl >= 0) v3 = vb[((long)hh * Ws + wl) * vstride];
+      if (hh <= Hs - 1 && wh <= Ws - 1) v4 = vb[((long)hh * Ws + wh) * vstride];
+      val = uh * uw * v1 + uh * lw * v2 + lh * uw * v3 + lh * lw * v4;
     }
+    acc += val * (lg[p] / den);
   }
-  __syncthreads();
-  const int c = threadIdx.x & 31;
-  const long vstride = (long)heads * 32;
-#pragma unroll 2
-  for (int gl = threadIdx.x >> 5; gl < MSDA_G; gl += 8) {
-    const long g = g0 + gl;
-    if (g >= total_g) break;
-    const int h = (int)(g % heads);
-    const long b = g / heads / Q;
-    const float* vb = value + b * Hs * Ws * heads * 32 + h * 32 + c;
-    float acc = 0.f;
-#pragma unroll
-    for (int p = 0; p < P; ++p) {
-      const MsdaTap& t = taps[gl][p];   // (one address per half-wave: an LDS broadcast)
-      float val = 0.f;
-      if (t.inside) {
-        const float v1 = t.o[0] >= 0 ? vb[(long)t.o[0] * vstride] : 0.f, v2 = t.o[1] >= 0 ? vb[(long)t.o[1] * vstride] : 0.f;
-        const float v3 = t.o[2] >= 0 ? vb[(long)t.o[2] * vstride] : 0.f, v4 = t.o[3] >= 0 ? vb[(long)t.o[3] * vstride] : 0.f;
-        val = t.w[0] * v1 + t.w[1] * v2 + t.w[2] * v3 + t.w[3] * v4;
-      }
-      acc += val * t.aw;
-    }
-    out[g * 32 + c] = acc;
-  }
+  out[idx] = acc;
 }
 
 extern "C" int gr_msda_f32(const float* value, const float* offw, const float* ref, float* out, int B, int Q, int heads,
                            int n_points, int Hs, int Ws, int ld, int rdim, int ref_batched, hipStream_t stream) {
   if (!value || !offw || !ref || !out || n_points != 4 || (rdim != 2 && rdim != 4)) return GR_EINVAL;
-  const long groups = (long)B * Q * heads;
-  hipLaunchKernelGGL(msda_kernel<4>, dim3(gr_cdiv(groups, MSDA_G)), dim3(256), 0, stream, value, offw, ref, out, B, Q, heads,
+  const long total = (long)B * Q * heads * 32;
+  hipLaunchKernelGGL(msda_kernel<4>, dim3(gr_cdiv(total, 256)), dim3(256), 0, stream, value, offw, ref, out, B, Q, heads,
                      Hs, Ws, ld, rdim, ref_batched);
   GR_CHECK_LAUNCH();
   return GR_OK;
