@@ -15,6 +15,7 @@ SOURCES = {
     "gemv_fp8.hip": [],
     "gemm_fp8_256.hip": [],
     "gemm_skinny.hip": [],
+    "gemm_skinny_fp8.hip": [],
     "fp8.hip": [],
     "gemm_f32.hip": [],
     "attention.hip": [],
@@ -43,7 +44,7 @@ def _stale(target, deps):
 
 
 def build(force=False, verbose=True):
-    hdrs = [os.path.join(HERE, "gr_common.h"), os.path.join(HERE, "gemm_common.h"), os.path.join(HERE, "gemv_args.h"), os.path.join(HERE, "gemm_bf16_256.hip"), os.path.join(HERE, "..", "..", "include", "groma_hip.h"),
+    hdrs = [os.path.join(HERE, "gr_common.h"), os.path.join(HERE, "gemm_common.h"), os.path.join(HERE, "gemv_args.h"), os.path.join(HERE, "gemm_bf16_256.hip"), os.path.join(HERE, "gemm_skinny.hip"), os.path.join(HERE, "..", "..", "include", "groma_hip.h"),
             os.path.abspath(__file__)]
     jobs, links = [], []
     for suffix, defs, lib in VARIANTS:

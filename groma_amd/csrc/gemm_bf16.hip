@@ -280,7 +280,7 @@ extern "C" int gr_gemm_bf16(const gr_gemm_desc* d, hipStream_t stream) {
     return GR_EINVAL;
   if (d->M <= 0 || d->N <= 0 || d->K <= 0) return GR_EINVAL;
   if (d->K % BK != 0 || d->N % 4 != 0) return GR_EINVAL;
-  if (d->fp8 && (d->K % 128 != 0 || d->conv_C % 128 != 0 || !d->w_scale || d->tile == 1 || d->tile == 2)) return GR_EINVAL;
+  if (d->fp8 && (d->K % 128 != 0 || d->conv_C % 128 != 0 || !d->w_scale || d->tile == 1 || d->tile == 2)) return GR_EINVAL;  // (tile 3: gemm_skinny_fp8.hip)
   if (d->conv_C > 0 && (d->conv_C % BK != 0 || d->K % (9 * d->conv_C) != 0)) return GR_EINVAL;
   const int splits = d->splits > 1 ? d->splits : 1;
   if (splits > 1 && !d->ws) return GR_EINVAL;
@@ -322,9 +322,9 @@ extern "C" int gr_gemm_bf16(const gr_gemm_desc* d, hipStream_t stream) {
   const bool partials_only = d->tile == 2;         // the caller's next kernel consumes ws[splits, M, N] (decode.hip)
   if (gemv && (p.M > 8 || p.conv_C > 0 || splits != gr_cdiv(p.K, 512) || !p.ws)) return GR_EINVAL;
   const bool skinny = d->tile == 3;                // decode steps of 9..64 rows: the weight stream on the matrix unit (gemm_skinny.hip)
-  if (skinny && (d->fp8 || splits > 1)) return GR_EINVAL;
+  if (skinny && splits > 1) return GR_EINVAL;
   if (d->tile != 0 && d->tile != 1 && d->tile != 2 && d->tile != 3 && d->tile != 128 && d->tile != 256 && d->tile != GR_TILE_PP192) return GR_EINVAL;
-  if (d->tile == 256 || d->fp8) use256 = true;  // fp8 exists for the 256x256 kernel only
+  if (d->tile == 256 || (d->fp8 && !skinny)) use256 = true;  // fp8 exists for the 256x256 kernel (and the skinny stream) only
   else if (d->tile == GR_TILE_PP192) { use256 = true; pp_rows = 192; }
   else if (d->tile == 0) {
     const long t128 = (long)gr_cdiv(p.M, 128) * gr_cdiv(p.N, 128);
@@ -361,7 +361,7 @@ extern "C" int gr_gemm_bf16(const gr_gemm_desc* d, hipStream_t stream) {
     (void)hipEventRecord(rec.a, stream);
   }
   if (skinny) {
-    const int rc = gr_launch_gemm_skinny(p, stream);
+    const int rc = d->fp8 ? gr_launch_gemm_skinny_fp8(p, stream) : gr_launch_gemm_skinny(p, stream);
     if (rc != GR_OK) return rc;
   } else if (gemv) {
     const int rc = gr_launch_gemv(p, stream);

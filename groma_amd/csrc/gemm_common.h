@@ -315,7 +315,8 @@ __device__ __forceinline__ void epi_dispatch(const GemmArgs& p, const char* base
 
 // skinny M<=8 streaming kernel (gemv_bf16.hip): requires p.splits == ceil(K/512) and p.ws
 int gr_launch_gemv(const GemmArgs& p, hipStream_t stream);
-int gr_launch_gemm_skinny(const GemmArgs& p, hipStream_t stream);  // gemm_skinny.hip: decode steps of 9..64 rows (tile == 3)
+int gr_launch_gemm_skinny(const GemmArgs& p, hipStream_t stream);      // gemm_skinny.hip: decode steps of 9..64 rows (tile == 3)
+int gr_launch_gemm_skinny_fp8(const GemmArgs& p, hipStream_t stream);  // ... with e4m3 operands (gemm_skinny_fp8.hip)
 // (256 | 192) x 256 x 64 ping-pong kernel (gemm_bf16_256.hip); p.tiles_m counts row tiles of height tile_rows
 int gr_launch_gemm256(const GemmArgs& p, hipStream_t stream, int tile_rows);
 // OCP-fp8 build of the same kernel (gemm_fp8_256.hip); A/W are e4m3 bytes, K % 128 == 0

@@ -20,9 +20,27 @@
 // Epilogues (the prefill GEMM's, gemm_common.h): bias, f32 / 16-bit out, fp32 residual (in place allowed), SwiGLU over interleaved rows.
 // Waits are the compiler's: every operand goes through registers (no LDS-DMA), so hipcc counts vmcnt exactly; the loop is unrolled by 6
 // (the W ring has 3 slots, the x ring 2) and its steady state carries no guard.
+//
+// The same source builds the OCP e4m3 variant (gemm_skinny_fp8.hip defines SK_FP8 = 1; round 6: e4m3 models past 8 rows).  A slice is 512
+// BYTES of a row in both builds and a lane's eight 16-B chunks of it sit at the same byte offsets (chunk i at 64 i + 16 fg), so loads, the
+// x image and its swizzle are identical; what differs is the product -- four v_mfma_scale_f32_16x16x128_f8f6f4 (unit block scales: chunks
+// 2 j, 2 j + 1 are exactly the 32 k-values per lane the instruction takes) instead of eight 16x16x32 -- and the epilogue's dequantisation
+// acc * w_scale[n] * a_scale[m] (per-row activation scales from gr_norm_fp8 / gr_quant_rows_fp8, per-output-channel weight scales), in the
+// e4m3 GEMM's order.
 #include "gemm_common.h"
 
-#define SK_KS 256   // k-values per slice (512 B per row)
+#ifndef SK_FP8
+#define SK_FP8 0
+#endif
+#define SK_SB 512                          // bytes of a row per slice
+#define SK_EB (SK_FP8 ? 1 : 2)             // bytes per operand element
+#if SK_FP8
+#define gemm_skinny_kernel gemm_skinny_fp8_kernel
+#define gr_launch_gemm_skinny gr_launch_gemm_skinny_fp8
+#define gr_diag_skinny_kw gr_diag_skinny_fp8_kw
+typedef __attribute__((ext_vector_type(8))) int sk_i32x8;
+typedef __attribute__((ext_vector_type(4))) int sk_i32x4;
+#endif
 
 // NB: 16-row blocks of x (M <= 16 NB).  KW: K-ways -- the four waves of a workgroup are 4 / KW row blocks x KW slices of the same
 // iteration, so a workgroup owns 64 / KW rows of W and a launch has N KW / 64 workgroups: the N = 4096 matrices (o-proj, down-proj)
@@ -38,7 +56,7 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmArgs p) {
   constexpr int AHEAD = WD > XA ? WD : XA;
   constexpr int RBW = 4 / KW;                // row blocks (waves along N) per workgroup
   constexpr int XI = NB * 2 * KW;            // 16-B chunks of an x stage per thread (16 NB rows x 32 KW chunks / 256 threads)
-  constexpr int XROW = 512 * KW;             // bytes per staged x row
+  constexpr int XROW = SK_SB * KW;           // bytes per staged x row
   constexpr int XBYTES = NB * 16 * XROW;
   extern __shared__ __attribute__((aligned(16))) char smem[];  // 2 x stages (re-used by the KW reduction)
   const int tid = threadIdx.x, lane = tid & 63;
@@ -46,20 +64,21 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmArgs p) {
   const int rb = wave % RBW, kh = wave / RBW;
   const int fr = lane & 15, fg = lane >> 4;
   const int n0 = blockIdx.x * (16 * RBW);
-  const int nit = (p.K + SK_KS * KW - 1) / (SK_KS * KW);   // K % 32 == 0; slices past K multiply zeros (their W loads re-read k = 0)
+  const long KB = (long)p.K * SK_EB;                          // bytes of a row
+  const int nit = (int)((KB + SK_SB * KW - 1) / (SK_SB * KW));  // (KB % 64 == 0; chunks past the row multiply zeros: their W loads re-read byte 0)
 
   int wr = n0 + 16 * rb + fr;
   if (wr > p.N - 1) wr = p.N - 1;
-  const bf16_t* wrow = p.W + (long)wr * p.ldw + fg * 8 + kh * SK_KS;
-  const bf16_t* xsrc[XI];
-  int xdst[XI], xk[XI];
+  const char* wrow = (const char*)p.W + ((long)wr * p.ldw) * SK_EB + fg * 16 + kh * SK_SB;
+  const char* xsrc[XI];
+  int xdst[XI], xk[XI];   // xk: byte offset of the chunk inside an iteration's x rows
 #pragma unroll
   for (int i = 0; i < XI; ++i) {
     const int s = i * 256 + tid, row = s / (32 * KW), cpos = s % (32 * KW);
     int m = row;
     if (m > p.M - 1) m = p.M - 1;
-    xk[i] = (cpos ^ (row & 15)) << 3;                              // slot (row, cpos) holds logical chunk cpos ^ (row & 15)
-    xsrc[i] = p.A + (long)m * p.lda + xk[i];
+    xk[i] = (cpos ^ (row & 15)) << 4;                              // slot (row, cpos) holds logical chunk cpos ^ (row & 15)
+    xsrc[i] = (const char*)p.A + ((long)m * p.lda) * SK_EB + xk[i];
     xdst[i] = s << 4;
   }
   bf16x8 w[WD][8], xr[XD][XI];
@@ -70,17 +89,17 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmArgs p) {
   // EDGE: the iteration may reach past K -- k-blocks / chunks at or beyond K read k = 0 of the row (finite) against x = 0
   auto load_w = [&](int t, bf16x8* dst, bool edge) {
 #pragma unroll
-    for (int kb = 0; kb < 8; ++kb) {
-      long k = (long)t * (SK_KS * KW) + kb * 32;
-      if (edge && k + kh * SK_KS >= p.K) k = -(long)kh * SK_KS;
+    for (int kb = 0; kb < 8; ++kb) {   // chunk kb of the slice: bytes 64 kb + 16 fg ..
+      long k = (long)t * (SK_SB * KW) + kb * 64;
+      if (edge && k + kh * SK_SB >= KB) k = -(long)kh * SK_SB;
       dst[kb] = __builtin_nontemporal_load((const bf16x8*)(wrow + k));
     }
   };
   auto load_x = [&](int t, bf16x8* dst, bool edge) {
 #pragma unroll
     for (int i = 0; i < XI; ++i) {
-      const bool in = !edge || t * (SK_KS * KW) + xk[i] < p.K;
-      dst[i] = in ? *(const bf16x8*)(xsrc[i] + (long)t * (SK_KS * KW)) : (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+      const bool in = !edge || (long)t * (SK_SB * KW) + xk[i] < KB;
+      dst[i] = in ? *(const bf16x8*)(xsrc[i] + (long)t * (SK_SB * KW)) : (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
     }
   };
   auto put_x = [&](const bf16x8* src, int buf) {
@@ -89,6 +108,21 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmArgs p) {
   };
   auto compute = [&](const bf16x8* wv, int buf) {
     const char* xb = smem + buf * XBYTES;
+#if SK_FP8
+#pragma unroll
+    for (int j = 0; j < 4; ++j)   // one 128-byte k-block: chunks 2 j, 2 j + 1 of the slice for A and B alike
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) {
+        const int row = nb * 16 + fr;
+        union { struct { sk_i32x4 a, b; } h; sk_i32x8 v; } ua, ub;
+        ua.h.a = __builtin_bit_cast(sk_i32x4, wv[2 * j]);
+        ua.h.b = __builtin_bit_cast(sk_i32x4, wv[2 * j + 1]);
+        ub.h.a = *(const sk_i32x4*)(xb + row * XROW + (((kh * 32 + (2 * j) * 4 + fg) ^ fr) << 4));
+        ub.h.b = *(const sk_i32x4*)(xb + row * XROW + (((kh * 32 + (2 * j + 1) * 4 + fg) ^ fr) << 4));
+        // formats e4m3 x e4m3 (cbsz = blgp = 0), both block scales the e8m0 code for 2^0: a plain product at the MX rate
+        acc[nb] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(ua.v, ub.v, acc[nb], 0, 0, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
+      }
+#else
 #pragma unroll
     for (int kb = 0; kb < 8; ++kb)
 #pragma unroll
@@ -97,6 +131,7 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmArgs p) {
         const bf16x8 xv = *(const bf16x8*)(xb + row * XROW + (((kh * 32 + kb * 4 + fg) ^ fr) << 4));
         acc[nb] = GR_MFMA_16x16x32(wv[kb], xv, acc[nb]);
       }
+#endif
   };
   // iteration t: W in w[t % WD], x in LDS stage t % 2; x of t + 1 (.. t + XD) in the register ring
 #pragma unroll
@@ -153,11 +188,18 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmArgs p) {
   if (n >= p.N) return;
   f32x4 bias = {0.f, 0.f, 0.f, 0.f};
   if (p.bias) bias = *(const f32x4*)(p.bias + n);
+#if SK_FP8
+  const f32x4 wsc = *(const f32x4*)(p.w_scale + n);
+#endif
 #pragma unroll
   for (int nb = 0; nb < NB; ++nb) {
     const int m = nb * 16 + fr;
     if (m >= p.M) continue;
+#if SK_FP8
+    f32x4 v = acc[nb] * wsc * (p.a_scale ? p.a_scale[m] : 1.f) + bias;   // dequantise: acc * w_scale[n] * a_scale[m], the e4m3 GEMM epilogue's order
+#else
     f32x4 v = acc[nb] + bias;
+#endif
     if (p.act == 3) {   // interleaved rows: even = gate_j, odd = up_j (weights.pack_llm) -> 2 outputs
       uint32_t hi, lo;
       split2(silu_f(v[0]) * v[1], silu_f(v[2]) * v[3], hi, lo);
@@ -183,7 +225,7 @@ extern "C" int gr_diag_skinny_kw(int kw) {
 
 template <int NB, int KW>
 static int launch_skinny(const GemmArgs& p, hipStream_t stream) {
-  const size_t lds = 2 * (size_t)NB * 16 * 512 * KW;
+  const size_t lds = 2 * (size_t)NB * 16 * SK_SB * KW;
   static bool attr_set = false;
   if (!attr_set && lds > 65536) {
     if (hipFuncSetAttribute((const void*)gemm_skinny_kernel<NB, KW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return GR_EINVAL;
@@ -195,7 +237,8 @@ static int launch_skinny(const GemmArgs& p, hipStream_t stream) {
 
 int gr_launch_gemm_skinny(const GemmArgs& p, hipStream_t stream) {
   if (GR_SP) return GR_EINVAL;   // (operand pairs: the general kernels)
-  if (p.M < 1 || p.M > 64 || p.K % 32 != 0 || p.N % 4 != 0 || p.lda % 8 != 0 || p.ldw % 8 != 0) return GR_EINVAL;
+  if (p.M < 1 || p.M > 64 || ((long)p.K * SK_EB) % 64 != 0 || p.N % 4 != 0 || ((long)p.lda * SK_EB) % 16 != 0 || ((long)p.ldw * SK_EB) % 16 != 0) return GR_EINVAL;
+  if (SK_FP8 && (!p.w_scale || p.K % 128 != 0)) return GR_EINVAL;
   if (p.conv_C > 0 || p.splits > 1 || p.scale || p.a_parts || p.resid_mod > 0 || p.c_group > 0) return GR_EINVAL;
   if (p.act == 3 && (p.resid || p.out_f32 || (p.N & 7))) return GR_EINVAL;
   if ((((uintptr_t)p.A) | ((uintptr_t)p.W)) & 15) return GR_EINVAL;
@@ -207,7 +250,7 @@ int gr_launch_gemm_skinny(const GemmArgs& p, hipStream_t stream) {
   const int nbt = nb <= 1 ? 1 : nb == 2 ? 2 : 4;
   int kw = g_skinny_kw ? g_skinny_kw : (p.N >= 8192 ? 1 : 4);
   if (nbt == 4 && kw > 2) kw = 2;   // (64 rows x 4 K-ways: the x stage alone would need 128 registers)
-  while (kw > 1 && p.K < SK_KS * kw * 2) kw >>= 1;
+  while (kw > 1 && (long)p.K * SK_EB < SK_SB * kw * 2) kw >>= 1;
   if (nbt == 1) return kw == 1 ? launch_skinny<1, 1>(p, stream) : kw == 2 ? launch_skinny<1, 2>(p, stream) : launch_skinny<1, 4>(p, stream);
   if (nbt == 2) return kw == 1 ? launch_skinny<2, 1>(p, stream) : kw == 2 ? launch_skinny<2, 2>(p, stream) : launch_skinny<2, 4>(p, stream);
   return kw == 1 ? launch_skinny<4, 1>(p, stream) : launch_skinny<4, 2>(p, stream);

@@ -683,8 +683,8 @@ class LlamaEngine:
         if FUSED_DECODE and L == 1 and M <= 8 and fits8 and T <= 8192 and cache.smax <= 8192 and ops.SP() == 1 and states is None \
                 and self.prec is None:
             return self._decode_forward(h, bs, cache, kv_len, pos_dev, pos_stride, past)
-        if WIDE_DECODE and L == 1 and 8 < M <= 64 and not w["fp8"] and ops.SP() == 1 and self.prec is None and states is None \
-                and T % 32 == 0 and self.I % 32 == 0 and cache.smax <= 8192:
+        if WIDE_DECODE and L == 1 and 8 < M <= 64 and ops.SP() == 1 and self.prec is None and states is None \
+                and T % 32 == 0 and self.I % 32 == 0 and cache.smax <= 8192 and (not w["fp8"] or (T % 128 == 0 and self.I % 128 == 0)):
             return self._decode_forward_wide(h, bs, cache, kv_len, pos_dev, pos_stride, past)
         # A decode step that does not fit the weight-streaming paths (more than 64 rows, pair operands, e4m3 beyond 8 rows, > 8192 keys)
         # runs the general kernels below.  Its scratch may be baked into GreedyDecoder's captured hipGraph, so -- like _decode_forward --
@@ -822,26 +822,46 @@ class LlamaEngine:
         kernels of their own here (a 64-row operand no longer fits a workgroup's prologue).  Never-moved buffers: the step is captured."""
         w, ws, T, H, hd = self.w, self.ws, self.T, self.H, self.hd
         dyn = pos_dev is not None
+        fp8 = w["fp8"]
         x = ws.get("decw_x", (bs, T), H16(), exact=True)
         qkv = ws.get("decw_qkv", (bs, 3 * T), H16(), exact=True)
         q = ws.get("decw_q", (bs, H, 1, hd), H16(), exact=True)
         ctx = ws.get("decw_ctx", (bs, T), H16(), exact=True)
         y = ws.get("decw_y", (bs, self.I), H16(), exact=True)
+        # e4m3 models (csrc/gemm_skinny_fp8.hip): operands quantised per row exactly as the prefill forms them -- a normalisation output
+        # straight from fp32 (gr_norm_fp8), a stored 16-bit activation through the row quantiser -- into never-moved buffers
+        q8 = {K_: (ws.get(f"decw_q8_{K_}", (bs, K_), ops.FP8, exact=True), ws.get(f"decw_s8_{K_}", (bs,), F32, exact=True))
+              for K_ in ((T, self.I) if fp8 else ())}
+
+        def lin(h_f32, gain, wt, **kw):       # RMSNorm -> GEMM
+            if fp8:
+                x8, sx = ops.norm_fp8(h_f32, gain, None, self.eps, True, out=q8[T])
+                return ops.gemm(x8, wt[0], a_scale=sx, w_scale=wt[1], tile=3, **kw)
+            return ops.gemm(ops.rmsnorm(h_f32, gain, self.eps, out=x), wt[0], tile=3, **kw)
+
+        def lin16(a16, wt, **kw):             # stored 16-bit activation -> GEMM
+            if fp8:
+                x8, sx = ops.quant_rows_fp8(a16, out=q8[a16.shape[-1]])
+                return ops.gemm(x8, wt[0], a_scale=sx, w_scale=wt[1], tile=3, **kw)
+            return ops.gemm(a16, wt[0], tile=3, **kw)
+
         for i, Lw in enumerate(w["layers"]):
-            ops.rmsnorm(h, Lw["n1"], self.eps, out=x)
-            ops.gemm(x, Lw["wqkv"][0], out=qkv, tile=3)
+            lin(h, Lw["n1"], Lw["wqkv"], out=qkv)
             ops.qkv_split(qkv, q, cache.k[i], cache.vt[i], B=bs, H=H, L=1, hd=hd, pos0=past, cos=w["cos"], sin=w["sin"],
                           pos_dev=pos_dev, pos_stride=pos_stride)
             ops.decode_attention(q, cache.k[i], cache.vt[i], ctx, Smax=cache.smax if dyn else past + 1, q_pos0=past, kv_len=kv_len,
                                  pos_dev=pos_dev, pos_stride=pos_stride, nsplit=1)
-            ops.gemm(ctx, Lw["wo"][0], resid=h, out=h, out_f32=True, tile=3)
-            ops.rmsnorm(h, Lw["n2"], self.eps, out=x)
-            ops.gemm(x, Lw["wgu"][0], act=3, out=y, tile=3)
-            ops.gemm(y, Lw["wd"][0], resid=h, out=h, out_f32=True, tile=3)
+            lin16(ctx, Lw["wo"], resid=h, out=h, out_f32=True)
+            lin(h, Lw["n2"], Lw["wgu"], act=3, out=y)
+            lin16(y, Lw["wd"], resid=h, out=h, out_f32=True)
         if not dyn:
             cache.seq_len = past + 1
+        logits = self.decode_logits(bs)
+        if fp8 and "head8" in w:
+            lin(h, w["norm"], w["head8"], out_f32=True, out=logits)
+            return logits.view(bs, 1, self.Vpad)[:, :, : self.V], None
         hn = ops.rmsnorm(h, w["norm"], self.eps, out=x)
-        logits = ops.gemm(hn, w["head"], out_f32=True, out=self.decode_logits(bs), tile=3)
+        ops.gemm(hn, w["head"], out_f32=True, out=logits, tile=3)
         return logits.view(bs, 1, self.Vpad)[:, :, : self.V], hn
 
     def _decode_forward(self, h, bs, cache, kv_len, pos_dev, pos_stride, past):

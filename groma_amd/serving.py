@@ -109,8 +109,8 @@ class ContinuousBatcher:
     @engine.model_entry(lambda self, *a, **kw: (a[0] if a else kw["model"]).precision)
     def __init__(self, model, max_rows=8, max_len=1024, use_graph=True, grow_to=None):
         if max_rows < 1 or max_rows > 64:
-            raise ValueError("max_rows must be in 1..64 (1..8: the fused 8-row weight streams; 9..64: the matrix-unit weight stream, "
-                             "csrc/gemm_skinny.hip -- 16-bit single-type models; others fall back to the general kernels)")
+            raise ValueError("max_rows must be in 1..64 (1..8: the fused 8-row weight streams; 9..64: the matrix-unit weight streams, "
+                             "csrc/gemm_skinny.hip / gemm_skinny_fp8.hip -- single-type 16-bit or e4m3 models; others fall back to the general kernels)")
         if max_len % 64 or max_len > 8192:
             raise ValueError("max_len must be a multiple of 64 and <= 8192")
         if grow_to is not None and (grow_to % 64 or grow_to < max_len or grow_to > 8192):

@@ -1,7 +1,7 @@
 """Continuous batching throughput on Groma-7B (random init): R requests x T new tokens through max_rows slots.
    python tests/serve_bench.py [--fp8] [--rows 4,8,16,32] [--precision bf16] [--requests N]
-   (--fp8: e4m3 weights + activations, the batcher on the e4m3 decode streams, <= 8 rows;
-    rows > 8: the matrix-unit weight stream, csrc/gemm_skinny.hip -- round 6)"""
+   (--fp8: e4m3 weights + activations, the batcher on the e4m3 decode streams;
+    rows > 8: the matrix-unit weight streams, csrc/gemm_skinny.hip / gemm_skinny_fp8.hip -- round 6)"""
 import os, sys, time, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from groma_amd import config, constants, synth
@@ -20,7 +20,7 @@ m = GromaModel.from_synthetic(cfg, seed=0, device='cuda', fp8=FP8, precision=pre
 m.init_special_token_id(constants.SyntheticTokenizer())
 m.generation_config.eos_token_id = None
 T = 32
-rows_list = [int(x) for x in arg('--rows', '4,8' if FP8 else '4,8,16,32').split(',')]
+rows_list = [int(x) for x in arg('--rows', '4,8,16,32').split(',')]
 for rows in rows_list:
     R = int(arg('--requests', max(16, 2 * rows)))   # two admission waves per slot
     images, ids = synth.make_inputs(cfg, m, R, seed=5)

@@ -141,3 +141,78 @@ def test_sixteen_row_batcher_rows_equal_their_solo_runs(tiny, use_graph):
         same += int(b4.result(rid).tokens == want)
     print(f"requests whose tokens also equal the 8-row stream's: {same} / 4")
     assert same >= 2
+
+
+@pytest.mark.parametrize("M,N,K", [(16, 4096, 4096), (33, 1024, 11008), (64, 2048, 4096), (12, 512, 1408 - 1408 % 128)])
+def test_skinny_gemm_e4m3(dev, M, N, K):
+    """csrc/gemm_skinny_fp8.hip against the e4m3 ping-pong GEMM on the SAME quantised operands (both dequantise acc * w_scale[n] * a_scale[m];
+    they differ by the matrix unit's block accumulation order) and against float64 of the dequantised operands; rows independent of company"""
+    from groma_amd import ops, weights
+    g = torch.Generator().manual_seed(M + N)
+    x = (torch.randn((M, K), generator=g) * 0.7).to(dev)
+    w = (torch.randn((N, K), generator=g) * 0.05).to(dev)
+    x8, sx = ops.quant_rows_fp8(x)
+    w8, sw = weights.q8(w)
+    ref = (x8.float().double().cpu() * sx.double().cpu()[:, None]) @ (w8.float().double().cpu() * sw.double().cpu()[:, None]).t()
+    out = ops.gemm(x8, w8, a_scale=sx, w_scale=sw, out_f32=True, tile=3)
+    assert util.relerr(out, ref) < 2e-4
+    assert util.relerr(out, ops.gemm(x8, w8, a_scale=sx, w_scale=sw, out_f32=True)) < 2e-4       # the 256 x 256 e4m3 kernel
+    resid = torch.randn((M, N), generator=g).to(dev)
+    r2 = resid.clone()
+    ops.gemm(x8, w8, a_scale=sx, w_scale=sw, resid=r2, out=r2, out_f32=True, tile=3)
+    assert util.relerr(r2, ref + resid.double().cpu()) < 2e-4
+    if N % 8 == 0:
+        act = ops.gemm(x8, w8, a_scale=sx, w_scale=sw, act=3, tile=3)
+        assert util.relerr(act, torch.nn.functional.silu(ref[:, 0::2]) * ref[:, 1::2]) < 1e-2
+    if M > 48:
+        sub = ops.gemm(x8[:55].contiguous(), w8, a_scale=sx[:55].contiguous(), w_scale=sw, out_f32=True, tile=3)
+        assert torch.equal(sub, out[:55])
+
+
+def test_e4m3_model_wide_step_and_batcher(dev):
+    """an fp8 = True model past 8 rows: the 12-row decode step on the e4m3 matrix-unit stream against the same step on the general e4m3
+    kernels, and ContinuousBatcher(max_rows = 12) rows equal to their solo runs (quantisation is per row: nothing crosses rows)"""
+    from groma_amd import constants, engine, synth
+    from groma_amd.groma import GromaModel
+    from groma_amd.serving import ContinuousBatcher
+    cfg, sd, tk = util.tiny_setup(seed=0)
+    model = GromaModel.from_state_dict(cfg, sd, "cuda", fp8=True)
+    model.init_special_token_id(constants.SyntheticTokenizer())
+    model.generation_config.eos_token_id = None
+    llm = model.llm
+    if llm.T % 128 or llm.I % 128:
+        pytest.skip("tiny widths are not multiples of the e4m3 k-block")
+    outs = {}
+    bs = 12
+    for wide in (True, False):
+        engine.WIDE_DECODE = wide
+        try:
+            cache = llm.new_cache(bs, 128, model.device)
+            g = torch.Generator().manual_seed(3)
+            for l in range(len(cache.k)):
+                cache.k[l][:, :, :40] = (torch.randn(cache.k[l][:, :, :40].shape, generator=g) * 0.3).to(model.device).to(cache.k[l].dtype)
+                cache.vt[l][..., :40] = (torch.randn(cache.vt[l][..., :40].shape, generator=g) * 0.3).to(model.device).to(cache.vt[l].dtype)
+            cache.seq_len = 40
+            h = (torch.randn((bs, llm.T), generator=g) * 0.5).to(model.device)
+            logits, _ = llm.forward(h, bs, 1, cache)
+            outs[wide] = logits.float().cpu().clone()
+        finally:
+            engine.WIDE_DECODE = True
+    e = util.relerr(outs[True], outs[False])
+    print(f"e4m3 12-row step, matrix-unit stream vs general e4m3 kernels: {e:.2e}")
+    assert e < 5e-2       # (e4m3 quantisation steps amplify last-bit differences of the fp32 sums: the chained bound of tests/test_fp8_gpu.py)
+    reqs = []
+    for i in range(6):
+        images, ids = synth.make_inputs(cfg, tk, bs=1, seed=400 + i)
+        reqs.append((ids[0], images[0], 5 + i % 3, 700 + i))
+    solo = []
+    for ids, image, n, seed in reqs:
+        b = ContinuousBatcher(model, max_rows=12, max_len=1024)
+        rid = b.submit(ids, image, max_new_tokens=n, seed=seed)
+        b.run_until_done()
+        solo.append(b.result(rid).tokens)
+    b = ContinuousBatcher(model, max_rows=12, max_len=1024)
+    rids = [b.submit(ids, image, max_new_tokens=n, seed=seed) for ids, image, n, seed in reqs]
+    res = b.run_until_done()
+    for rid, want in zip(rids, solo):
+        assert res[rid].error is None and res[rid].tokens == want
