@@ -479,6 +479,23 @@ def extras_block(model, cfg, args, dev, P):
         g["workload"] = "configs[3] per-GPU share: prefill + greedy decode (hipGraph replay), no EOS"
         return g
     ex["generate_4_images_per_call"] = decode_step(model, g, ex["forward_4_images_per_call"]["ms_per_step"])
+    # configs[3]'s WHOLE batch on one GPU (round 6): 32 rows decode on the matrix-unit weight stream (csrc/gemm_skinny.hip) -- the same
+    # weight bytes per token as 4 rows, eight times the tokens
+    eos = model.generation_config.eos_token_id
+    model.generation_config.eos_token_id = None
+    try:
+        pre32 = line(model, 32, False, steps=3, warmup=3)
+        g32 = line(model, 32, True, steps=2, warmup=3)
+        g32["new_tokens"], g32["prefill_ms_32_images"] = args.new_tokens, pre32["ms_per_step"]
+        g32["decode_step"] = {"ms_per_token": (g32["ms_per_step"] - pre32["ms_per_step"]) / max(args.new_tokens - 1, 1), "rows": 32,
+                              "note": "(generate ms - 32-image prefill ms) / (new_tokens - 1): one tick of 32 rows"}
+        g32["workload"] = "configs[3]'s global batch (32 images) in ONE generate() call on one GPU: prefill + greedy decode, 32 rows per tick"
+        ex["generate_32_images_per_call"] = g32
+    except Exception as e:
+        ex["generate_32_images_per_call"] = {"error": f"{type(e).__name__}: {e}"}
+        torch.cuda.empty_cache()
+    finally:
+        model.generation_config.eos_token_id = eos
     def other(name, dtype_note, steps=5, gen_name=None, **kw):
         """a line measured on another model instance (built, measured, freed); gen_name: also its greedy generate at 4 images per call.
         A failure costs this line only (the error is reported in its place), never the lines already measured."""
@@ -631,7 +648,9 @@ def extras_summary(ex):
             rf = v.get("roofline") or {}
             out[k] = [round(v["value"], 2), round(rf["frac"], 3) if "frac" in rf else None]
             if "decode_step" in v and "ms_per_token" in v["decode_step"]:
-                out[("decode_fp8" if "fp8" in k else "decode") + "_ms_per_token"] = [round(v["decode_step"]["ms_per_token"], 3), round(v["decode_step"]["frac_of_8TBps"], 3)]
+                tag = "decode_fp8" if "fp8" in k else ("decode_32_rows" if "_32_" in k else "decode")
+                fr = v["decode_step"].get("frac_of_8TBps")
+                out[tag + "_ms_per_token"] = [round(v["decode_step"]["ms_per_token"], 3), round(fr, 3) if fr is not None else None]
     return out
 
 

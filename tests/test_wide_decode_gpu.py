@@ -216,3 +216,35 @@ def test_e4m3_model_wide_step_and_batcher(dev):
     res = b.run_until_done()
     for rid, want in zip(rids, solo):
         assert res[rid].error is None and res[rid].tokens == want
+
+
+@pytest.mark.parametrize("graph", [True, False])
+def test_generate_twelve_rows_matches_oracle_greedy(dev, graph):
+    """generate() with more than 8 rows decodes on the matrix-unit weight stream: every token of 12 rows against HF-greedy over the
+    oracle (R: groma/eval/eval_rec.py:93-104 over groma/model/groma.py:176-200,376-402; the oracle consumes the device's ViT states,
+    as in tests/test_parity_gpu.py; boosted <r_k> rows keep every step's margin far outside the 16-bit error band)"""
+    from groma_amd import synth
+    from oracle import groma_oracle as O
+    cfg, sd, tk = util.tiny_setup(seed=0)
+    sd = dict(sd)
+    w = sd["extra_lm_head.weight"].clone()
+    w[w.shape[0] - 100:] *= 40.0
+    sd["extra_lm_head.weight"] = w
+    model = util.device_model(cfg, sd)
+    model.generation_config.eos_token_id = None
+    model.decode_graph = graph
+    images, ids = synth.make_inputs(cfg, tk, bs=12, seed=1239)
+    n = 4
+    torch.manual_seed(9)
+    g = model.generate(ids.clone(), images=images, max_new_tokens=n, return_dict_in_generate=True, output_hidden_states=True)
+    dev_h = [model._ws.get(f"vit_h{i}", (12, model.vit.T, model.vit.D), torch.float32).cpu() for i in range(4)]
+    torch.manual_seed(9)
+    with torch.no_grad():
+        ref = O.greedy_generate(sd, cfg.to_dict(), util.tok_dict(tk), ids.clone(), images, n, eos_token_id=-1, hidden_states=tuple(dev_h))
+    boxes = g.hidden_states[0][-1]["pred_boxes"]
+    for i in range(12):
+        assert torch.allclose(boxes[i].cpu(), ref["pred_boxes"][i], atol=1e-5)
+    P = ids.shape[1]
+    ncmp = util.assert_greedy_tokens_match(g.sequences[:, P:].cpu(), ref["sequences"][:, P:], ref["margins"], 0.05, "12-row generate")
+    print("compared", ncmp, "of", 12 * n)
+    assert ncmp >= 12 * n - 4
