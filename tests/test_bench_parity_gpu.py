@@ -42,6 +42,8 @@ def test_parity_block_of_the_benchmarked_modes_on_the_bench_inputs(dev, precisio
         if p["all_index_results_equal"]:
             assert p["logits_rel_l2"] <= r["logits_tolerance"], p          # per image: the stated tolerance of the mode
     assert not r["unexplained_images"], r                                  # a differing image is a near-tie (gap < 2 err), nothing else
-    assert r["images_with_all_index_results_equal"] >= 2                   # (91-93 % of ordinary images: profiles/r06_index_survival.txt)
+    # (91-93 % of ordinary images are fully equal: profiles/r06_index_survival.txt.  Of these four, one resolves -- equal by theorem --, one is
+    #  a near-tie that differs, two are near-ties that happen to agree and may flip with the host BLAS's blocking on another box)
+    assert r["images_with_all_index_results_equal"] >= 1
     assert r["within_tolerance"] and r["logits_rel_l2"] <= r["logits_tolerance"] and r["argmax_agree"] >= 0.9
     assert r["logits_tolerance"] == {"hybrid": 1.5e-2, "hybrid-fp16": 2e-3}[precision]
