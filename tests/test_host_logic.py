@@ -385,6 +385,19 @@ def test_graph_pool_policy(monkeypatch):
     assert "k" in fs._graphs and fs.captures == 1 and not engine.GraphPool._first_sight[0]
     fs.run("k2", mk("k2"))
     assert "k2" not in fs._graphs                                         # outside the block: third sighting again
+    # eager() (round 6): the settling pass of a warm-up launches eagerly and leaves no trace -- not even a sighting -- so the
+    # first_sight() pass after it captures on the settled addresses and no never-replayable graph sits in the LRU pool
+    n_runs = len(runs)
+    with engine.GraphPool.eager():
+        with engine.GraphPool.first_sight():                              # (eager wins over first_sight)
+            fs.run("settle", mk("settle"))
+        fs.run("settle", mk("settle"))
+    assert len(runs) == n_runs + 2 and "settle" not in fs._graphs and "settle" not in fs._seen and not engine.GraphPool._eager[0]
+    # drop(): graphs (and sighting counts) whose key bakes in memory that no longer exists are forgotten (serving._grow)
+    fs.run("k2", mk("k2"))                                                # second sighting of k2: counted, not captured
+    assert "k2" in fs._seen
+    fs.drop(lambda key: key in ("k", "k2"))
+    assert "k" not in fs._graphs and "k2" not in fs._seen and "k" not in fs._bytes
     # a launch that raises inside the capture: the capture is ended, the ORIGINAL error surfaces, nothing is kept
     def boom():
         raise RuntimeError("GR_EINVAL inside the capture")
