@@ -143,6 +143,20 @@ def _open(path, operand):
         raise RuntimeError(f"{os.path.basename(path)} ABI version mismatch")
     if lib.gr_operand_type() != operand:
         raise RuntimeError(f"{os.path.basename(path)} was built for another 16-bit operand type")
+    # The float64-accumulating proposer GEMM (csrc/gemm_f32.hip) asks the hardware once which accumulator element holds which output
+    # row of v_mfma_f64_16x16x4_f64.  Ask NOW, at load time, so that the probe (a tiny launch + a stream sync) can never fall into a
+    # hipGraph capture; an unexpected answer fails here, loudly, instead of at the first proposer launch.
+    try:
+        import torch
+        has_gpu = torch.cuda.is_available()
+    except Exception:
+        has_gpu = False
+    if has_gpu:
+        probe = getattr(lib, "gr_diag_mfma64_rowmap", None)
+        if probe is not None:
+            probe.restype = c_int
+            if probe() not in (0, 1):
+                raise RuntimeError(f"{os.path.basename(path)}: the f64 MFMA accumulator layout probe failed (csrc/gemm_f32.hip mfma64_rowmap)")
     return lib
 
 
