@@ -60,6 +60,7 @@ SIGNATURES = {
     "gr_prof_enable": [_I],
     "gr_prof_read": [_P, _P, _P],
     "gr_prof_read_launches": [_L, _P, _P, _P],
+    "gr_gemm_yield": [_I],
     "gr_gemm_bf16": [ctypes.POINTER(GemmDesc), _P],
     "gr_gemv_fused": [ctypes.POINTER(GemvDesc), _P],
     "gr_gemm_f32": [_P, _P, _P, _P, _P, _I, _I, _I, _L, _L, _L, _I, _P],

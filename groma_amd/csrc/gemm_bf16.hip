@@ -274,6 +274,12 @@ extern "C" int gr_prof_read_launches(long cap, int* mnk, float* ms, long* n_out)
   return GR_OK;
 }
 
+static thread_local int g_gemm_yield = 0;
+extern "C" int gr_gemm_yield(int on) {
+  g_gemm_yield = on != 0;
+  return GR_OK;
+}
+
 extern "C" int gr_gemm_bf16(const gr_gemm_desc* d, hipStream_t stream) {
   if (!d || (!d->A && !d->a_parts) || !d->W || (!d->C && d->tile != 2)) return GR_EINVAL;
   if (d->a_parts && ((d->tile != 1 && d->tile != 2) || d->a_nsplit < 1 || d->a_hd < 8 || d->a_hd % 8 != 0 || d->K % d->a_hd != 0))
@@ -343,6 +349,7 @@ extern "C" int gr_gemm_bf16(const gr_gemm_desc* d, hipStream_t stream) {
     if (e256 < best) { best = e256; use256 = true; pp_rows = 256; }
     if (e192 < best * PP_MARGIN) { best = e192; use256 = true; pp_rows = 192; }
   }
+  p.yield = g_gemm_yield;
   p.tiles_m = gr_cdiv(p.M, use256 ? pp_rows : BM);
   p.tiles_n = gr_cdiv(p.N, use256 ? 256 : BN);
   static bool attr_set = false;

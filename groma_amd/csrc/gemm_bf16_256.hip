@@ -464,7 +464,7 @@ int G256_LAUNCH(const GemmArgs& p, hipStream_t stream, int tile_rows) {  // tile
 #ifdef G256_NO_PERSIST  // diagnostic build (tests/diag/build_variant.py name -DG256_NO_PERSIST): one tile per workgroup
   const bool persist_off = true;
 #else
-  const bool persist_off = G256_FP8 != 0 && !G256_FP8_PERSIST;
+  const bool persist_off = (G256_FP8 != 0 && !G256_FP8_PERSIST) || p.yield != 0;
 #endif
   const int tiles = p.tiles_m * p.tiles_n;
   dim3 grid(persist_off ? tiles : (tiles < n_cu ? tiles : n_cu), p.splits);

@@ -30,6 +30,7 @@ struct GemmArgs {
   int resid_mod;
   int c_group, c_group_stride, c_row_off;
   int tiles_m, tiles_n;
+  int yield;  // ping-pong kernel: one workgroup per tile instead of the persistent grid (gr_gemm_yield)
 };
 
 // XCD-aware, L2-friendly tile order: consecutive ids on one XCD (block b runs on XCD b%8),

@@ -21,6 +21,8 @@ H16 = ops.H16  # dtype of the active 16-bit operand type (bf16 / fp16: ops.preci
 Q_IN_PLACE = True  # prefill attention reads q (and applies RoPE) straight from the fused QKV projection
 FUSED_DECODE = True  # a decode step of <= 8 rows runs on the fused weight streams (False: the general kernels -- tests compare the two)
 WIDE_DECODE = True   # a decode step of 9..64 rows runs on the matrix-unit weight stream (csrc/gemm_skinny.hip); False: the general kernels
+YIELD_PYRAMID = True  # the region pyramid's convolutions (side stream) run one workgroup per tile, so the proposer chain on the main stream is not
+                      # stalled behind multi-millisecond persistent launches (ops.gemm_yield); False: persistent grids (tests/diag A-B)
 
 
 def _ru(x, m):
@@ -492,7 +494,10 @@ class RegionEngine:
         # (0.65 GB at 14 images), the GroupNorm partial sums / coefficients and the split-K workspace of the plan-split GEMMs --
         # none of them is born inside a capture any more, so a captured batch shape pins nothing in a private graph pool
         bufs += self._fuse_temps(bs, S)
-        self.graphs.run(("fuse", bs, ops._PLAN[0]) + tuple(t.data_ptr() for t in bufs), lambda: self._fuse_launch(hidden3))
+        def launch():
+            with ops.gemm_yield(YIELD_PYRAMID):
+                self._fuse_launch(hidden3)
+        self.graphs.run(("fuse", bs, ops._PLAN[0], YIELD_PYRAMID) + tuple(t.data_ptr() for t in bufs), launch)
         return feats, S
 
     def _fuse_temps(self, bs, S):

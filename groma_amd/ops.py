@@ -183,6 +183,27 @@ class gemm_plan:
         _PLAN[0] = self.prev
 
 
+class gemm_yield:
+    """with ops.gemm_yield(): ...  -- the ping-pong GEMMs launched inside (by this thread) run one workgroup per tile instead of a
+    persistent grid, so kernels queued on other streams get CUs whenever a tile retires (include/groma_hip.h gr_gemm_yield); re-entrant"""
+    _depth = _lib.ThreadSlot(0)
+
+    def __init__(self, on=True):
+        self.on = bool(on)
+
+    def __enter__(self):
+        if self.on:
+            gemm_yield._depth[0] += 1
+            if gemm_yield._depth[0] == 1:
+                _lib.check(_lib.load().gr_gemm_yield(1), "gr_gemm_yield")
+
+    def __exit__(self, *a):
+        if self.on:
+            gemm_yield._depth[0] -= 1
+            if gemm_yield._depth[0] == 0:
+                _lib.check(_lib.load().gr_gemm_yield(0), "gr_gemm_yield")
+
+
 _SPLIT_WS = {}
 
 

@@ -54,6 +54,12 @@ int gr_operand_type(void);
 int gr_prof_enable(int on);
 int gr_prof_read(double* total_ms, long* launches, double* flops);
 int gr_prof_read_launches(long cap, int* mnk, float* ms, long* n_out);
+/* Launch geometry of the ping-pong GEMM for the CALLING THREAD's subsequent gr_gemm_bf16 launches (round 6).  The kernel normally runs
+ * as a persistent grid (one workgroup per CU walking the tile list), which holds every CU until the whole GEMM is done; on != 0 switches
+ * to one workgroup per tile, so that workgroups of kernels queued on OTHER streams are dispatched whenever a tile retires.  The path
+ * sets it around the region pyramid's convolutions (side stream), whose multi-millisecond launches otherwise stall the latency-bound
+ * proposer chain on the main stream (groma/model/groma.py:240-280 runs beside roi_align.py:180-193).  Same tiles, same bits. */
+int gr_gemm_yield(int on);
 
 /* ------------------------------------------------------------------ dense contractions (MFMA) -- */
 /* C[M,N] = epilogue(A[M,K] . W[N,K]^T).  Replaces every nn.Linear / nn.Conv2d on the path:
