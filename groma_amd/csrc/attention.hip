@@ -50,12 +50,19 @@ extern "C" int gr_diag_att_clk(unsigned long long* out) { return (int)hipMemcpyF
 #define ATT_MARK(i)
 #endif
 
+// ATT_PIPE = 1: the pipelined main loop (see the loop itself); ATT_PIPE_PRE: soft-max steps issued ahead of its first MFMA
+#ifndef ATT_PIPE
+#define ATT_PIPE 0
+#endif
+#ifndef ATT_PIPE_PRE
+#define ATT_PIPE_PRE 5
+#endif
 // (soft-max row statistics are reduced across the four 16-lane rows with rows_max / rows_sum, gr_common.h)
 #ifndef ATT_G64
 #define ATT_G64 2   // K / V^T fragments per prefetch group at head dim 64
 #endif
 #ifndef ATT_G128
-#define ATT_G128 (GR_SP ? 4 : 8)  // ... at head dim 128 (A/B: -5 % with 8; each fragment is a hi / lo pair in the split build)
+#define ATT_G128 ((GR_SP || ATT_PIPE) ? 4 : 8)  // ... at head dim 128 (A/B: -5 % with 8; each fragment is a hi / lo pair in the split build)
 #endif
 #define ATT_G (HD == 128 ? ATT_G128 : ATT_G64)
 // Split-operand build (gr_common.h): q, K, V^T and the context are (hi, lo) pairs in 32-element blocks, so a K row is 2*hd
@@ -116,6 +123,14 @@ __device__ __forceinline__ constexpr int att_step_kk(int g, int e) {
 #ifndef ATT_SUM4
 #define ATT_SUM4 0
 #endif
+
+template <int I, int N, class F>
+__device__ __forceinline__ void att_static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    att_static_for<I + 1, N>(f);
+  }
+}
 
 template <int HD>
 __global__ __launch_bounds__(256, GR_SP ? 1 : 2) void attention_kernel(AttnArgs p) {
@@ -180,10 +195,9 @@ __global__ __launch_bounds__(256, GR_SP ? 1 : 2) void attention_kernel(AttnArgs 
   const int wav_min_limit = p.causal ? min(kvmax, q_pos0 + wav_first + 1) : kvmax;  // min over the wave's rows
 
   // stage K tile (lds chunk position pos holds logical chunk pos ^ (row&7)) and Vt tile of kv tile t into buffer t&1
-  auto stage = [&](int t) {
+  auto stage_k = [&](int t) {
     const int kv0 = t * KV;
     char* ksm = smem + (t & 1) * STAGE;
-    char* vsm = ksm + KTILE;
     constexpr int NCH = KV * KCH;
 #pragma unroll
     for (int i = 0; i < NCH / 256; ++i) {
@@ -194,6 +208,10 @@ __global__ __launch_bounds__(256, GR_SP ? 1 : 2) void attention_kernel(AttnArgs 
       if (kr > Skv - 1) kr = Skv - 1;
       __builtin_amdgcn_global_load_lds((gptr_t)(Kp + (long)kr * (HD * SPW) + c * 8), (lptr_t)(ksm + i * 4096 + wave * 1024), 16, 0, 0);
     }
+  };
+  auto stage_v = [&](int t) {
+    const int kv0 = t * KV;
+    char* vsm = smem + (t & 1) * STAGE + KTILE;
     constexpr int NVC = HD * VCH;
 #pragma unroll
     for (int i = 0; i < NVC / 256; ++i) {
@@ -203,6 +221,10 @@ __global__ __launch_bounds__(256, GR_SP ? 1 : 2) void attention_kernel(AttnArgs 
       __builtin_amdgcn_global_load_lds((gptr_t)(Vp + ((long)row * p.kv_stride + kv0) * SPW + c * 8),
                                        (lptr_t)(vsm + i * 4096 + wave * 1024), 16, 0, 0);
     }
+  };
+  auto stage = [&](int t) {
+    stage_k(t);
+    stage_v(t);
   };
 
   // ATT_STAGE_FIRST: tile 0's LDS-DMA is requested BEFORE the query fragments (and their RoPE tables) are fetched, so the two
@@ -302,46 +324,35 @@ __global__ __launch_bounds__(256, GR_SP ? 1 : 2) void attention_kernel(AttnArgs 
       for (int i = 0; i < ATT_SKEW; ++i) __builtin_amdgcn_s_sleep(16);
   }
 #endif
-  for (int t = 0; t < ntiles; ++t) {
-    const int kv0 = t * KV;
-    ATT_MARK(0)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();  // tile t landed for every wave; everyone finished reading the other buffer
-    ATT_MARK(1)
-    if (t + 1 < ntiles) stage(t + 1);
-    // wave-uniform skips: every key of this tile is masked for all of this wave's rows, or the wave has no query row at all
-    // (the last query block of T = 1025 holds one row: three of its four waves only help staging the tiles)
-    if (kv0 >= wav_limit || !wave_has_rows) continue;
-    const char* ksm = smem + (t & 1) * STAGE;
-    const char* vsm = ksm + KTILE;
-
-    // ---- S^T tiles: rows = keys (4 sub-tiles of 16), col = this lane's query (per q-tile); K fragments shared
-    f32x4 s[QT][4];
+  // ---- the three pieces of an iteration (shared by the plain loop and the pipelined one, ATT_PIPE)
+  // S^T tiles: rows = keys (4 sub-tiles of 16), col = this lane's query (per q-tile); K fragments shared.
+  // K fragments are read one group AHEAD of the MFMAs that use them (double buffer, GK fragments per group): the
+  // LDS latency of the next group hides behind this group's MFMAs instead of stalling every MFMA pair
+  constexpr int GK = ATT_G;                   // fragments per group
+  constexpr int NKK = HD / 32;                // k-steps per score sub-tile
+  constexpr int NKG = 4 * NKK / GK;           // groups over (j, kk)
+  auto load_k = [&](const char* ksm, int g, bf16x8* dst) {
+#pragma unroll
+    for (int e = 0; e < GK; ++e) {
+      const int j = att_step_j<GK, NKK>(g, e), kk = att_step_kk<GK, NKK>(g, e);
+      const int row = (j >> 1) * 32 + (fr >> 2) * 8 + (j & 1) * 4 + (fr & 3);
+      dst[e] = *(const bf16x8*)(ksm + row * KROW + (((kk * 4 * SPW + fg) ^ kswz(row)) << 4));
+#if GR_SP
+      dst[GK + e] = *(const bf16x8*)(ksm + row * KROW + (((kk * 8 + 4 + fg) ^ kswz(row)) << 4));
+#endif
+    }
+  };
+  auto compute_S = [&](const char* ksm, f32x4 (&s)[QT][4]) {
 #pragma unroll
     for (int u = 0; u < QT; ++u)
 #pragma unroll
       for (int j = 0; j < 4; ++j) s[u][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    // K fragments are read one group AHEAD of the MFMAs that use them (double buffer, GK fragments per group): the
-    // LDS latency of the next group hides behind this group's MFMAs instead of stalling every MFMA pair
-    constexpr int GK = ATT_G;                   // fragments per group
-    constexpr int NKG = 4 * (HD / 32) / GK;     // groups over (j, kk)
     bf16x8 kfr[2][GK * SPW];  // split build: [.., GK + e] = lo halves
-    auto load_k = [&](int g, bf16x8* dst) {
-#pragma unroll
-      for (int e = 0; e < GK; ++e) {
-        const int j = att_step_j<GK, HD / 32>(g, e), kk = att_step_kk<GK, HD / 32>(g, e);
-        const int row = (j >> 1) * 32 + (fr >> 2) * 8 + (j & 1) * 4 + (fr & 3);
-        dst[e] = *(const bf16x8*)(ksm + row * KROW + (((kk * 4 * SPW + fg) ^ kswz(row)) << 4));
-#if GR_SP
-        dst[GK + e] = *(const bf16x8*)(ksm + row * KROW + (((kk * 8 + 4 + fg) ^ kswz(row)) << 4));
-#endif
-      }
-    };
-    load_k(0, kfr[0]);
+    load_k(ksm, 0, kfr[0]);
     ATT_MFMA_BEGIN
 #pragma unroll
     for (int g = 0; g < NKG; ++g) {
-      if (g + 1 < NKG) load_k(g + 1, kfr[(g + 1) & 1]);
+      if (g + 1 < NKG) load_k(ksm, g + 1, kfr[(g + 1) & 1]);
       __builtin_amdgcn_sched_barrier(0);
 #if GR_SP && ATT_S_ORDER
       // pair build: the three passes are the SLOW index, so an accumulator is revisited every GK * QT MFMAs, not every QT
@@ -349,7 +360,7 @@ __global__ __launch_bounds__(256, GR_SP ? 1 : 2) void attention_kernel(AttnArgs 
       for (int pp = 0; pp < 3; ++pp)
 #pragma unroll
         for (int e = 0; e < GK; ++e) {
-          const int j = att_step_j<GK, HD / 32>(g, e), kk = att_step_kk<GK, HD / 32>(g, e);
+          const int j = att_step_j<GK, NKK>(g, e), kk = att_step_kk<GK, NKK>(g, e);
 #pragma unroll
           for (int u = 0; u < QT; ++u)
             s[u][j] = GR_MFMA_16x16x32(kfr[g & 1][pp == 2 ? GK + e : e], pp == 1 ? qfl[u][kk] : qf[u][kk], s[u][j]);
@@ -357,7 +368,7 @@ __global__ __launch_bounds__(256, GR_SP ? 1 : 2) void attention_kernel(AttnArgs 
 #else
 #pragma unroll
       for (int e = 0; e < GK; ++e) {
-        const int j = att_step_j<GK, HD / 32>(g, e), kk = att_step_kk<GK, HD / 32>(g, e);
+        const int j = att_step_j<GK, NKK>(g, e), kk = att_step_kk<GK, NKK>(g, e);
 #pragma unroll
         for (int u = 0; u < QT; ++u) s[u][j] = GR_MFMA_16x16x32(kfr[g & 1][e], qf[u][kk], s[u][j]);
 #if GR_SP
@@ -371,81 +382,81 @@ __global__ __launch_bounds__(256, GR_SP ? 1 : 2) void attention_kernel(AttnArgs 
       __builtin_amdgcn_sched_barrier(0);
     }
     ATT_MFMA_END
-    ATT_MARK(2)
-    // ---- online softmax; lane holds keys kv0 + (j>>1)*32 + fg*8 + (j&1)*4 + r of query fr (per q-tile).
-    // The running max is kept in RAW score units and the softmax scale is folded into one fma per element
-    // (e = exp2(s*c - m*c)); masking (2 cmp + 2 select per element) is compiled only into boundary tiles.
-    union PB { bf16x8 v; uint32_t w[4]; };
-    PB pb[QT][2];
+  };
+  // online softmax; lane holds keys kv0 + (j>>1)*32 + fg*8 + (j&1)*4 + r of query fr (per q-tile).
+  // The running max is kept in RAW score units and the softmax scale is folded into one fma per element
+  // (e = exp2(s*c - m*c)); masking (2 cmp + 2 select per element) is compiled only into boundary tiles.
+  union PB { bf16x8 v; uint32_t w[4]; };
+  PB pb[QT][2];
 #if GR_SP
-    PB pbl[QT][2];  // lo halves of P
+  PB pbl[QT][2];  // lo halves of P
 #endif
-    const float cs = p.scale_log2;
-    auto softmax_tile = [&](auto masked_tag) {
-      constexpr bool MASKED = decltype(masked_tag)::value;
-#pragma unroll
-      for (int u = 0; u < QT; ++u) {
-        float mxp[4] = {-1e30f, -1e30f, -1e30f, -1e30f};
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            if (MASKED) {
-              const int key = kv0 + (j >> 1) * 32 + fg * 8 + (j & 1) * 4 + r;
-              if (key >= limit[u]) s[u][j][r] = -1e30f;
-            }
-            mxp[ATT_SUM4 ? j : 0] = fmaxf(mxp[ATT_SUM4 ? j : 0], s[u][j][r]);
-          }
-        float mx = fmaxf(fmaxf(mxp[0], mxp[1]), fmaxf(mxp[2], mxp[3]));
-        mx = rows_max(mx);
-        const float m_new = fmaxf(m_run[u], mx);
-        const float alpha = __builtin_amdgcn_exp2f((m_run[u] - m_new) * cs);
-        const float mc = -m_new * cs;
-        float rsp[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            // masked entries: s = -1e30 -> exp2(-huge) = 0 exactly, unless the whole row is masked so far (m_new = -1e30,
-            // argument 0): select 0 there
-            float e = __builtin_amdgcn_exp2f(__builtin_fmaf(s[u][j][r], cs, mc));
-            if (MASKED) e = s[u][j][r] <= -1e30f ? 0.f : e;
-            s[u][j][r] = e;
-            rsp[ATT_SUM4 ? j : 0] += e;
-          }
-        float rs = (rsp[0] + rsp[1]) + (rsp[2] + rsp[3]);
-        rs = rows_sum(rs);
-        l_run[u] = l_run[u] * alpha + rs;
-        m_run[u] = m_new;
-#pragma unroll
-        for (int n = 0; n < HD / 16; ++n) o[u][n] *= alpha;
-        // P^T as the B operand; k-slot (fg,e) <-> key 32*tt + fg*8 + e (standard contiguous slot)
-#pragma unroll
-        for (int tt = 0; tt < 2; ++tt) {
+  const float cs = p.scale_log2;
 #if GR_SP
 #ifdef ATT_R04_PAIR
 #define ATT_SPLIT_P split2
 #else
 #define ATT_SPLIT_P split2_unit   // (P in [0, 1]: no saturation)
 #endif
-          ATT_SPLIT_P(s[u][2 * tt][0], s[u][2 * tt][1], pb[u][tt].w[0], pbl[u][tt].w[0]);
-          ATT_SPLIT_P(s[u][2 * tt][2], s[u][2 * tt][3], pb[u][tt].w[1], pbl[u][tt].w[1]);
-          ATT_SPLIT_P(s[u][2 * tt + 1][0], s[u][2 * tt + 1][1], pb[u][tt].w[2], pbl[u][tt].w[2]);
-          ATT_SPLIT_P(s[u][2 * tt + 1][2], s[u][2 * tt + 1][3], pb[u][tt].w[3], pbl[u][tt].w[3]);
-#else
-          pb[u][tt].w[0] = pack2bf_unit(s[u][2 * tt][0], s[u][2 * tt][1]);
-          pb[u][tt].w[1] = pack2bf_unit(s[u][2 * tt][2], s[u][2 * tt][3]);
-          pb[u][tt].w[2] = pack2bf_unit(s[u][2 * tt + 1][0], s[u][2 * tt + 1][1]);
-          pb[u][tt].w[3] = pack2bf_unit(s[u][2 * tt + 1][2], s[u][2 * tt + 1][3]);
 #endif
+  // P^T of q-tile u, key half tt, as the B operand; k-slot (fg,e) <-> key 32*tt + fg*8 + e (standard contiguous slot)
+  auto pack_p = [&](f32x4 (&s)[QT][4], int u, int tt) {
+#if GR_SP
+    ATT_SPLIT_P(s[u][2 * tt][0], s[u][2 * tt][1], pb[u][tt].w[0], pbl[u][tt].w[0]);
+    ATT_SPLIT_P(s[u][2 * tt][2], s[u][2 * tt][3], pb[u][tt].w[1], pbl[u][tt].w[1]);
+    ATT_SPLIT_P(s[u][2 * tt + 1][0], s[u][2 * tt + 1][1], pb[u][tt].w[2], pbl[u][tt].w[2]);
+    ATT_SPLIT_P(s[u][2 * tt + 1][2], s[u][2 * tt + 1][3], pb[u][tt].w[3], pbl[u][tt].w[3]);
+#else
+    pb[u][tt].w[0] = pack2bf_unit(s[u][2 * tt][0], s[u][2 * tt][1]);
+    pb[u][tt].w[1] = pack2bf_unit(s[u][2 * tt][2], s[u][2 * tt][3]);
+    pb[u][tt].w[2] = pack2bf_unit(s[u][2 * tt + 1][0], s[u][2 * tt + 1][1]);
+    pb[u][tt].w[3] = pack2bf_unit(s[u][2 * tt + 1][2], s[u][2 * tt + 1][3]);
+#endif
+  };
+  auto softmax_tile = [&](auto masked_tag, f32x4 (&s)[QT][4], int kv0) {
+    constexpr bool MASKED = decltype(masked_tag)::value;
+#pragma unroll
+    for (int u = 0; u < QT; ++u) {
+      float mxp[4] = {-1e30f, -1e30f, -1e30f, -1e30f};
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          if (MASKED) {
+            const int key = kv0 + (j >> 1) * 32 + fg * 8 + (j & 1) * 4 + r;
+            if (key >= limit[u]) s[u][j][r] = -1e30f;
+          }
+          mxp[ATT_SUM4 ? j : 0] = fmaxf(mxp[ATT_SUM4 ? j : 0], s[u][j][r]);
         }
-      }
-    };
-    if (kv0 + KV <= wav_min_limit) softmax_tile(std::false_type{});  // every key of the tile visible to every row
-    else softmax_tile(std::true_type{});
-    ATT_MARK(3)
-    // ---- O^T += Vt . P^T ; Vt fragments shared by the q-tiles
-    // same for the V^T fragments: the next group's reads are issued before this group's MFMAs
+      float mx = fmaxf(fmaxf(mxp[0], mxp[1]), fmaxf(mxp[2], mxp[3]));
+      mx = rows_max(mx);
+      const float m_new = fmaxf(m_run[u], mx);
+      const float alpha = __builtin_amdgcn_exp2f((m_run[u] - m_new) * cs);
+      const float mc = -m_new * cs;
+      float rsp[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          // masked entries: s = -1e30 -> exp2(-huge) = 0 exactly, unless the whole row is masked so far (m_new = -1e30,
+          // argument 0): select 0 there
+          float e = __builtin_amdgcn_exp2f(__builtin_fmaf(s[u][j][r], cs, mc));
+          if (MASKED) e = s[u][j][r] <= -1e30f ? 0.f : e;
+          s[u][j][r] = e;
+          rsp[ATT_SUM4 ? j : 0] += e;
+        }
+      float rs = (rsp[0] + rsp[1]) + (rsp[2] + rsp[3]);
+      rs = rows_sum(rs);
+      l_run[u] = l_run[u] * alpha + rs;
+      m_run[u] = m_new;
+#pragma unroll
+      for (int n = 0; n < HD / 16; ++n) o[u][n] *= alpha;
+#pragma unroll
+      for (int tt = 0; tt < 2; ++tt) pack_p(s, u, tt);
+    }
+  };
+  // O^T += Vt . P^T ; Vt fragments shared by the q-tiles; the next group's reads are issued before this group's MFMAs
+  auto compute_PV = [&](const char* vsm) {
     constexpr int GV = ATT_G;
     constexpr int NG = 2 * (HD / 16) / GV;  // groups of GV (tt, n) steps
     bf16x8 vfr[2][GV * SPW];
@@ -496,8 +507,140 @@ __global__ __launch_bounds__(256, GR_SP ? 1 : 2) void attention_kernel(AttnArgs 
       __builtin_amdgcn_sched_barrier(0);
     }
     ATT_MFMA_END
+  };
+
+#if ATT_PIPE
+  // ---- pipelined loop (round 6): iteration t issues the score MFMAs of tile t + 1 BETWEEN the soft-max instructions of tile t, one
+  // MFMA per 16-clk matrix-pipe slot with the VALU work in its shadow (an in-order wave only overlaps the two pipes if its own
+  // instruction stream alternates them; `sched_barrier` fences pin the order -- the compiler would cluster the MFMAs otherwise),
+  // then P.V of tile t.  K is staged one tile ahead of V^T in the same two LDS stages.  Same operations in the same order per
+  // accumulator as the plain loop: bitwise-identical results (tests/diag/attn_variants.py).  Boundary tiles (masked soft-max) and
+  // the last tile run the plain pieces.
+  static_assert(!ATT_S_ORDER && !ATT_SUM4, "the pipelined loop implements the default accumulation order");
+  const int nt_w = wave_has_rows ? min(ntiles, (wav_limit + KV - 1) / KV) : 0;  // this wave computes tiles [0, nt_w)
+  auto fused = [&](const char* ksm, f32x4 (&cur)[QT][4], f32x4 (&nxt)[QT][4]) {
+    constexpr int PASSES = GR_SP ? 3 : 1;
+    constexpr int NM = 4 * NKK * PASSES * QT;  // score MFMAs of a tile
+    constexpr int NO = HD / 16;
+    // soft-max steps per q-tile: 4 max, 1 row max, 18 of the exp phase (software-pipelined over the 16 scores: the fma of score k, the
+    // exp of score k - 1 and the row-sum add of score k - 2 share a step, so a step holds no dependent pair), 1 row sum, NO rescales, 2 packs
+    constexpr int NVU = 26 + NO;
+    constexpr int NV = QT * NVU;
+    constexpr int PRE = ATT_PIPE_PRE;          // soft-max steps ahead of the first MFMA (in the shadow of the first K fragment reads)
+    bf16x8 kfr[2][GK * SPW];
+    float mx[QT], m_new[QT], alpha[QT], mc[QT], rs[QT];
+    auto valu = [&](auto kc) {
+      constexpr int k = decltype(kc)::value;
+      constexpr int u = k / NVU, q = k % NVU;
+      if constexpr (q < 4) {
+        const float m4 = fmaxf(fmaxf(cur[u][q][0], cur[u][q][1]), fmaxf(cur[u][q][2], cur[u][q][3]));
+        mx[u] = q == 0 ? fmaxf(-1e30f, m4) : fmaxf(mx[u], m4);
+      } else if constexpr (q == 4) {
+        mx[u] = rows_max(mx[u]);
+        m_new[u] = fmaxf(m_run[u], mx[u]);
+        alpha[u] = __builtin_amdgcn_exp2f((m_run[u] - m_new[u]) * cs);
+        mc[u] = -m_new[u] * cs;
+      } else if constexpr (q < 23) {
+        constexpr int x = q - 5;  // 0..17
+        if constexpr (x >= 2) {   // add of score x - 2 (in score order: the plain loop's summation order)
+          constexpr int j = (x - 2) / 4, r = (x - 2) % 4;
+          rs[u] = x == 2 ? 0.f + cur[u][j][r] : rs[u] + cur[u][j][r];
+        }
+        if constexpr (x >= 1 && x <= 16) {
+          constexpr int j = (x - 1) / 4, r = (x - 1) % 4;
+          cur[u][j][r] = __builtin_amdgcn_exp2f(cur[u][j][r]);
+        }
+        if constexpr (x <= 15) {
+          constexpr int j = x / 4, r = x % 4;
+          cur[u][j][r] = __builtin_fmaf(cur[u][j][r], cs, mc[u]);
+        }
+      } else if constexpr (q == 23) {
+        rs[u] = rows_sum(rs[u]);
+        l_run[u] = l_run[u] * alpha[u] + rs[u];
+        m_run[u] = m_new[u];
+      } else if constexpr (q < 24 + NO) {
+        o[u][q - 24] *= alpha[u];
+      } else {
+        pack_p(cur, u, q - 24 - NO);
+      }
+    };
+    auto mfma = [&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      constexpr int u = i % QT, pass = (i / QT) % PASSES, ge = i / (QT * PASSES);
+      constexpr int g = ge / GK, e = ge % GK, j = ge / NKK, kk = ge % NKK;
+      if constexpr (e == 0 && pass == 0 && u == 0 && g + 1 < NKG) load_k(ksm, g + 1, kfr[(g + 1) & 1]);
+      const f32x4 c = (kk == 0 && pass == 0) ? (f32x4){0.f, 0.f, 0.f, 0.f} : nxt[u][j];
+#if GR_SP
+      nxt[u][j] = GR_MFMA_16x16x32(kfr[g & 1][pass == 2 ? GK + e : e], pass == 1 ? qfl[u][kk] : qf[u][kk], c);
+#else
+      nxt[u][j] = GR_MFMA_16x16x32(kfr[g & 1][e], qf[u][kk], c);
+#endif
+    };
+    load_k(ksm, 0, kfr[0]);
+    __builtin_amdgcn_sched_barrier(0);
+    att_static_for<0, PRE>(valu);
+    __builtin_amdgcn_sched_barrier(0);
+    att_static_for<0, NM>([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      mfma(ic);
+      __builtin_amdgcn_sched_barrier(0);
+      att_static_for<PRE + i * (NV - PRE) / NM, PRE + (i + 1) * (NV - PRE) / NM>(valu);
+      __builtin_amdgcn_sched_barrier(0);
+    });
+  };
+  f32x4 sA[QT][4], sB[QT][4];
+  if (ntiles > 0) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();  // tile 0 landed for every wave
+    if (ntiles > 1) stage_k(1);
+    if (nt_w > 0) compute_S(smem, sA);
+  }
+  auto iter = [&](int t, f32x4 (&cur)[QT][4], f32x4 (&nxt)[QT][4]) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();  // K(t+1) and V^T(t) landed for every wave; everyone finished iteration t-1 (read K(t), V^T(t-1))
+    if (t + 2 < ntiles) stage_k(t + 2);
+    if (t + 1 < ntiles) stage_v(t + 1);
+    if (t >= nt_w) return;  // wave-uniform: every key of this tile is masked for all of this wave's rows, or it has no query row
+    const int kv0 = t * KV;
+    const char* ksm_n = smem + ((t + 1) & 1) * STAGE;
+    const char* vsm = smem + (t & 1) * STAGE + KTILE;
+    const bool unmasked = kv0 + KV <= wav_min_limit;  // every key of the tile visible to every row
+    if (ATT_PIPE == 1 && t + 1 < nt_w && unmasked) {
+      fused(ksm_n, cur, nxt);
+    } else {
+      if (t + 1 < nt_w) compute_S(ksm_n, nxt);
+      if (unmasked) softmax_tile(std::false_type{}, cur, kv0);
+      else softmax_tile(std::true_type{}, cur, kv0);
+    }
+    compute_PV(vsm);
+  };
+  for (int t = 0; t < ntiles; t += 2) {
+    iter(t, sA, sB);
+    if (t + 1 < ntiles) iter(t + 1, sB, sA);
+  }
+#else
+  for (int t = 0; t < ntiles; ++t) {
+    const int kv0 = t * KV;
+    ATT_MARK(0)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();  // tile t landed for every wave; everyone finished reading the other buffer
+    ATT_MARK(1)
+    if (t + 1 < ntiles) stage(t + 1);
+    // wave-uniform skips: every key of this tile is masked for all of this wave's rows, or the wave has no query row at all
+    // (the last query block of T = 1025 holds one row: three of its four waves only help staging the tiles)
+    if (kv0 >= wav_limit || !wave_has_rows) continue;
+    const char* ksm = smem + (t & 1) * STAGE;
+    const char* vsm = ksm + KTILE;
+    f32x4 s[QT][4];
+    compute_S(ksm, s);
+    ATT_MARK(2)
+    if (kv0 + KV <= wav_min_limit) softmax_tile(std::false_type{}, s, kv0);  // every key of the tile visible to every row
+    else softmax_tile(std::true_type{}, s, kv0);
+    ATT_MARK(3)
+    compute_PV(vsm);
     ATT_MARK(4)
   }
+#endif
 #ifdef G256_CLK
   if (threadIdx.x == 0 && blockIdx.y == 0 && blockIdx.x == 0 && HD == 128)
     for (int i = 0; i < 20; ++i) att_clk[i] = am[i];
