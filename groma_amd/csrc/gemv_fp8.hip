@@ -31,7 +31,7 @@
 #define G8_KS 512    // K bytes per slice and row (4 MFMA k-blocks of 128)
 #define G8_ROWS 16   // rows of W per group = the MFMA's 16 A rows
 #ifndef G8_WG_PER_CU
-#define G8_WG_PER_CU 3
+#define G8_WG_PER_CU 2   // (round 6: the prologue holds a whole batch of operand rows in registers beside the two slices in flight)
 #endif
 
 typedef __attribute__((ext_vector_type(8))) int g8_i32x8;
@@ -90,29 +90,44 @@ __global__ __launch_bounds__(256, G8_WG_PER_CU) void gemv_fp8_kernel(GemvFArgs p
     if (cnt > 1) load(1, wB);
   };
   int grp = blockIdx.x;
-  start_group(grp);
+  set_group(grp);
+  // The first group's two slices per wave: issued by the prologue AFTER its own first loads (below).  vmcnt retires in order, so a
+  // prologue load queued BEHIND the weight slices is not usable before every slice has landed -- in the QKV launch, where a workgroup
+  // owns exactly one group, that is the whole 50 MB burst: the round-5 kernel, which started the slices first, quantised its operand
+  // AFTER the weights had arrived instead of in their shadow (tests/diag/gemv_w8_bench.py with -DG8_DIAG_NOPRO: QKV 20.4 -> 14.5 us,
+  // down 20.3 -> 15.4, all streams of a token 2.66 -> 2.16 ms without a prologue; profiles/r06_gemv_w8_decomp.txt).  Unconditional
+  // (waves without a slice re-read the row's last block: `load` clamps) so that the compiler can COUNT the loads it may leave in flight.
+  auto first_slices = [&]() {
+#ifdef G8_FIRST_BARRIER
+    __syncthreads();  // every wave of the workgroup has issued its operand loads before any weight slice is requested
+#endif
+    load(0, wA);
+    load(1, wB);
+  };
 
   // ---- prologue: the quantised operand, once per workgroup, in the shadow of the first weight loads
   if (tid < 8) amax_u[tid] = 0u;
   __syncthreads();
-  // rows given as 16-bit values through `src(m, c)` (8 values of chunk c of row m): max, then quantise -> bytes.  Two rows at a time
-  // and every load of a pair issued before the first use: the operand is L2-resident, so a pass costs one L2 round trip per row
-  // pair, not one per chunk (the first version walked row by row, chunk by chunk: the o-proj / down-proj launches, whose operand
-  // comes this way, were SLOWER than their 16-bit twins -- 12.6 vs 11.2 us and 25.2 vs 21.5 us, profiles/r05_gemv_w8_mfma.txt)
-  auto quantise_rows = [&](auto src) {
-    constexpr int CH = 6;  // chunks of 8 per thread and row: K <= 12288
+  // rows given as 16-bit values through `src(m, c)` (8 values of chunk c of row m): max, then quantise -> bytes.  Two rows at a time,
+  // every load of a batch issued before the first use and the rows kept in registers between the max and the quantising pass: the
+  // operand is L2-resident, so a batch costs ONE L2 round trip (the first version walked row by row, chunk by chunk: the o-proj /
+  // down-proj launches, whose operand comes this way, were SLOWER than their 16-bit twins -- 12.6 vs 11.2 us and 25.2 vs 21.5 us,
+  // profiles/r05_gemv_w8_mfma.txt; round 5 re-read the rows for the second pass).  `hook` runs once, behind the first batch's loads.
+  auto quantise_rows = [&](auto src, auto hook) {
+    constexpr int CH = 6, RQ = 2;  // chunks of 8 per thread and row: K <= 12288; rows per batch (4 spill beside the weight slices)
     const int c8 = p.K >> 3;
-    for (int m0 = 0; m0 < MB; m0 += 2) {
-      bf16x8 v[2][CH];
+    auto batch = [&](int m0, auto first) {
+      bf16x8 v[RQ][CH];
 #pragma unroll
-      for (int mi = 0; mi < 2; ++mi)
+      for (int mi = 0; mi < RQ; ++mi)
 #pragma unroll
         for (int i = 0; i < CH; ++i) {
           const int c = tid + i * 256;
           v[mi][i] = (m0 + mi < p.M && c < c8) ? src(m0 + mi, c) : (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
         }
+      if (decltype(first)::value) hook();
 #pragma unroll
-      for (int mi = 0; mi < 2; ++mi) {
+      for (int mi = 0; mi < RQ; ++mi) {
         float am = 0.f;
 #pragma unroll
         for (int i = 0; i < CH; ++i)
@@ -121,20 +136,10 @@ __global__ __launch_bounds__(256, G8_WG_PER_CU) void gemv_fp8_kernel(GemvFArgs p
         am = wave_max(am);
         if (lane == 0) atomicMax(&amax_u[m0 + mi], __builtin_bit_cast(unsigned, am));
       }
-    }
-    __syncthreads();
-    if (tid < MB) xsc[tid] = fmaxf(__builtin_bit_cast(float, amax_u[tid]), 1e-20f) / 448.0f;
-    for (int m0 = 0; m0 < MB; m0 += 2) {
-      bf16x8 v[2][CH];
+      __syncthreads();
+      if (tid < RQ) xsc[m0 + tid] = fmaxf(__builtin_bit_cast(float, amax_u[m0 + tid]), 1e-20f) / 448.0f;
 #pragma unroll
-      for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-        for (int i = 0; i < CH; ++i) {
-          const int c = tid + i * 256;
-          v[mi][i] = (m0 + mi < p.M && c < c8) ? src(m0 + mi, c) : (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
-        }
-#pragma unroll
-      for (int mi = 0; mi < 2; ++mi) {
+      for (int mi = 0; mi < RQ; ++mi) {
         const float inv = 1.0f / (fmaxf(__builtin_bit_cast(float, amax_u[m0 + mi]), 1e-20f) / 448.0f);
 #pragma unroll
         for (int i = 0; i < CH; ++i) {
@@ -148,13 +153,24 @@ __global__ __launch_bounds__(256, G8_WG_PER_CU) void gemv_fp8_kernel(GemvFArgs p
           if (c < c8) *(uint2*)(xs + (long)(m0 + mi) * XLD + (c << 3)) = o;
         }
       }
-    }
+    };
+    batch(0, std::true_type{});
+#pragma unroll 1
+    for (int m0 = RQ; m0 < MB; m0 += RQ) batch(m0, std::false_type{});
     __syncthreads();
   };
-  if (p.x_mode == 0) {  // stored 16-bit activation rows (attention context, SwiGLU output): two passes over the L2-resident rows
-    quantise_rows([&](int m, int c) { return *(const bf16x8*)(p.A + (long)m * p.lda + (c << 3)); });
+#ifdef G8_DIAG_NOPRO  // (tests/diag only: what the launches cost WITHOUT the quantising prologue -- a constant operand)
+  first_slices();
+  for (int i = tid; i < MB * XLD / 4; i += 256) ((uint32_t*)xs)[i] = 0x38383838u;
+  if (tid < 8) xsc[tid] = 1.0f;
+  __syncthreads();
+  if (true) {
+#else
+  if (p.x_mode == 0) {  // stored 16-bit activation rows (attention context, SwiGLU output), L2-resident
+    quantise_rows([&](int m, int c) { return *(const bf16x8*)(p.A + (long)m * p.lda + (c << 3)); }, first_slices);
+#endif
   } else if (p.x_mode == 1) {  // x = gamma * (h * rsqrt(mean(h^2) + eps)) (HF LlamaRMSNorm), quantised straight from fp32; K <= 4096
-    constexpr int KJ = 4, RB = 2;
+    constexpr int KJ = 4, RB = 4;
     f32x4 g[KJ];
     int cc[KJ];
     bool cin[KJ];
@@ -165,13 +181,15 @@ __global__ __launch_bounds__(256, G8_WG_PER_CU) void gemv_fp8_kernel(GemvFArgs p
       cc[j] = cin[j] ? c : 0;
       g[j] = *(const f32x4*)(p.gamma + cc[j]);
     }
-#pragma unroll 1
-    for (int m0 = 0; m0 < MB; m0 += RB) {  // RB rows at a time: 16 x RB registers of h per thread (the main loop wants the rest)
+    // RB rows at a time (16 x RB registers of h per thread): one batch at 4 batch rows, two at 8 -- the second batch's loads queue
+    // behind the weight slices, which have landed by the time the first batch is done
+    auto batch = [&](int m0, auto first) {
       f32x4 hv[RB][KJ];
 #pragma unroll
       for (int mi = 0; mi < RB; ++mi)
 #pragma unroll
         for (int j = 0; j < KJ; ++j) hv[mi][j] = *(const f32x4*)(p.h + (long)min(m0 + mi, p.M - 1) * p.ldh + cc[j]);
+      if (decltype(first)::value) first_slices();
       float ss[RB];
 #pragma unroll
       for (int mi = 0; mi < RB; ++mi) {
@@ -183,7 +201,7 @@ __global__ __launch_bounds__(256, G8_WG_PER_CU) void gemv_fp8_kernel(GemvFArgs p
         }
         ss[mi] = wave_sum(ss[mi]);
       }
-      __syncthreads();
+      __syncthreads();  // (every thread has read the previous batch's maxima in stat[])
       if (lane == 0) {
 #pragma unroll
         for (int mi = 0; mi < RB; ++mi) stat[wave][mi] = ss[mi];
@@ -218,7 +236,9 @@ __global__ __launch_bounds__(256, G8_WG_PER_CU) void gemv_fp8_kernel(GemvFArgs p
         for (int j = 0; j < KJ; ++j)
           if (cin[j]) *(uint32_t*)(xs + (long)m * XLD + cc[j]) = pack4_fp8(hv[mi][j][0] * inv, hv[mi][j][1] * inv, hv[mi][j][2] * inv, hv[mi][j][3] * inv);
       }
-    }
+    };
+    batch(0, std::true_type{});
+    if constexpr (MB > RB) batch(RB, std::false_type{});
     __syncthreads();
   } else {  // x_mode 2: merge the key slices of decode_attention (slice order; rounded like its nsplit = 1 output), then quantise
     const int hd = p.a_hd, c8 = p.K >> 3;
@@ -245,8 +265,9 @@ __global__ __launch_bounds__(256, G8_WG_PER_CU) void gemv_fp8_kernel(GemvFArgs p
       }
       *(bf16x8*)(tmp16 + (long)m * p.K + k0) = pk.v;
     }
+    first_slices();  // (behind the merge's own global reads; the quantising passes below read LDS only)
     __syncthreads();
-    quantise_rows([&](int m, int c) { return *(const bf16x8*)(tmp16 + (long)m * p.K + (c << 3)); });
+    quantise_rows([&](int m, int c) { return *(const bf16x8*)(tmp16 + (long)m * p.K + (c << 3)); }, [] {});
   }
 
   const uint8_t* x_lane = xs + (long)fr * XLD + fg * 16;  // this lane's batch row (column of the product); rows >= MB read as zero
@@ -272,7 +293,11 @@ __global__ __launch_bounds__(256, G8_WG_PER_CU) void gemv_fp8_kernel(GemvFArgs p
 #pragma unroll 1
   while (true) {
     acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+#ifdef G8_DIAG_NOSTREAM  // (tests/diag only: prologue + reduction + epilogue, one slice per wave)
+    for (int i = 0; i < (cnt < 1 ? cnt : 1); i += 2) {
+#else
     for (int i = 0; i < cnt; i += 2) {
+#endif
       consume(i, wA);
       if (i + 2 < cnt) load(i + 2, wA);
       if (i + 1 < cnt) {

@@ -106,7 +106,17 @@ __global__ __launch_bounds__(256, (XG && MB == 8) ? 1 : 2) void gemv_fused_kerne
     if (cnt > 1) load(1, wB);
   };
   int grp = blockIdx.x;
-  start_group(grp);
+  set_group(grp);
+  // The first group's two slices: requested by the prologue BEHIND its own first loads.  vmcnt retires in order, so an operand load
+  // queued behind the weight slices cannot be used before every slice has landed -- rounds 4-5 started the slices first and the
+  // RMSNorm prologue then ran AFTER the weights had arrived instead of in their shadow (found on the e4m3 stream, csrc/gemv_fp8.hip;
+  // profiles/r06_gemv_w8_decomp.txt).  Unconditional (`load` clamps: a wave without a slice re-reads the row's last 16 B) so that the
+  // compiler can COUNT the loads it may leave in flight.
+  auto first_slices = [&]() {
+    load(0, wA);
+    load_x(0);
+    load(1, wB);
+  };
 
   // ---- prologue (x_mode 1 / 2), once per workgroup, in the shadow of the first weight loads
   if (!XG && p.x_mode == 1) {  // x = f16(gamma * (h * rsqrt(mean(h^2) + eps)))  (HF LlamaRMSNorm), 4 batch rows at a time
@@ -124,13 +134,13 @@ __global__ __launch_bounds__(256, (XG && MB == 8) ? 1 : 2) void gemv_fused_kerne
         cc[j] = cin[j] ? c : 0;
         g[j] = *(const f32x4*)(p.gamma + cc[j]);
       }
-#pragma unroll 1
-      for (int m0 = 0; m0 < MB; m0 += 4) {
+      auto chunk = [&](int m0, auto first) {
         f32x4 hv[4][KJ];
 #pragma unroll
         for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
           for (int j = 0; j < KJ; ++j) hv[mi][j] = *(const f32x4*)(p.h + (long)min(m0 + mi, p.M - 1) * p.ldh + cc[j]);
+        if (decltype(first)::value) first_slices();
         float ss[4];
 #pragma unroll
         for (int mi = 0; mi < 4; ++mi) {
@@ -161,8 +171,12 @@ __global__ __launch_bounds__(256, (XG && MB == 8) ? 1 : 2) void gemv_fused_kerne
             if (cin[j]) *(uint2*)(xs + (long)m * p.K + cc[j]) = pk;
           }
         }
-      }
+      };
+      chunk(0, std::true_type{});
+#pragma unroll 1
+      for (int m0 = 4; m0 < MB; m0 += 4) chunk(m0, std::false_type{});
     } else {
+      first_slices();
       for (int m = 0; m < MB; ++m) {  // wide rows (K > 4096): statistics pass, then a second read of the row
         float ss = 0.f;
         if (m < p.M)
@@ -187,6 +201,7 @@ __global__ __launch_bounds__(256, (XG && MB == 8) ? 1 : 2) void gemv_fused_kerne
     }
     __syncthreads();
   } else if (!XG && p.x_mode == 2) {  // merge the key slices of decode_attention (slice order; rounded like its nsplit = 1 output)
+    first_slices();
     const int hd = p.a_hd, c8 = p.K >> 3;
     for (int idx = tid; idx < MB * c8; idx += 256) {
       const int m = idx / c8, k0 = (idx - m * c8) << 3;
@@ -212,6 +227,8 @@ __global__ __launch_bounds__(256, (XG && MB == 8) ? 1 : 2) void gemv_fused_kerne
       *(bf16x8*)(xs + (long)m * p.K + k0) = pk.v;
     }
     __syncthreads();
+  } else {
+    first_slices();
   }
 
   float acc[ROWS][MB];

@@ -2,6 +2,7 @@
     python tests/diag/gemv_w8_bench.py [M=4] [tag]"""
 import sys, os, statistics, torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__))); import _variant; _variant.use_env()   # GROMA_HIP_LIB=<build> for an A/B
 from groma_amd import ops, weights
 
 M = int(sys.argv[1]) if len(sys.argv) > 1 else 4
