@@ -407,7 +407,9 @@ extern "C" int gr_gemv_fused(const gr_gemv_desc* d, hipStream_t stream) {
     n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   }
   const int groups = gr_cdiv(d->N, ROWS);
-  const dim3 grid(groups < GF_WG_PER_CU * n_cu ? groups : GF_WG_PER_CU * n_cu);  // persistent over row groups
+  // persistent over row groups.  (An even split -- grid = groups / rounds -- was measured in round 6: the e4m3 stream gains from it,
+  // gemv_fp8.hip; here gate/up loses 35.5 -> 38.1 us at 4 rows, profiles/r06_gemv_grid.txt.)
+  const dim3 grid(groups < GF_WG_PER_CU * n_cu ? groups : GF_WG_PER_CU * n_cu);
   if (w8) {  // e4m3 weights: the MFMA stream (gemv_fp8.hip)
     if (d->epi == 3 && d->HD % 32 != 0) return GR_EINVAL;
     const int prof8 = gr_prof_begin(stream, d->M, d->N, d->K, 8 | 16 | 32);
