@@ -13,6 +13,11 @@ a step -- so the MI355X design batches the decode steps of *different requests*:
   * the requests admitted in one tick are prefilled TOGETHER (one batched forward into a staging cache, then each row's KV is moved
     to its slot).  Every kernel of the path is row- / image-independent, so a row of that batch is bit-identical to a batch-1
     `GromaModel.forward` of the same request (tests/test_fullsize_properties_gpu.py) and independent of its company;
+  * with `overlap_admission=True` (round 6) that prefill runs on a worker thread and a stream of its own while the decode ticks of
+    the live rows go on: the prefill is compute-bound, the ticks stream weights, and the two share the chip (measured,
+    profiles/r06_overlap_probe.txt: the same work finishes 1.12-1.16x sooner, and a live row waits <= 15 ms for its next token
+    during an admission instead of the whole 50 ms prefill).  The rows join at the first tick after their prefill has finished;
+    a request's tokens are the same either way (rows are independent);
   * every decode step advances ALL occupied rows with one captured hipGraph: per-row positions live on the device
     (`pos_dev`, stride 1 -- csrc/decode.hip), idle rows are masked, the host only reads back the `max_rows` new ids;
   * rows are computed independently by every kernel of the step (GEMV rows, per-(row, head) attention), so a
@@ -21,6 +26,7 @@ a step -- so the MI355X design batches the decode steps of *different requests*:
 Ragged lengths are exact here: each row attends to its own [0, pos] -- the padded-prefix artefact of batched HF
 generate cannot occur because rows are never padded against each other.
 """
+import threading
 from collections import deque
 from dataclasses import dataclass, field
 from typing import List, Optional
@@ -107,7 +113,7 @@ class _RowView:
 
 class ContinuousBatcher:
     @engine.model_entry(lambda self, *a, **kw: (a[0] if a else kw["model"]).precision)
-    def __init__(self, model, max_rows=8, max_len=1024, use_graph=True, grow_to=None):
+    def __init__(self, model, max_rows=8, max_len=1024, use_graph=True, grow_to=None, overlap_admission=None):
         if max_rows < 1 or max_rows > 64:
             raise ValueError("max_rows must be in 1..64 (1..8: the fused 8-row weight streams; 9..64: the matrix-unit weight streams, "
                              "csrc/gemm_skinny.hip / gemm_skinny_fp8.hip -- single-type 16-bit or e4m3 models; others fall back to the general kernels)")
@@ -138,6 +144,14 @@ class ContinuousBatcher:
         self.seed = torch.zeros((max_rows,), dtype=I64, device=dev)       # per-row sampler seed
         self.graph = None
         self.steps = 0
+        # overlapped admission: at most ONE prefill in flight (there is one staging cache), on `_side`; `_placed` orders the next
+        # prefill's writes into the staging cache behind the previous batch's move into the arena
+        if overlap_admission and not use_graph:
+            raise ValueError("overlap_admission needs the captured decode step (use_graph=True): the eager step shares workspaces with the prefill")
+        self.overlap = bool(use_graph if overlap_admission is None else overlap_admission)   # default: on whenever the step is a graph
+        self._job = None
+        self._side = torch.cuda.Stream(device=dev) if self.overlap else None
+        self._placed = None
 
     # ------------------------------------------------------------------ admission-time warm-up
     @engine.model_entry(lambda self, *a, **kw: self.model.precision)
@@ -159,9 +173,10 @@ class ContinuousBatcher:
         # first pass EAGER: the workspace arenas grow to their working size and every kernel has had its first launch (lazy
         # function attributes, module load) -- a graph captured on this pass would be keyed on pre-growth addresses, never be
         # replayed, and sit in the LRU pools evicting useful ones.  Second pass: capture, on the settled addresses.
-        with engine.GraphPool.eager():
+        # (overlapped admissions launch their GEMMs one workgroup per tile, ops.gemm_yield: capture that form)
+        with engine.GraphPool.eager(), ops.gemm_yield(self.overlap):
             once()
-        with engine.GraphPool.first_sight():
+        with engine.GraphPool.first_sight(), ops.gemm_yield(self.overlap):
             once()
 
     # ------------------------------------------------------------------ request intake
@@ -250,19 +265,28 @@ class ContinuousBatcher:
                 t.copy_(v)
         return True
 
+    def _grow_for(self, reqs):
+        if self.max_len < self.grow_to:
+            # (_bound is a worst case -- the real spliced length is only known after the prefill -- so a request that would just
+            #  have fitted can trigger a growth; the alternative, prefilling first and re-admitting, costs a second prefill)
+            need = max(self._bound(r) for r in reqs)
+            if need > self.max_len:
+                self._grow(need)   # False: the old caches stay; the length checks of the prefill refuse what does not fit
+
     # ------------------------------------------------------------------ admission: one batched prefill per tick
     def _admit(self, reqs):
         """Prefill `reqs` (<= free slots) in ONE forward and move each row's KV into its slot.  Row results of the
         prefill are bit-identical to a batch-1 forward of the same request (every kernel of the path is row- /
         image-independent, tests/test_fullsize_properties_gpu.py), so admission order and company never change a
         request's tokens; each request's region shuffle draws from its own seed."""
+        self._grow_for(reqs)
+        self._place(reqs, self._prefill(reqs))
+
+    def _prefill(self, reqs):
+        """The device half of an admission, on the CURRENT stream: one batched forward into the staging cache + each row's first token.
+        Returns [(request, staging row, first token, 1/temperature)] for the requests that go on; touches neither the slot table nor
+        the arena nor the loop state (with overlap_admission it runs on the worker thread while the decode ticks use those)."""
         m, k = self.model, len(reqs)
-        if self.max_len < self.grow_to:
-            # (_bound is a worst case -- the real spliced length is only known after the prefill -- so a request that would just
-            #  have fitted can trigger a growth; the alternative, prefilling first and re-admitting, costs a second prefill)
-            need = max(self._bound(r) for r in reqs)
-            if need > self.max_len:
-                self._grow(need)   # False: the old caches stay; the length checks below refuse what does not fit
         P = max(r.input_ids.numel() for r in reqs)
         ids = torch.full((k, P), int(m.pad_token_id), dtype=I64)
         for i, r in enumerate(reqs):
@@ -278,12 +302,23 @@ class ContinuousBatcher:
         except RuntimeError as e:
             if k == 1:
                 reqs[0].done, reqs[0].error = True, str(e)
-                return
-            for r in reqs:  # isolate the offender: admit one by one
-                self._admit([r])
-            return
+                return []
+            # isolate the offender: one by one.  Each survivor's KV must be in ITS OWN staging row when the batch is placed, and a
+            # batch-1 prefill lands in row 0 -- so the survivors are moved to their rows as they come
+            placed = []
+            for i in range(k - 1, -1, -1):   # (last to first: row 0 is where every batch-1 prefill lands, so its own request goes last)
+                one = self._prefill([reqs[i]])
+                if one:
+                    if i:
+                        for l in range(len(self.staging.k)):
+                            self.staging.k[l][i].copy_(self.staging.k[l][0])
+                            self.staging.vt[l][i].copy_(self.staging.vt[l][0])
+                    placed.append((reqs[i], i, one[0][2], one[0][3]))
+            placed.reverse()
+            return placed
         lengths = m._last_aux["lengths"]
-        rows, slots = [], []
+        placed = []
+        dev = self.tok.device
         for i, r in enumerate(reqs):
             r.prompt_len = int(lengths[i])
             r.pred_boxes = out.hidden_states[1]["pred_boxes"][i]
@@ -291,11 +326,18 @@ class ContinuousBatcher:
                 r.done, r.error = True, "prompt + max_new_tokens exceeds the KV slot (max_len)"
                 continue
             it = 0.0 if r.temperature < 1e-4 else 1.0 / r.temperature
-            dev = self.tok.device
             first = int(ops.sample_rows(out.logits[i, r.prompt_len - 1][None].contiguous(), out.logits.shape[-1],
                                         torch.tensor([it], dtype=F32, device=dev),
                                         torch.tensor([int(r.seed or 0)], dtype=I64, device=dev),
                                         pos=torch.tensor([r.prompt_len], dtype=I32, device=dev))[0])
+            placed.append((r, i, first, it))
+        return placed
+
+    def _place(self, reqs, placed):
+        """The host half of an admission, on the decode stream between two ticks: emit the first tokens, hand out slots, move the rows'
+        KV from the staging cache into the arena, arm the loop state."""
+        rows, slots = [], []
+        for r, i, first, it in placed:
             self._emit(r, first)
             if r.done:
                 continue
@@ -314,6 +356,54 @@ class ContinuousBatcher:
             for l in range(len(self.arena.k)):
                 self.arena.k[l].index_copy_(0, dst, self.staging.k[l].index_select(0, src))
                 self.arena.vt[l].index_copy_(0, dst, self.staging.vt[l].index_select(0, src))
+
+    # ------------------------------------------------------------------ overlapped admission (worker thread + side stream)
+    def _launch_admission(self, reqs):
+        """start the prefill of `reqs` on the worker thread; the caller has made sure no other one is in flight"""
+        job = {"reqs": reqs, "placed": [], "done": threading.Event(), "event": None, "error": None}
+        if self._placed is not None:
+            self._side.wait_event(self._placed)   # the previous batch has left the staging cache
+        else:
+            self._side.wait_stream(torch.cuda.current_stream())
+
+        job["thread"] = threading.Thread(target=self._admission_work, args=(job,), name="groma-admission", daemon=True)
+        self._job = job
+        job["thread"].start()
+
+    @engine.model_entry(lambda self, *a, **kw: self.model.precision)
+    def _admission_work(self, job):
+        """worker thread: the operand type, no-grad mode, current stream and GEMM grid form are all per thread"""
+        try:
+            with torch.cuda.stream(self._side), ops.gemm_yield():   # (one workgroup per GEMM tile: the ticks' kernels get CUs as tiles retire)
+                job["placed"] = self._prefill(job["reqs"])
+                ev = torch.cuda.Event()
+                ev.record(self._side)
+                job["event"] = ev
+        except BaseException as e:   # never leave the batcher waiting for a job that died
+            job["error"] = e
+        finally:
+            job["done"].set()
+
+    def _finish_admission(self, wait=False):
+        """place the rows of a finished prefill (wait=True: block until it has finished).  Returns the admission events."""
+        job = self._job
+        if job is None or not (wait or job["done"].is_set()):
+            return []
+        job["done"].wait()
+        job["thread"].join()
+        self._job = None
+        if job["error"] is not None:
+            for r in job["reqs"]:
+                if not r.done:
+                    r.done, r.error = True, f"admission failed: {job['error']}"
+            if not isinstance(job["error"], Exception):
+                raise job["error"]
+        else:
+            torch.cuda.current_stream().wait_event(job["event"])
+            self._place(job["reqs"], job["placed"])
+            self._placed = torch.cuda.Event()
+            self._placed.record(torch.cuda.current_stream())
+        return [(r.rid, r.tokens[-1] if r.tokens else None, r.done) for r in job["reqs"]]
 
     def _emit(self, r, token):
         r.tokens.append(token)
@@ -339,7 +429,15 @@ class ContinuousBatcher:
                 raise RuntimeError("capture must precede the first admission")
             self._capture()
         events = []
-        if self.queue and self.slots.n_free:
+        if self.overlap:
+            events += self._finish_admission()
+            if self._job is None and self.queue and self.slots.n_free:
+                batch = [self.queue.popleft() for _ in range(min(len(self.queue), self.slots.n_free))]
+                self._grow_for(batch)
+                self._launch_admission(batch)
+            if self._job is not None and not self.slots.active():
+                events += self._finish_admission(wait=True)   # nothing to decode meanwhile: wait for the rows
+        elif self.queue and self.slots.n_free:
             batch = [self.queue.popleft() for _ in range(min(len(self.queue), self.slots.n_free))]
             self._admit(batch)
             for r in batch:
@@ -361,7 +459,7 @@ class ContinuousBatcher:
 
     def run_until_done(self, max_steps=100000):
         for _ in range(max_steps):
-            if not self.queue and not self.slots.active():
+            if not self.queue and not self.slots.active() and self._job is None:
                 break
             self.step()
         return {rid: r for rid, r in self.live.items()}

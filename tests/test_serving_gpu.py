@@ -107,6 +107,41 @@ def test_rows_are_independent_of_batch_composition(setup, use_graph):
         assert res[rid].tokens == want
 
 
+def test_overlapped_admission_changes_no_token(setup):
+    """overlap_admission=True (round 6): the admission prefill runs on a worker thread and a stream of its own while the live rows keep
+    decoding; rows join at the first tick after their prefill.  Rows are independent, so every request's tokens equal the
+    non-overlapped batcher's -- all at once (slot reuse, several admission waves) and with staggered arrival (admissions in the middle of
+    live traffic); an over-long request inside a wave is refused without disturbing its companions; the scheduler drains and frees
+    every slot.  (R: groma/serve/model_worker.py:287-338 serves one request at a time.)"""
+    from groma_amd.serving import ContinuousBatcher
+    cfg, model, reqs = setup
+    plain = ContinuousBatcher(model, max_rows=2, max_len=1024, overlap_admission=False)
+    rids = [plain.submit(ids, image, max_new_tokens=n, seed=seed) for ids, image, n, seed in reqs]
+    want = [plain.run_until_done()[r].tokens for r in rids]
+    for rep in range(2):   # (twice: the second pass replays what the first one captured)
+        b = ContinuousBatcher(model, max_rows=2, max_len=1024, overlap_admission=True)
+        rids = [b.submit(ids, image, max_new_tokens=n, seed=seed) for ids, image, n, seed in reqs]
+        big = b.submit(reqs[0][0], reqs[0][1], max_new_tokens=4000, seed=1)   # refused: prompt + 4000 > max_len
+        res = b.run_until_done()
+        assert [res[r].tokens for r in rids] == want
+        assert all(res[r].error is None and res[r].done for r in rids)
+        assert res[big].error is not None and res[big].done
+        assert b.slots.n_free == 2 and b._job is None
+    b = ContinuousBatcher(model, max_rows=4, max_len=1024, overlap_admission=True)
+    rids = []
+    ticks_with_prefill_in_flight = 0
+    for ids, image, n, seed in reqs:
+        rids.append(b.submit(ids, image, max_new_tokens=n, seed=seed))
+        for _ in range(2):
+            b.step()
+            ticks_with_prefill_in_flight += int(b._job is not None and bool(b.slots.active()))
+    res = b.run_until_done()
+    assert [res[r].tokens for r in rids] == want
+    assert b.slots.n_free == 4 and b._job is None
+    with pytest.raises(ValueError):
+        ContinuousBatcher(model, max_rows=2, max_len=1024, use_graph=False, overlap_admission=True)
+
+
 def test_eos_stop_and_oversize_rejection(setup):
     from groma_amd.serving import ContinuousBatcher
     cfg, model, reqs = setup
