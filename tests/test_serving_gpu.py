@@ -142,6 +142,71 @@ def test_overlapped_admission_changes_no_token(setup):
         ContinuousBatcher(model, max_rows=2, max_len=1024, use_graph=False, overlap_admission=True)
 
 
+@pytest.mark.parametrize("overlap", [False, True])
+def test_a_failing_request_is_isolated_from_its_admission_wave(setup, overlap):
+    """three requests admitted in ONE prefill, the middle one making the forward raise: the batched forward raises, the
+    wave is re-run one by one, the offender is refused with its error and its companions' tokens are what they are alone (each
+    survivor's KV has to end up in its own staging row although every batch-1 prefill lands in row 0)."""
+    from groma_amd.serving import ContinuousBatcher
+    cfg, model, reqs = setup
+    solo = []
+    for ids, image, n, seed in (reqs[0], reqs[2]):
+        b = ContinuousBatcher(model, max_rows=4, max_len=1024)
+        rid = b.submit(ids, image, max_new_tokens=n, seed=seed)
+        solo.append(b.run_until_done()[rid].tokens)
+    orig = model.forward
+
+    def poisoned(*a, **kw):   # (a request the model cannot serve, whatever the reason: here its seed)
+        if 666 in (kw.get("_seeds") or []):
+            raise RuntimeError("poisoned request")
+        return orig(*a, **kw)
+    model.forward = poisoned
+    try:
+        b = ContinuousBatcher(model, max_rows=4, max_len=1024, overlap_admission=overlap, admit_min=1)
+        a = b.submit(reqs[0][0], reqs[0][1], max_new_tokens=reqs[0][2], seed=reqs[0][3])
+        bad = b.submit(reqs[1][0], reqs[1][1], max_new_tokens=5, seed=666)
+        c = b.submit(reqs[2][0], reqs[2][1], max_new_tokens=reqs[2][2], seed=reqs[2][3])
+        res = b.run_until_done()
+    finally:
+        del model.forward
+    assert res[bad].done and "poisoned" in res[bad].error and not res[bad].tokens
+    assert res[a].error is None and res[c].error is None
+    assert [res[a].tokens, res[c].tokens] == solo
+    assert b.slots.n_free == 4
+
+
+def test_admission_hold_policy(setup):
+    """admit_min / admit_hold: while rows are live an admission waits until `admit_min` requests can share one prefill (or the queue
+    holds fewer), at most `admit_hold` ticks; tokens do not depend on it"""
+    from groma_amd.serving import ContinuousBatcher
+    cfg, model, reqs = setup
+    want = []
+    for ids, image, n, seed in reqs[:3]:
+        b = ContinuousBatcher(model, max_rows=2, max_len=1024)
+        rid = b.submit(ids, image, max_new_tokens=n, seed=seed)
+        want.append(b.run_until_done()[rid].tokens)
+    b = ContinuousBatcher(model, max_rows=2, max_len=1024, overlap_admission=False, admit_min=2, admit_hold=3)
+    r0 = b.submit(reqs[0][0], reqs[0][1], max_new_tokens=reqs[0][2], seed=reqs[0][3])   # 6 tokens
+    b.step()                                  # idle batcher: admitted at once although it is alone
+    assert b.slots.n_free == 1
+    r1 = b.submit(reqs[1][0], reqs[1][1], max_new_tokens=reqs[1][2], seed=reqs[1][3])
+    b.step()
+    assert b.slots.n_free == 0                # a queue of ONE is never held
+    r2 = b.submit(reqs[2][0], reqs[2][1], max_new_tokens=reqs[2][2], seed=reqs[2][3])
+    r3 = b.submit(reqs[0][0], reqs[0][1], max_new_tokens=4, seed=reqs[0][3])
+    held = 0
+    while b.live[r0].done is False:
+        b.step()
+    assert b.slots.n_free == 1 and len(b.queue) == 2      # r0 has left; r2 / r3 wait for a second slot ...
+    for _ in range(3):
+        b.step(); held += int(len(b.queue) == 2)
+    assert held == 3
+    b.step()
+    assert len(b.queue) == 1                              # ... for admit_hold ticks, then one goes in alone
+    res = b.run_until_done()
+    assert [res[r0].tokens, res[r1].tokens, res[r2].tokens] == want and res[r3].tokens == want[0][:4]
+
+
 def test_eos_stop_and_oversize_rejection(setup):
     from groma_amd.serving import ContinuousBatcher
     cfg, model, reqs = setup
