@@ -58,7 +58,8 @@ int gr_prof_read_launches(long cap, int* mnk, float* ms, long* n_out);
  * as a persistent grid (one workgroup per CU walking the tile list), which holds every CU until the whole GEMM is done; on != 0 switches
  * to one workgroup per tile, so that workgroups of kernels queued on OTHER streams are dispatched whenever a tile retires.  The path
  * sets it around the region pyramid's convolutions (side stream), whose multi-millisecond launches otherwise stall the latency-bound
- * proposer chain on the main stream (groma/model/groma.py:240-280 runs beside roi_align.py:180-193).  Same tiles, same bits. */
+ * proposer chain on the main stream (groma/model/groma.py:240-280 runs beside roi_align.py:180-193), and the serving loop around
+ * an admission prefill that shares the GPU with the decode ticks of live rows (groma_amd/serving.py).  Same tiles, same bits. */
 int gr_gemm_yield(int on);
 
 /* ------------------------------------------------------------------ dense contractions (MFMA) -- */
