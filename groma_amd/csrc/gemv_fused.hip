@@ -119,6 +119,13 @@ __global__ __launch_bounds__(256, (XG && MB == 8) ? 1 : 2) void gemv_fused_kerne
   };
 
   // ---- prologue (x_mode 1 / 2), once per workgroup, in the shadow of the first weight loads
+#ifdef GF_DIAG_NOPRO  // (tests/diag only: what the launches cost WITHOUT the normalising prologue -- a constant operand)
+  if (!XG && p.x_mode == 1) {
+    first_slices();
+    for (int i = tid; i < MB * p.K / 2; i += 256) ((uint32_t*)xs)[i] = 0x38003800u;
+    __syncthreads();
+  } else
+#endif
   if (!XG && p.x_mode == 1) {  // x = f16(gamma * (h * rsqrt(mean(h^2) + eps)))  (HF LlamaRMSNorm), 4 batch rows at a time
     constexpr int KJ = 4;      // float4 per thread and row held in registers (K <= 4096); wider rows take the two-pass form below
     if (p.K <= KJ * 1024) {
