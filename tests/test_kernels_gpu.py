@@ -48,6 +48,34 @@ def test_gemm_plain(dev, M, N, K, tile):
     assert torch.equal(out16, ops.gemm(a, w, tile=192))
 
 
+def test_gemm_yield_grid_is_per_thread_and_changes_no_bit(dev):
+    """gr_gemm_yield (round 6): the ping-pong GEMM as one workgroup per tile instead of a persistent grid -- same tiles, same bits, for
+    the plain and the implicit-conv forms; the switch is per thread (the serving loop's admission worker uses it beside a decode thread
+    that must not see it) and nests."""
+    import threading
+    ops = _ops()
+    a = rnd((2328, 1024), dev, seed=1).bfloat16()
+    w = rnd((1536, 1024), dev, seed=2).bfloat16()
+    res = rnd((2328, 1536), dev, seed=3)
+    base = ops.gemm(a, w, tile=256)
+    base_r = ops.gemm(a, w, resid=res, out_f32=True, tile=256)
+    lib = ops._lib.load()
+    with ops.gemm_yield():
+        with ops.gemm_yield():          # nests: the flag stays on until the outer block ends
+            assert torch.equal(ops.gemm(a, w, tile=256), base)
+        assert lib.gr_gemm_yield(1) == 0
+        assert torch.equal(ops.gemm(a, w, resid=res, out_f32=True, tile=256), base_r)
+        assert torch.equal(ops.gemm(a, w, tile=192), base)
+        seen = []
+        t = threading.Thread(target=lambda: seen.append(ops.gemm_yield._depth[0]))
+        t.start(); t.join()
+        assert seen == [0]              # another thread's launches keep the persistent grid
+    assert ops.gemm_yield._depth[0] == 0
+    with ops.gemm_yield(False):         # a disabled block is a no-op
+        assert ops.gemm_yield._depth[0] == 0
+    assert torch.equal(ops.gemm(a, w, tile=256), base)
+
+
 @pytest.mark.parametrize("M,N,K", [(8148, 4096, 4096), (582, 4096, 11008), (512, 256, 1280), (300, 512, 1216), (1000, 768, 2048)])
 def test_gemm_fp32_residual_large_shapes(dev, M, N, K):
     """C(f32) = A.W^T + R(f32) at the LLaMA o-proj / down-proj shapes on the persistent 256x256 kernel (several tiles per
