@@ -711,6 +711,9 @@ def main():
                          "reduced depth: N = 1, rank 0, after the timed region)")
     ap.add_argument("--no-traffic", action="store_true",
                     help="skip the live rocprofv3 PMC passes for roofline.traffic (the committed profiles/ summary is reported instead)")
+    ap.add_argument("--generate-traffic", action="store_true",
+                    help="--mode generate: also run the rocprofv3 PMC passes for the stream kernel's traffic (OFF by default: the profiler crashes or hangs "
+                         "on the generate run on this image -- round 6 lost two 5-minute timeouts to it; the round-5 figure stands: 103.7 MB per launch against 102.5 algorithmic)")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the `extras` block (1 and 4 images per call, greedy generate, e4m3 operands: measured after the "
                          "headline's timed region, N = 1 only)")
@@ -884,7 +887,7 @@ def main():
         out["config"]["new_tokens"] = args.new_tokens
         ach = gv_bytes / (gv_ms * 1e-3) / 1e9 if gv_ms > 0 else 0.0
         gv_traffic = None
-        if rank == 0 and world == 1 and not args.no_traffic and args.config == "7b" and not fp8:
+        if rank == 0 and world == 1 and not args.no_traffic and args.generate_traffic and args.config == "7b" and not fp8:
             # FETCH_SIZE / WRITE_SIZE of the fused weight-streaming kernel, per launch, from two rocprofv3 --pmc child runs of this
             # command (the decode steps are graph replays there; the counters see the same kernels)
             gv_traffic = measure_traffic(args.batch, "gemv_fused_kernel", ["--mode", "generate", "--new-tokens", str(args.new_tokens),

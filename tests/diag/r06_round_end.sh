@@ -7,6 +7,7 @@ t0=$(date +%s)
 (timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 --gemm-breakdown $O/gemm_shapes_b14.txt > $O/bench.json 2> $O/bench.err)
 echo "wall seconds: $(( $(date +%s) - t0 ))" > $O/bench_wall.txt
 (timeout 400 python tests/serve_bench.py > $O/serve_bench.txt 2>&1)
+(timeout 400 python tests/serve_bench.py --rows 8,16,32 --requests 64 --ragged > $O/serve_bench_ragged.txt 2>&1)
 (timeout 300 python bench.py --mode generate --batch 4 --steps 3 --warmup 2 --no-cpu-baseline --no-parity > $O/bench_gen.json 2>$O/bench_gen.err)
 cd /tmp && export TMPDIR=/tmp
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/prof_fwd -o fwd -- python $R/bench.py --no-cpu-baseline --no-traffic --no-extras --no-parity --steps 5 --warmup 3 > $R/$O/bench_prof.json 2>/dev/null
