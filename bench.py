@@ -154,7 +154,7 @@ def measure_traffic(batch, kernel="gemm_bf16_256_kernel", extra=()):
             cmd = ["rocprofv3", "--pmc", ctr, "--kernel-trace", "--output-format", "csv", "-d", out, "--", sys.executable,
                    os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "1", "--batch", str(batch), "--no-cpu-baseline",
                    "--no-traffic", "--no-extras", "--no-prefill-graphs"] + list(extra)   # (eager launches: no graph set-up passes under the profiler)
-            subprocess.run(cmd, cwd="/tmp", env=env, timeout=420, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=True)
+            subprocess.run(cmd, cwd="/tmp", env=env, timeout=150, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=True)
             tot, n = 0.0, 0
             for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
                 for r in csv.DictReader(open(f)):
