@@ -154,7 +154,18 @@ def measure_traffic(batch, kernel="gemm_bf16_256_kernel", extra=()):
             cmd = ["rocprofv3", "--pmc", ctr, "--kernel-trace", "--output-format", "csv", "-d", out, "--", sys.executable,
                    os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "1", "--batch", str(batch), "--no-cpu-baseline",
                    "--no-traffic", "--no-extras", "--no-prefill-graphs"] + list(extra)   # (eager launches: no graph set-up passes under the profiler)
-            subprocess.run(cmd, cwd="/tmp", env=env, timeout=150, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=True)
+            # own process group: on a timeout the profiler AND the python under it are ended (exactly the group started here), so a hung
+            # pass can neither outlive this call nor keep the GPU busy under the timed steps that follow
+            proc = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, start_new_session=True)
+            try:
+                rc = proc.wait(timeout=150)   # (normally ~25 s)
+            except subprocess.TimeoutExpired:
+                import signal
+                os.killpg(proc.pid, signal.SIGKILL)
+                proc.wait()
+                return None
+            if rc != 0:
+                return None
             tot, n = 0.0, 0
             for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
                 for r in csv.DictReader(open(f)):
