@@ -150,16 +150,20 @@ def _gemv_ws(splits, M, N, device):
 #   "throughput" (default): never split.  The benchmark's 14 images per GPU fill the chip with whole tiles.
 #   "latency": splits = f(N, K) -- the factor that fills the 512 tile slots of the 128x128 kernel for ONE request-sized row
 #              block (640 rows: a 582-token prompt, a 1025-token ViT image rounds to the same factor), applied at every M.
-#              One image per call: 39 -> 47 img/s (o-proj / down-proj / ViT fc2 / bridge leave most CUs idle otherwise); at
+#              One image per call: 39 -> 47 img/s (o-proj / down-proj / ViT fc2 / bridge leave most CUs idle otherwise; in the operand-pair
+#              build K counts PHYSICAL k-values, so the hybrid ViT's K = 1024 GEMMs split in two: 43.4 -> 44.3 img/s, round 6); at
 #              large M it costs the partial-sum traffic, which is why it is a plan the CALLER picks (GromaModel.gemm_plan),
 #              not something inferred from the batch.
 _PLAN = _lib.ThreadSlot("throughput")  # per thread, like the operand type (groma_amd/_lib.py)
 _PLAN_REF_ROWS = 640
+PAIR_PLAN_PHYSICAL_K = True
 
 
 def plan_splits(N, K, plan=None):
     """split-K factor of a plain bf16 GEMM with this (N, K) under `plan` (default: the active plan); a function of (N, K) only"""
     plan = plan or _PLAN[0]
+    if PAIR_PLAN_PHYSICAL_K:
+        K = K * SP()   # operand-pair build: a logical k-value is two physical ones, and the K-steps the rule counts are physical (round 6)
     if plan == "throughput" or K < 2048:
         return 1
     t128 = -(-_PLAN_REF_ROWS // 128) * -(-N // 128)

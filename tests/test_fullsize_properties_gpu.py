@@ -82,6 +82,27 @@ def test_batch_independence_bitwise(big, plan):
         m.gemm_plan = old
 
 
+def test_batch_independence_bitwise_benchmarked_build_latency_plan(dev):
+    """the benchmarked build (precision="hybrid-fp16": the ViT on operand pairs) under the latency plan -- in the pair build the plan
+    counts PHYSICAL k-values (round 6), so the ViT's K = 1024 GEMMs are split in two and fc2 in eight: an image's logits and index
+    results still do not depend on its batch mates, bit for bit (the factors are a function of (N, K) and the build, never of M)."""
+    from groma_amd import config, constants, ops, synth
+    from groma_amd.groma import GromaModel
+    cfg = config.groma_7b(box_score_thres=0.0)
+    m = GromaModel.from_synthetic(cfg, seed=0, device=dev, precision="hybrid-fp16")
+    m.init_special_token_id(constants.SyntheticTokenizer())
+    images, ids = synth.make_inputs(cfg, m, 3, seed=99)
+    with ops.precision("ref"), ops.gemm_plan("latency"):
+        assert [ops.plan_splits(N, K) for N, K in ((3072, 1024), (1024, 1024), (4096, 1024), (1024, 4096))] == [2, 2, 2, 8]
+    m.gemm_plan = "latency"
+
+    def check(i, single, batched):
+        assert torch.equal(single, batched), f"image {i}: logits depend on batch mates (hybrid-fp16, latency plan)"
+    _batch_vs_single(m, images.to(dev), ids.to(dev), check)
+    del m
+    torch.cuda.empty_cache()
+
+
 def test_plans_agree_to_bf16_noise(big):
     """"latency" splits the o-proj / down-proj / fc2 / bridge GEMMs along K: fp32 sums in another order, so the bf16 roundings
     behind them differ at noise level from the "throughput" plan.  Checked stage by stage on identical stage inputs: the ViT
