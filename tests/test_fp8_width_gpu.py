@@ -270,6 +270,8 @@ def test_fp8_chained_logits_and_vit_states_at_width(f8):
     assert e_b16d < 1e-1 and e_f32 < 1e-1
     # the implementation is closer to its own oracle than the format is to bf16 (measured 4.7e-2: two e4m3 evaluations whose fp32
     # sums differ in the last bits re-quantise a few values one e4m3 step apart, and every later stage amplifies that)
+    # -- tests/test_oracle_rounding_modes.py::test_a_rounded_evaluation_is_sensitive_to_its_last_input_bits shows the same ratio between the
+    # e4m3-rounded oracle and ITSELF with its input perturbed by 1e-6: 3.6-4.7e-2 of a 1.0e-1 format distance (CPU, no device involved)
     assert e_impl < 0.6 * e_b16d
     assert abs(e_b16d - o_fmt) < 0.5 * o_fmt       # and the device's format error is the oracle's format error
     # the stated tolerance relative to what is MEASURED -- the device may exceed the e4m3 FORMAT's own distance
