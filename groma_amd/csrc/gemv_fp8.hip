@@ -98,7 +98,7 @@ __global__ __launch_bounds__(256, G8_WG_PER_CU) void gemv_fp8_kernel(GemvFArgs p
   // down 20.3 -> 15.4, all streams of a token 2.66 -> 2.16 ms without a prologue; profiles/r06_gemv_w8_decomp.txt).  Unconditional
   // (waves without a slice re-read the row's last block: `load` clamps) so that the compiler can COUNT the loads it may leave in flight.
   auto first_slices = [&]() {
-#ifdef G8_FIRST_BARRIER
+#ifdef G8_FIRST_BARRIER  // (tests/diag A/B, measured flat -- `bar` rows of profiles/r06_gemv_w8_decomp.txt: the order inside a wave is what matters)
     __syncthreads();  // every wave of the workgroup has issued its operand loads before any weight slice is requested
 #endif
     load(0, wA);
