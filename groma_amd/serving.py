@@ -358,9 +358,13 @@ class ContinuousBatcher:
             dev = self.tok.device
             src = torch.tensor(rows, dtype=I64, device=dev)
             dst = torch.tensor(slots, dtype=I64, device=dev)
+            # only the prefix the prompts fill (whole 64-position blocks: a prefix in the pair layout too): what lies behind a row's
+            # position is rewritten by its own decode steps before it is ever attended to
+            n = min(self.max_len, -(-max(r.prompt_len for r, _, _, _ in placed if r.slot is not None) // 64) * 64)
+            sp = getattr(self.arena, "sp", 1)
             for l in range(len(self.arena.k)):
-                self.arena.k[l].index_copy_(0, dst, self.staging.k[l].index_select(0, src))
-                self.arena.vt[l].index_copy_(0, dst, self.staging.vt[l].index_select(0, src))
+                self.arena.k[l][:, :, :n].index_copy_(0, dst, self.staging.k[l][:, :, :n].index_select(0, src))
+                self.arena.vt[l][..., : n * sp].index_copy_(0, dst, self.staging.vt[l][..., : n * sp].index_select(0, src))
 
     # ------------------------------------------------------------------ overlapped admission (worker thread + side stream)
     def _launch_admission(self, reqs):
