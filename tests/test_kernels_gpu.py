@@ -48,6 +48,44 @@ def test_gemm_plain(dev, M, N, K, tile):
     assert torch.equal(out16, ops.gemm(a, w, tile=192))
 
 
+def test_pipelined_attention_loop_is_bitwise_the_plain_loop(dev, tmp_path):
+    """csrc/attention.hip built with -DATT_PIPE=1 -- the interleaved loop VERDICT r05 asked for (score MFMAs of tile t + 1 between the
+    soft-max instructions of tile t; measured slower and therefore off) -- performs the same operations in the same order per
+    accumulator: its outputs equal the product library's bit for bit (causal + ragged + RoPE-free shapes, both head dims).  The variant
+    is compiled here (one source, ~40 s) and linked against the product's other objects; skipped where hipcc or the objects are absent."""
+    import os, shutil, subprocess
+    from groma_amd import _lib
+    from groma_amd.csrc import build as B
+    ops = _ops()
+    if shutil.which("hipcc") is None:
+        pytest.skip("hipcc not on PATH")
+    objs = [os.path.join(B.HERE, src.replace(".hip", ".o")) for src in B.SOURCES]
+    if not all(os.path.exists(o) for o in objs):
+        pytest.skip("the product's object files are not in the tree")
+    att = str(tmp_path / "attention_pipe.o")
+    so = str(tmp_path / "libgroma_hip_attpipe.so")
+    subprocess.check_call(["hipcc"] + B.COMMON + B.SOURCES["attention.hip"] + ["-DATT_PIPE=1", "-c", os.path.join(B.HERE, "attention.hip"), "-o", att])
+    subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", so] +
+                          [att if o.endswith("attention.o") else o for o in objs])
+    pipe, plain = _lib._open(so, 0), _lib.load()
+    cases = [(2, 4, 582, 582, 128, True, None), (1, 3, 1025, 1025, 64, False, None), (3, 2, 200, 200, 128, True, [200, 131, 64]),
+             (1, 2, 70, 70, 64, False, None)]
+    try:
+        for B_, H, Lq, S, hd, causal, lens in cases:
+            stride = (S + 63) // 64 * 64
+            q = rnd((B_, H, Lq, hd), dev, seed=1).bfloat16()
+            k = rnd((B_, H, stride, hd), dev, seed=2).bfloat16()
+            vt = rnd((B_, H, hd, stride), dev, seed=3).bfloat16()
+            kv_len = torch.tensor(lens, dtype=torch.int32, device=dev) if lens else None
+            _lib._lib = plain
+            want = ops.attention(q, k, vt, Skv=S, causal=causal, kv_len=kv_len).clone()
+            _lib._lib = pipe
+            got = ops.attention(q, k, vt, Skv=S, causal=causal, kv_len=kv_len)
+            assert torch.equal(got, want), (B_, H, Lq, S, hd, causal)
+    finally:
+        _lib._lib = plain
+
+
 def test_gemm_yield_grid_is_per_thread_and_changes_no_bit(dev):
     """gr_gemm_yield (round 6): the ping-pong GEMM as one workgroup per tile instead of a persistent grid -- same tiles, same bits, for
     the plain and the implicit-conv forms; the switch is per thread (the serving loop's admission worker uses it beside a decode thread
